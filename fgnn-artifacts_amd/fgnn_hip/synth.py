@@ -1,0 +1,95 @@
+"""Synthetic datasets in the reference's on-disk layout (samgraph/common/engine.cc:73-264).
+
+No real dataset can be downloaded here, so every test and bench input is generated: a CSR whose row
+degrees follow a truncated power law and whose neighbour ids are skewed towards low ids (hubs),
+which reproduces the two properties the hot path is sensitive to: many rows longer than the
+fanout, and heavy duplication among sampled neighbours.
+"""
+import os
+
+import numpy as np
+
+# datagen/products.py:92-98, datagen/papers100M.py:88-94, datagen/twitter.sh:35-43, datagen/uk-2006-05.sh:35-43
+DATASET_SHAPES = {
+    "products": dict(num_node=2449029, num_edge=123718152, feat_dim=100, num_class=47, num_train=196615),
+    "papers100M": dict(num_node=111059956, num_edge=1615685872, feat_dim=128, num_class=172, num_train=1207179),
+    "twitter": dict(num_node=41652230, num_edge=1468365182, feat_dim=256, num_class=150, num_train=416500),
+    "uk-2006-05": dict(num_node=77741046, num_edge=2965197340, feat_dim=256, num_class=150, num_train=1000000),
+}
+
+
+def powerlaw_degrees(num_node, num_edge, rng, alpha=1.8, zero_frac=0.02):
+    """Degrees ~ Pareto(alpha) scaled so that they sum to num_edge exactly; a few isolated rows."""
+    raw = rng.pareto(alpha, size=num_node) + 0.05
+    raw[rng.random(num_node) < zero_frac] = 0.0
+    deg = np.floor(raw * (num_edge / raw.sum())).astype(np.int64)
+    short = int(num_edge - deg.sum())
+    if short > 0:
+        bump = rng.integers(0, num_node, size=short)
+        np.add.at(deg, bump, 1)
+    return deg
+
+
+def powerlaw_csr(num_node, num_edge, seed=42, alpha=1.8, skew=2.0):
+    """Returns (indptr u32[N+1], indices u32[E]).  Row = destination/seed, entries = sources."""
+    rng = np.random.default_rng(seed)
+    deg = powerlaw_degrees(num_node, num_edge, rng, alpha)
+    indptr = np.zeros(num_node + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    assert indptr[-1] == num_edge and num_edge < 2**32
+    u = rng.random(num_edge)
+    indices = np.minimum((num_node * u**skew).astype(np.int64), num_node - 1)
+    # scatter hub ids over the id space so that hash-table and cache behaviour is not id-ordered
+    perm_mul = 2654435761 % num_node
+    while np.gcd(perm_mul, num_node) != 1:
+        perm_mul += 1
+    indices = (indices * perm_mul) % num_node
+    return indptr.astype(np.uint32), indices.astype(np.uint32)
+
+
+def prob_prefix_table(indptr, indices, seed=7):
+    """Per-row inclusive prefix sums of edge weights (create_prob_prefix_table.cc:83-124):
+    weight 100 if out-degree(src) < 10 else 1."""
+    num_node = len(indptr) - 1
+    out_deg = np.bincount(indices, minlength=num_node)
+    w = np.where(out_deg[indices] < 10, 100.0, 1.0).astype(np.float32)
+    prefix = np.empty_like(w)
+    ip = indptr.astype(np.int64)
+    for r in range(num_node):
+        a, b = ip[r], ip[r + 1]
+        if b > a:
+            acc = np.float32(0)
+            for k in range(a, b):  # sequential f32 accumulation like the tool
+                acc = np.float32(acc + w[k])
+                prefix[k] = acc
+    return prefix
+
+
+def node_features(num_node, dim, seed=3, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((num_node, dim), dtype=np.float32).astype(dtype)
+
+
+def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train, num_valid=0, num_test=0,
+                  seed=42, with_prefix=False):
+    """Writes <root>/<name>/{meta.txt,indptr.bin,indices.bin,feat.bin,label.bin,*_set.bin}."""
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    indptr, indices = powerlaw_csr(num_node, num_edge, seed)
+    rng = np.random.default_rng(seed + 1)
+    perm = rng.permutation(num_node).astype(np.uint32)
+    train, valid, test = perm[:num_train], perm[num_train:num_train + num_valid], \
+        perm[num_train + num_valid:num_train + num_valid + num_test]
+    indptr.tofile(os.path.join(d, "indptr.bin"))
+    indices.tofile(os.path.join(d, "indices.bin"))
+    node_features(num_node, feat_dim, seed + 2).tofile(os.path.join(d, "feat.bin"))
+    rng.integers(0, num_class, size=num_node, dtype=np.uint64).tofile(os.path.join(d, "label.bin"))
+    train.tofile(os.path.join(d, "train_set.bin"))
+    valid.tofile(os.path.join(d, "valid_set.bin"))
+    test.tofile(os.path.join(d, "test_set.bin"))
+    if with_prefix:
+        prob_prefix_table(indptr, indices).tofile(os.path.join(d, "prob_prefix_table.bin"))
+    with open(os.path.join(d, "meta.txt"), "w") as f:
+        f.write(f"NUM_NODE {num_node}\nNUM_EDGE {num_edge}\nFEAT_DIM {feat_dim}\nNUM_CLASS {num_class}\n"
+                f"NUM_TRAIN_SET {len(train)}\nNUM_VALID_SET {len(valid)}\nNUM_TEST_SET {len(test)}\n")
+    return d

@@ -1,0 +1,615 @@
+/*
+ * fgnn_oracle.c -- CPU restatement of the SamGraph hot path.  TEST INFRASTRUCTURE ONLY
+ * (see fgnn_oracle.h).  Plain C11, no dependencies; `make -C oracle` builds libfgnn_oracle.so.
+ *
+ * Pinning status: the RNG-free stages and the mt19937 "CPU twin" mode are checked bit-for-bit
+ * against outputs of the reference's own CPU sources compiled in the build container
+ * (oracle/Makefile target `_ref`, fixtures under tests/golden/, generator
+ * tests/golden/make_golden.py).  The Philox mode shares every line of the sampling / dedup /
+ * remap / cache / gather code with the twin mode and differs only in where a draw comes from.
+ */
+#include "fgnn_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ Philox4x32-10 ---------- */
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+void fgnn_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += PHILOX_W0;
+    k1 += PHILOX_W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void fgnn_philox_draw(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t draw,
+                      uint32_t out[4]) {
+  uint32_t ctr[4] = {draw, item, tag, (uint32_t)batch_key};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(batch_key >> 32)};
+  fgnn_philox4x32_10(ctr, key, out);
+}
+
+/* ------------------------------------------------------------------ mt19937 ---------------- */
+
+void fgnn_mt19937_seed(fgnn_mt19937 *g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i)
+    g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+
+uint32_t fgnn_mt19937_next(fgnn_mt19937 *g) {
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      uint32_t v = g->mt[(i + 397) % 624] ^ (y >> 1);
+      if (y & 1u) v ^= 0x9908b0dfu;
+      g->mt[i] = v;
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+/* libstdc++-11 bits/uniform_int_dist.h: for a generator spanning exactly 32 bits the
+ * distribution uses Lemire's nearly-divisionless method (_S_nd) on 64-bit products. */
+uint32_t fgnn_mt19937_uniform_int(fgnn_mt19937 *g, uint32_t lo, uint32_t hi) {
+  uint32_t urange = hi - lo;
+  if (urange == 0xFFFFFFFFu) return fgnn_mt19937_next(g) + lo;
+  uint32_t range = urange + 1u;
+  uint64_t product = (uint64_t)fgnn_mt19937_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    uint32_t threshold = (0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)fgnn_mt19937_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32) + lo;
+}
+
+void fgnn_rng_init(fgnn_rng *r, int mode, uint64_t seed) {
+  r->mode = mode;
+  r->seed = seed;
+  fgnn_mt19937_seed(&r->mt, 5489u); /* default-constructed std::mt19937, cpu_random.cc:27 */
+}
+
+/* ------------------------------------------------------------------ helpers ---------------- */
+
+size_t fgnn_predict_num_nodes(size_t batch_size, const size_t *fanout, size_t num_fanout_to_comp) {
+  size_t count = batch_size;
+  for (long i = (long)num_fanout_to_comp - 1; i >= 0; --i) count += count * fanout[i];
+  return count;
+}
+
+size_t fgnn_table_size(size_t num, size_t scale) {
+  /* 1 << (size_t)(1 + log2(num >> 1)) with the double log2 of the reference == position of the
+   * highest set bit of (num >> 1), plus one. */
+  size_t half = num >> 1;
+  size_t lg = 0;
+  while ((half >> (lg + 1)) != 0) ++lg; /* floor(log2(half)) for half >= 1 */
+  size_t next_pow2 = (size_t)1 << (1 + lg);
+  return next_pow2 << scale;
+}
+
+size_t fgnn_dtype_bytes(int dtype) {
+  switch (dtype) {
+    case FGNN_I8:
+    case FGNN_U8: return 1;
+    case FGNN_F16: return 2;
+    case FGNN_F32:
+    case FGNN_I32: return 4;
+    case FGNN_I64:
+    case FGNN_F64: return 8;
+    default: return 4;
+  }
+}
+
+static uint32_t khop_tag(int sample_type, uint32_t layer) { return ((uint32_t)sample_type << 8) | (layer & 0xffu); }
+
+/* compaction shared by khop0 / khop2: std::remove_if(kEmptyKey) over the padded
+ * [num_input x fanout] arrays (cpu_sampling_khop0.cc:69-80) == count_edge + compact_edge
+ * (cuda_sampling_khop0.cu:92-174). */
+static size_t compact_padded(uint32_t *src, uint32_t *dst, size_t n) {
+  size_t w = 0;
+  for (size_t r = 0; r < n; ++r) {
+    if (src[r] != FGNN_EMPTY_KEY) {
+      src[w] = src[r];
+      dst[w] = dst[r];
+      ++w;
+    }
+  }
+  return w;
+}
+
+/* ------------------------------------------------------------------ khop0 ------------------ */
+
+void fgnn_oracle_sample_khop0(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                              size_t num_input, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                              size_t *num_out, fgnn_rng *rng, uint64_t batch_key, uint32_t layer) {
+  const uint32_t tag = khop_tag(FGNN_KHOP0, layer);
+  for (size_t i = 0; i < num_input; ++i) {
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    uint32_t *s = out_src + i * fanout;
+    uint32_t *d = out_dst + i * fanout;
+    if (len <= fanout) {
+      size_t j = 0;
+      for (; j < len; ++j) { s[j] = rid; d[j] = indices[off + j]; }
+      for (; j < fanout; ++j) { s[j] = FGNN_EMPTY_KEY; d[j] = FGNN_EMPTY_KEY; }
+    } else {
+      for (size_t j = 0; j < fanout; ++j) { s[j] = rid; d[j] = indices[off + j]; }
+      for (size_t j = fanout; j < len; ++j) {
+        uint32_t k;
+        if (rng->mode == FGNN_RNG_MT_CPU_TWIN) {
+          /* cpu_sampling_khop0.cc:61: RandomID(0, j + 1), bounds inclusive */
+          k = fgnn_mt19937_uniform_int(&rng->mt, 0, (uint32_t)(j + 1));
+        } else {
+          /* cuda_sampling_khop0.cu:80: curand() % (j + 1) */
+          uint32_t r[4];
+          fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
+          k = r[0] % (uint32_t)(j + 1);
+        }
+        if (k < fanout) d[k] = indices[off + j];
+      }
+    }
+  }
+  *num_out = compact_padded(out_src, out_dst, num_input * fanout);
+}
+
+/* ------------------------------------------------------------------ khop2 ------------------ */
+
+void fgnn_oracle_sample_khop2(const uint32_t *indptr, uint32_t *indices, const uint32_t *input,
+                              size_t num_input, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                              size_t *num_out, fgnn_rng *rng, uint64_t batch_key, uint32_t layer) {
+  const uint32_t tag = khop_tag(FGNN_KHOP2, layer);
+  for (size_t i = 0; i < num_input; ++i) {
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    uint32_t *s = out_src + i * fanout;
+    uint32_t *d = out_dst + i * fanout;
+    if (len <= fanout) {
+      size_t j = 0;
+      for (; j < len; ++j) { s[j] = rid; d[j] = indices[off + j]; }
+      for (; j < fanout; ++j) { s[j] = FGNN_EMPTY_KEY; d[j] = FGNN_EMPTY_KEY; }
+    } else {
+      for (size_t j = 0; j < fanout; ++j) {
+        uint32_t sel;
+        if (rng->mode == FGNN_RNG_MT_CPU_TWIN) {
+          /* cpu_sampling_khop2.cc:57: RandomID(0, len - j - 1) */
+          sel = fgnn_mt19937_uniform_int(&rng->mt, 0, (uint32_t)(len - j - 1));
+        } else {
+          /* cuda_sampling_khop2.cu:75: curand() % (len - j) */
+          uint32_t r[4];
+          fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
+          sel = r[0] % (uint32_t)(len - j);
+        }
+        const uint32_t picked = indices[off + sel];
+        s[j] = rid;
+        d[j] = picked;
+        /* swap indices[off+sel] <-> indices[off+len-j-1] (khop2.cu:80-82) */
+        indices[off + sel] = indices[off + len - j - 1];
+        indices[off + len - j - 1] = picked;
+      }
+    }
+  }
+  *num_out = compact_padded(out_src, out_dst, num_input * fanout);
+}
+
+/* ------------------------------------------------------------------ weighted prefix -------- */
+
+static float philox_uniform_float(uint32_t x) {
+  /* (0,1], 24 significant bits -- stands in for curand_uniform (which is also (0,1]) */
+  return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);
+}
+
+static double philox_uniform_double(uint32_t x) {
+  /* (0,1) -- stands in for curand_uniform_double */
+  return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+
+typedef struct { uint32_t src, dst; size_t ord; } pair_ord;
+static int cmp_pair_src_stable(const void *a, const void *b) {
+  const pair_ord *x = (const pair_ord *)a, *y = (const pair_ord *)b;
+  if (x->src != y->src) return x->src < y->src ? -1 : 1;
+  if (x->ord != y->ord) return x->ord < y->ord ? -1 : 1;
+  return 0;
+}
+
+void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices,
+                                             const float *prob_prefix, const uint32_t *input,
+                                             size_t num_input, size_t fanout, uint32_t *out_src,
+                                             uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
+                                             uint64_t batch_key, uint32_t layer) {
+  const uint32_t tag = khop_tag(FGNN_WEIGHTED_KHOP_PREFIX, layer);
+  const size_t num_task = num_input * fanout;
+  pair_ord *tmp = (pair_ord *)malloc(sizeof(pair_ord) * (num_task ? num_task : 1));
+  if (rng->mode != FGNN_RNG_PHILOX) abort(); /* no CPU twin exists in the reference */
+  for (size_t t = 0; t < num_task; ++t) {
+    const size_t i = t / fanout, j = t % fanout;
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    tmp[t].ord = t;
+    if (len == 0) {
+      tmp[t].src = FGNN_EMPTY_KEY;
+      tmp[t].dst = FGNN_EMPTY_KEY;
+      continue;
+    }
+    const float upbound = prob_prefix[off + len - 1];
+    uint32_t r[4];
+    fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
+    const float x = philox_uniform_float(r[0]) * upbound;
+    uint32_t pick;
+    if (x <= prob_prefix[off]) {
+      pick = indices[off];
+    } else {
+      size_t lo = off, hi = (size_t)off + len - 1;
+      while (hi - lo >= 2) {
+        size_t mid = (lo + hi) >> 1;
+        if (prob_prefix[mid] >= x) hi = mid; else lo = mid;
+      }
+      pick = indices[hi];
+    }
+    tmp[t].src = rid;
+    tmp[t].dst = pick;
+  }
+  /* cub::DeviceRadixSort::SortPairs(key = src, val = dst): stable, ascending, kEmptyKey last */
+  qsort(tmp, num_task, sizeof(pair_ord), cmp_pair_src_stable);
+  size_t w = 0;
+  for (size_t t = 0; t < num_task; ++t) {
+    int keep;
+    if (t + 1 < num_task)
+      keep = (tmp[t].src != tmp[t + 1].src || tmp[t].dst != tmp[t + 1].dst) && tmp[t].src != FGNN_EMPTY_KEY;
+    else
+      keep = tmp[t].src != FGNN_EMPTY_KEY;
+    if (keep) { out_src[w] = tmp[t].src; out_dst[w] = tmp[t].dst; ++w; }
+  }
+  *num_out = w;
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------ random walk + top-K ---- */
+
+typedef struct { uint32_t dst, count; size_t first; } visit_cnt;
+static int cmp_visit(const void *a, const void *b) {
+  const visit_cnt *x = (const visit_cnt *)a, *y = (const visit_cnt *)b;
+  if (x->count != y->count) return x->count > y->count ? -1 : 1;
+  if (x->first != y->first) return x->first < y->first ? -1 : 1;
+  return 0;
+}
+
+void fgnn_oracle_sample_random_walk(const uint32_t *indptr, const uint32_t *indices,
+                                    const uint32_t *input, size_t num_input, size_t walk_len,
+                                    double restart_prob, size_t num_walks, size_t K,
+                                    uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data,
+                                    size_t *num_out, fgnn_rng *rng, uint64_t batch_key,
+                                    uint32_t layer) {
+  const uint32_t tag = khop_tag(FGNN_RANDOM_WALK, layer);
+  const size_t per_node = num_walks * walk_len;
+  uint32_t *visited = (uint32_t *)malloc(sizeof(uint32_t) * (per_node ? per_node : 1));
+  visit_cnt *cnt = (visit_cnt *)malloc(sizeof(visit_cnt) * (per_node ? per_node : 1));
+  if (rng->mode != FGNN_RNG_PHILOX) abort();
+  size_t w = 0;
+  for (size_t i = 0; i < num_input; ++i) {
+    const uint32_t start = input[i];
+    /* layout pos = step * num_walks + walk (cuda_sampling_random_walk.cu:77-78) */
+    for (size_t walk = 0; walk < num_walks; ++walk) {
+      uint32_t node = start;
+      for (size_t step = 0; step < walk_len; ++step) {
+        const size_t pos = step * num_walks + walk;
+        if (node == FGNN_EMPTY_KEY) { visited[pos] = FGNN_EMPTY_KEY; continue; }
+        const uint32_t off = indptr[node];
+        const uint32_t len = indptr[node + 1] - off;
+        if (len == 0) { visited[pos] = FGNN_EMPTY_KEY; node = FGNN_EMPTY_KEY; continue; }
+        uint32_t r[4];
+        fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)(walk * walk_len + step), r);
+        const uint32_t k = r[0] % len;
+        node = indices[off + k];
+        visited[pos] = node;
+        if (philox_uniform_double(r[1]) < restart_prob) node = FGNN_EMPTY_KEY;
+      }
+    }
+    /* FrequencyHashmap::GetTopK: distinct (seed, dst) with counts, (count desc, first pos asc) */
+    size_t nd = 0;
+    for (size_t p = 0; p < per_node; ++p) {
+      if (visited[p] == FGNN_EMPTY_KEY) continue;
+      size_t q = 0;
+      for (; q < nd; ++q) if (cnt[q].dst == visited[p]) break;
+      if (q == nd) { cnt[nd].dst = visited[p]; cnt[nd].count = 1; cnt[nd].first = p; ++nd; }
+      else cnt[q].count++;
+    }
+    qsort(cnt, nd, sizeof(visit_cnt), cmp_visit);
+    const size_t take = nd < K ? nd : K;
+    for (size_t q = 0; q < take; ++q) {
+      out_src[w] = start;
+      out_dst[w] = cnt[q].dst;
+      out_data[w] = cnt[q].count;
+      ++w;
+    }
+  }
+  *num_out = w;
+  free(visited);
+  free(cnt);
+}
+
+/* ------------------------------------------------------------------ hashtable -------------- */
+
+fgnn_oracle_ht *fgnn_oracle_ht_create(size_t num_node, size_t capacity) {
+  fgnn_oracle_ht *ht = (fgnn_oracle_ht *)calloc(1, sizeof(*ht));
+  ht->o2n = (uint32_t *)malloc(sizeof(uint32_t) * (num_node ? num_node : 1));
+  ht->n2o = (uint32_t *)malloc(sizeof(uint32_t) * (capacity ? capacity : 1));
+  ht->num_node = num_node;
+  ht->capacity = capacity;
+  ht->num_items = 0;
+  memset(ht->o2n, 0xFF, sizeof(uint32_t) * num_node);
+  return ht;
+}
+
+void fgnn_oracle_ht_destroy(fgnn_oracle_ht *ht) {
+  if (!ht) return;
+  free(ht->o2n);
+  free(ht->n2o);
+  free(ht);
+}
+
+void fgnn_oracle_ht_reset(fgnn_oracle_ht *ht) {
+  for (size_t i = 0; i < ht->num_items; ++i) ht->o2n[ht->n2o[i]] = FGNN_EMPTY_KEY;
+  ht->num_items = 0;
+}
+
+int fgnn_oracle_ht_fill_unique(fgnn_oracle_ht *ht, const uint32_t *items, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    if (ht->o2n[items[i]] != FGNN_EMPTY_KEY) return -1;
+    const uint32_t local = (uint32_t)(ht->num_items + i);
+    ht->o2n[items[i]] = local;
+    ht->n2o[local] = items[i];
+  }
+  ht->num_items += n;
+  return 0;
+}
+
+void fgnn_oracle_ht_fill_duplicates(fgnn_oracle_ht *ht, const uint32_t *items, size_t n,
+                                    uint32_t *unique, size_t *num_unique) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t id = items[i];
+    if (ht->o2n[id] == FGNN_EMPTY_KEY) {
+      const uint32_t local = (uint32_t)ht->num_items++;
+      ht->o2n[id] = local;
+      ht->n2o[local] = id;
+    }
+  }
+  if (unique) memcpy(unique, ht->n2o, sizeof(uint32_t) * ht->num_items);
+  *num_unique = ht->num_items;
+}
+
+void fgnn_oracle_map_edges(const fgnn_oracle_ht *ht, const uint32_t *src, const uint32_t *dst, size_t n,
+                           uint32_t *new_src, uint32_t *new_dst) {
+  for (size_t i = 0; i < n; ++i) {
+    new_src[i] = ht->o2n[src[i]];
+    new_dst[i] = ht->o2n[dst[i]];
+  }
+}
+
+/* ------------------------------------------------------------------ batch driver ----------- */
+
+fgnn_oracle_task *fgnn_oracle_do_sample(const uint32_t *indptr, uint32_t *indices,
+                                        const float *prob_prefix, const fgnn_oracle_sample_cfg *cfg,
+                                        fgnn_oracle_ht *ht, const uint32_t *seeds, size_t num_seeds,
+                                        fgnn_rng *rng, uint64_t batch_key) {
+  fgnn_oracle_task *task = (fgnn_oracle_task *)calloc(1, sizeof(*task));
+  const size_t L = cfg->num_layers;
+  task->num_layers = L;
+  task->graphs = (fgnn_oracle_graph *)calloc(L ? L : 1, sizeof(fgnn_oracle_graph));
+
+  fgnn_oracle_ht_reset(ht);
+  if (fgnn_oracle_ht_fill_unique(ht, seeds, num_seeds) != 0) abort();
+
+  uint32_t *cur_input = (uint32_t *)malloc(sizeof(uint32_t) * (num_seeds ? num_seeds : 1));
+  memcpy(cur_input, seeds, sizeof(uint32_t) * num_seeds);
+  size_t num_input = num_seeds;
+
+  for (long i = (long)L - 1; i >= 0; --i) {
+    const size_t fanout = cfg->fanout[i];
+    const size_t cap = num_input * fanout;
+    uint32_t *out_src = (uint32_t *)malloc(sizeof(uint32_t) * (cap ? cap : 1));
+    uint32_t *out_dst = (uint32_t *)malloc(sizeof(uint32_t) * (cap ? cap : 1));
+    uint32_t *out_data = NULL;
+    size_t num_out = 0;
+    switch (cfg->sample_type) {
+      case FGNN_KHOP0:
+        fgnn_oracle_sample_khop0(indptr, indices, cur_input, num_input, fanout, out_src, out_dst, &num_out,
+                                 rng, batch_key, (uint32_t)i);
+        break;
+      case FGNN_KHOP2:
+        fgnn_oracle_sample_khop2(indptr, indices, cur_input, num_input, fanout, out_src, out_dst, &num_out,
+                                 rng, batch_key, (uint32_t)i);
+        break;
+      case FGNN_WEIGHTED_KHOP_PREFIX:
+        fgnn_oracle_sample_weighted_khop_prefix(indptr, indices, prob_prefix, cur_input, num_input, fanout,
+                                                out_src, out_dst, &num_out, rng, batch_key, (uint32_t)i);
+        break;
+      case FGNN_RANDOM_WALK:
+        out_data = (uint32_t *)malloc(sizeof(uint32_t) * (cap ? cap : 1));
+        fgnn_oracle_sample_random_walk(indptr, indices, cur_input, num_input, cfg->walk_len,
+                                       cfg->restart_prob, cfg->num_walks, cfg->num_neighbor, out_src,
+                                       out_dst, out_data, &num_out, rng, batch_key, (uint32_t)i);
+        break;
+      default:
+        abort();
+    }
+    size_t num_unique = 0;
+    uint32_t *unique = (uint32_t *)malloc(sizeof(uint32_t) * (num_out + ht->num_items + 1));
+    fgnn_oracle_ht_fill_duplicates(ht, out_dst, num_out, unique, &num_unique);
+
+    uint32_t *new_src = (uint32_t *)malloc(sizeof(uint32_t) * (num_out ? num_out : 1));
+    uint32_t *new_dst = (uint32_t *)malloc(sizeof(uint32_t) * (num_out ? num_out : 1));
+    fgnn_oracle_map_edges(ht, out_src, out_dst, num_out, new_src, new_dst);
+
+    fgnn_oracle_graph *g = &task->graphs[i];
+    g->num_src = num_unique;   /* cuda_loops.cc:211 */
+    g->num_dst = num_input;    /* :212 */
+    g->num_edge = num_out;     /* :213 */
+    g->col = new_src;          /* :214-217 col = new_src */
+    g->row = new_dst;          /* :218-221 row = new_dst */
+    g->data = out_data;
+    task->total_edges += num_out;
+
+    free(out_src);
+    free(out_dst);
+    free(cur_input);
+    cur_input = unique;
+    num_input = num_unique;
+  }
+  task->input_nodes = cur_input;
+  task->num_input_nodes = num_input;
+  return task;
+}
+
+void fgnn_oracle_task_free(fgnn_oracle_task *t) {
+  if (!t) return;
+  for (size_t i = 0; i < t->num_layers; ++i) {
+    free(t->graphs[i].row);
+    free(t->graphs[i].col);
+    free(t->graphs[i].data);
+  }
+  free(t->graphs);
+  free(t->input_nodes);
+  free(t);
+}
+
+/* ------------------------------------------------------------------ cache + gather --------- */
+
+void fgnn_oracle_cache_table_build(const uint32_t *ranking_nodes, size_t num_cached, size_t num_node,
+                                   uint32_t *table) {
+  for (size_t i = 0; i < num_node; ++i) table[i] = FGNN_EMPTY_KEY;
+  for (size_t i = 0; i < num_cached; ++i) table[ranking_nodes[i]] = (uint32_t)i;
+}
+
+void fgnn_oracle_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size_t n,
+                                      uint32_t *miss_src, uint32_t *miss_dst, size_t *num_miss,
+                                      uint32_t *cache_src, uint32_t *cache_dst, size_t *num_cache) {
+  size_t nm = 0, nc = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t slot = table[nodes[i]];
+    if (slot == FGNN_EMPTY_KEY) {
+      miss_dst[nm] = (uint32_t)i;   /* position in the batch (cuda_cache.cu:102) */
+      miss_src[nm] = nodes[i];      /* global node id        (cuda_cache.cu:104) */
+      ++nm;
+    } else {
+      cache_dst[nc] = (uint32_t)i;  /* cuda_cache.cu:145 */
+      cache_src[nc] = slot;         /* cache slot, cuda_cache.cu:147 */
+      ++nc;
+    }
+  }
+  *num_miss = nm;
+  *num_cache = nc;
+}
+
+void fgnn_oracle_extract(void *dst, const void *src, const uint32_t *index, size_t num_index, size_t dim,
+                         int dtype) {
+  const size_t row = dim * fgnn_dtype_bytes(dtype);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < num_index; ++i)
+    memcpy((char *)dst + i * row, (const char *)src + (size_t)index[i] * row, row);
+}
+
+void fgnn_oracle_combine(void *out, const void *rows, const uint32_t *src_index, const uint32_t *dst_index,
+                         size_t n, size_t dim, int dtype) {
+  const size_t row = dim * fgnn_dtype_bytes(dtype);
+  for (size_t i = 0; i < n; ++i) {
+    const size_t s = src_index ? src_index[i] : i;
+    memcpy((char *)out + (size_t)dst_index[i] * row, (const char *)rows + s * row, row);
+  }
+}
+
+static int cmp_u64_desc(const void *a, const void *b) {
+  const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x > y ? -1 : (x < y ? 1 : 0);
+}
+
+void fgnn_oracle_presample_rank(const uint32_t *freq, size_t num_node, uint32_t *ranking_nodes) {
+  uint64_t *t = (uint64_t *)malloc(sizeof(uint64_t) * (num_node ? num_node : 1));
+  for (size_t i = 0; i < num_node; ++i) t[i] = ((uint64_t)freq[i] << 32) | (uint64_t)i;
+  qsort(t, num_node, sizeof(uint64_t), cmp_u64_desc);
+  for (size_t i = 0; i < num_node; ++i) ranking_nodes[i] = (uint32_t)t[i];
+  free(t);
+}
+
+/* ------------------------------------------------------------------ shufflers -------------- */
+
+/* std::minstd_rand0: x <- 16807 x mod (2^31 - 1); seed 0 maps to 1; min 1, max 2^31-2. */
+static uint64_t minstd0_next(uint64_t *x) {
+  *x = (*x * 16807ull) % 2147483647ull;
+  return *x;
+}
+
+void fgnn_oracle_shuffle_minstd0(uint32_t *data, size_t n, uint64_t seed) {
+  uint64_t x = seed % 2147483647ull;
+  if (x == 0) x = 1;
+  const uint64_t urngmin = 1, urngrange = 2147483646ull - 1ull; /* max - min */
+  for (size_t i = n - 1; n > 0 && i > 0; --i) {
+    /* uniform_int_distribution<size_t>(0, i)(g), libstdc++-11 bits/uniform_int_dist.h:294-359 */
+    const uint64_t urange = (uint64_t)i;
+    uint64_t ret;
+    if (urngrange > urange) {
+      const uint64_t uerange = urange + 1;
+      const uint64_t scaling = urngrange / uerange;
+      const uint64_t past = uerange * scaling;
+      do ret = minstd0_next(&x) - urngmin; while (ret >= past);
+      ret /= scaling;
+    } else if (urngrange < urange) {
+      /* upscaling: never reached for train sets < 2^31 items */
+      abort();
+    } else {
+      ret = minstd0_next(&x) - urngmin;
+    }
+    const uint32_t tmp = data[i];
+    data[i] = data[ret];
+    data[ret] = tmp;
+  }
+}
+
+void fgnn_oracle_dist_shuffler_partition(size_t num_data, size_t batch_size, int sampler_id,
+                                         int num_sampler, size_t *dataset_offset,
+                                         size_t *num_local_step, size_t *local_data_size,
+                                         size_t *last_batch_size, size_t *epoch_step) {
+  /* drop_last == false path of dist_shuffler.cc:47-79 */
+  size_t num_step = (num_data + batch_size - 1) / batch_size;
+  size_t last = num_data % batch_size == 0 ? batch_size : num_data % batch_size;
+  if (sampler_id < num_sampler - 1) last = batch_size;
+  *epoch_step = num_step;
+  *dataset_offset = (num_step / (size_t)num_sampler * (size_t)sampler_id) * batch_size;
+  if (sampler_id == num_sampler - 1) {
+    const size_t previous_step = num_step / (size_t)num_sampler * (size_t)sampler_id;
+    *num_local_step = num_step - previous_step;
+    *local_data_size = num_data - previous_step * batch_size;
+  } else {
+    *num_local_step = num_step / (size_t)num_sampler;
+    *local_data_size = *num_local_step * batch_size;
+  }
+  *last_batch_size = last;
+}

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures by RUNNING THE REFERENCE's own CPU code.
+
+Run only in the build container (needs /root/reference):
+    make -C oracle _ref && python tests/golden/make_golden.py
+Outputs tests/golden/*.npz (inputs + the reference's outputs).  The reference's sources are never
+copied: oracle/_ref/ref_driver is compiled from them in place (see oracle/Makefile, ref_driver.cc).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+from fgnn_hip import synth  # noqa: E402
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+
+def run_job(lines, tmp):
+    job = os.path.join(tmp, "job.txt")
+    with open(job, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.check_call([DRIVER, job], env=env)
+
+
+def rd(tmp, name, dtype=np.uint32):
+    return np.fromfile(os.path.join(tmp, name), dtype=dtype)
+
+
+def unique_seeds(rng, num_node, n):
+    return rng.permutation(num_node)[:n].astype(np.uint32)
+
+
+def golden_khop_pipeline(sample, name, num_node=1500, num_edge=24000, fanouts=(6, 4), batch=120, num_batches=3):
+    """The reference's DoCPUSample order (cpu/cpu_loops.cc:55-191) driven through its own functions:
+    Reset, Populate(seeds), then per layer (last fanout first): CPUSampleKHop{0,2} -> Populate(out_dst) ->
+    MapNodes -> MapEdges.  All batches run in ONE process: the mt19937 stream and (khop2) the mutated CSR carry."""
+    rng = np.random.default_rng(1234)
+    indptr, indices = synth.powerlaw_csr(num_node, num_edge, seed=11)
+    with tempfile.TemporaryDirectory() as tmp:
+        indptr.tofile(os.path.join(tmp, "indptr.bin"))
+        indices.tofile(os.path.join(tmp, "indices.bin"))
+        lines = [f"graph {tmp}/indptr.bin {tmp}/indices.bin", f"ht_create {num_node}"]
+        seeds = []
+        for b in range(num_batches):
+            s = unique_seeds(rng, num_node, batch if b < num_batches - 1 else batch // 3)
+            seeds.append(s)
+            s.tofile(os.path.join(tmp, f"b{b}_seeds.bin"))
+            lines += ["ht_reset", f"ht_populate {tmp}/b{b}_seeds.bin"]
+            cur = f"{tmp}/b{b}_seeds.bin"
+            for li in range(len(fanouts) - 1, -1, -1):
+                p = f"{tmp}/b{b}_l{li}"
+                lines += [f"{sample} {cur} {fanouts[li]} {p}",
+                          f"ht_populate {p}.dst.bin",
+                          f"ht_mapnodes {p}.unique.bin",
+                          f"ht_mapedges {p}.src.bin {p}.dst.bin {p}.map"]
+                cur = f"{p}.unique.bin"
+        lines.append(f"dump_indices {tmp}/indices_after.bin")
+        run_job(lines, tmp)
+        out = dict(indptr=indptr, indices=indices, fanouts=np.array(fanouts, dtype=np.int64),
+                   indices_after=rd(tmp, "indices_after.bin"))
+        for b in range(num_batches):
+            out[f"b{b}_seeds"] = seeds[b]
+            for li in range(len(fanouts)):
+                p = f"b{b}_l{li}"
+                out[p + "_out_src"] = rd(tmp, p + ".src.bin")
+                out[p + "_out_dst"] = rd(tmp, p + ".dst.bin")
+                out[p + "_unique"] = rd(tmp, p + ".unique.bin")
+                out[p + "_col"] = rd(tmp, p + ".map.src.bin")   # new_src -> TrainGraph::col
+                out[p + "_row"] = rd(tmp, p + ".map.dst.bin")   # new_dst -> TrainGraph::row
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("b0")})
+
+
+def golden_edge_cases():
+    """Empty input, every row shorter than the fanout, fanout 1, isolated nodes, duplicates in Populate."""
+    out = {}
+    indptr = np.array([0, 0, 3, 3, 4, 9, 9, 15], dtype=np.uint32)      # rows: 0,3,0,1,5,0,6
+    indices = np.array([4, 6, 1, 0, 1, 2, 3, 5, 6, 0, 1, 2, 3, 4, 5], dtype=np.uint32)
+    inputs = {"empty": np.array([], dtype=np.uint32), "all": np.arange(7, dtype=np.uint32),
+              "rev": np.arange(6, -1, -1, dtype=np.uint32)}
+    with tempfile.TemporaryDirectory() as tmp:
+        indptr.tofile(f"{tmp}/indptr.bin")
+        indices.tofile(f"{tmp}/indices.bin")
+        lines = [f"graph {tmp}/indptr.bin {tmp}/indices.bin"]
+        order = []
+        for sample in ("khop0", "khop2"):
+            for iname, arr in inputs.items():
+                arr.tofile(f"{tmp}/{iname}.bin")
+                for fanout in (1, 3, 8):
+                    tag = f"{sample}_{iname}_f{fanout}"
+                    lines.append(f"{sample} {tmp}/{iname}.bin {fanout} {tmp}/{tag}")
+                    order.append(tag)
+        dup = np.array([5, 3, 5, 5, 1, 3, 0, 6, 1], dtype=np.uint32)
+        dup.tofile(f"{tmp}/dup.bin")
+        more = np.array([6, 2, 2, 5, 4], dtype=np.uint32)
+        more.tofile(f"{tmp}/more.bin")
+        lines += ["ht_create 7", f"ht_populate {tmp}/dup.bin", f"ht_mapnodes {tmp}/dup_unique.bin",
+                  f"ht_populate {tmp}/more.bin", f"ht_mapnodes {tmp}/more_unique.bin",
+                  f"ht_mapedges {tmp}/dup.bin {tmp}/dup.bin {tmp}/dupmap",
+                  f"dump_indices {tmp}/indices_after.bin"]
+        run_job(lines, tmp)
+        out.update(indptr=indptr, indices=indices, indices_after=rd(tmp, "indices_after.bin"),
+                   order=np.array(order), dup=dup, more=more, dup_unique=rd(tmp, "dup_unique.bin"),
+                   more_unique=rd(tmp, "more_unique.bin"), dupmap=rd(tmp, "dupmap.src.bin"))
+        for iname, arr in inputs.items():
+            out["in_" + iname] = arr
+        for tag in order:
+            out[tag + "_src"] = rd(tmp, tag + ".src.bin")
+            out[tag + "_dst"] = rd(tmp, tag + ".dst.bin")
+    np.savez_compressed(os.path.join(HERE, "edge_cases.npz"), **out)
+    print("edge_cases", len(order), "sampling calls")
+
+
+def golden_extract():
+    rng = np.random.default_rng(5)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        lines = []
+        idx = rng.integers(0, 200, size=77).astype(np.uint32)
+        idx.tofile(f"{tmp}/idx.bin")
+        out["index"] = idx
+        for name, dtype, code, dim in (("f32_d7", np.float32, 0, 7), ("f32_d100", np.float32, 0, 100),
+                                       ("i64_d1", np.int64, 6, 1), ("u8_d3", np.uint8, 3, 3),
+                                       ("f16_d5", np.float16, 2, 5)):
+            src = (rng.standard_normal((200, dim)) * 100).astype(dtype)
+            src.tofile(f"{tmp}/{name}.bin")
+            lines.append(f"extract {tmp}/{name}.bin {tmp}/idx.bin {dim} {code} {tmp}/{name}.out")
+            out[name + "_src"] = src
+        run_job(lines, tmp)
+        for name in ("f32_d7", "f32_d100", "i64_d1", "u8_d3", "f16_d5"):
+            out[name + "_out"] = np.fromfile(f"{tmp}/{name}.out", dtype=out[name + "_src"].dtype).reshape(
+                77, out[name + "_src"].shape[1])
+    np.savez_compressed(os.path.join(HERE, "extract.npz"), **out)
+    print("extract ok")
+
+
+def golden_shuffle():
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "probe")
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-o", exe, os.path.join(HERE, "std_shuffle_probe.cc")])
+        out = {}
+        for n, epochs in ((1, 2), (2, 3), (17, 3), (1000, 3)):
+            txt = subprocess.check_output([exe, str(n), str(epochs)]).decode().strip().split("\n")
+            out[f"n{n}"] = np.array([[int(x) for x in ln.split()] for ln in txt], dtype=np.uint32)
+    np.savez_compressed(os.path.join(HERE, "shuffle.npz"), **out)
+    print("shuffle ok")
+
+
+def golden_constants():
+    """The enum/constant block of the reference's Python binding (samgraph/common/__init__.py:47-265):
+    name -> int map the build's own samgraph/common/__init__.py must reproduce."""
+    import importlib.util
+    import json
+    path = "/root/reference/samgraph/common/__init__.py"
+    spec = importlib.util.spec_from_file_location("ref_samgraph_common", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    consts = {k: v for k, v in vars(mod).items() if k.startswith("k") and isinstance(v, int)}
+    consts_extra = dict(sample_types=mod.sample_types, cache_policies=getattr(mod, "cache_policies", None),
+                        builtin_archs=mod.builtin_archs)
+    with open(os.path.join(HERE, "py_constants.json"), "w") as f:
+        json.dump(dict(constants=consts, **consts_extra), f, indent=1, sort_keys=True)
+    print("constants", len(consts))
+
+
+if __name__ == "__main__":
+    if not os.path.exists(DRIVER):
+        sys.exit("build oracle/_ref first: make -C oracle _ref")
+    golden_khop_pipeline("khop0", "khop0_pipeline.npz")
+    golden_khop_pipeline("khop2", "khop2_pipeline.npz")
+    golden_edge_cases()
+    golden_extract()
+    golden_shuffle()
+    golden_constants()

@@ -1,0 +1,168 @@
+"""Pins oracle/ (the CPU restatement) against outputs of the REFERENCE's own CPU code.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py, which ran the
+reference's unmodified cpu_sampling_khop{0,2}.cc / cpu_random.cc / cpu_hashtable2.cc /
+cpu_extraction.cc (compiled in place by `make -C oracle _ref`).  Bar: bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("sample,fname", [("khop0", "khop0_pipeline.npz"), ("khop2", "khop2_pipeline.npz")])
+def test_pipeline_matches_reference_cpu(oracle, golden_dir, sample, fname):
+    """DoCPUSample order (cpu/cpu_loops.cc:55-191) over 3 batches in one process: the mt19937 stream and
+    khop2's in-place CSR mutation carry across layers and batches."""
+    g = _load(golden_dir, fname)
+    indptr = g["indptr"]
+    indices = g["indices"].copy()
+    fanouts = [int(x) for x in g["fanouts"]]
+    st = oracle.KHOP0 if sample == "khop0" else oracle.KHOP2
+    rng = oracle.make_rng(oracle.RNG_MT_CPU_TWIN)
+    ht = oracle.HashTable(len(indptr) - 1, len(indptr) - 1)
+    b = 0
+    while f"b{b}_seeds" in g:
+        task = oracle.do_sample(indptr, indices, g[f"b{b}_seeds"], fanouts, st, rng, batch_key=b, ht=ht)
+        for li in range(len(fanouts)):
+            p = f"b{b}_l{li}"
+            gr = task["graphs"][li]
+            assert gr["num_edge"] == len(g[p + "_out_dst"])
+            np.testing.assert_array_equal(gr["row"], g[p + "_row"])
+            np.testing.assert_array_equal(gr["col"], g[p + "_col"])
+            assert gr["num_src"] == len(g[p + "_unique"])
+        np.testing.assert_array_equal(task["input_nodes"], g[f"b{b}_l0_unique"])
+        b += 1
+    assert b == 3
+    np.testing.assert_array_equal(indices, g["indices_after"])
+    if sample == "khop0":
+        np.testing.assert_array_equal(indices, g["indices"])  # khop0 never mutates the CSR
+    else:
+        assert (indices != g["indices"]).any()                # khop2 does
+
+
+@pytest.mark.parametrize("sample", ["khop0", "khop2"])
+def test_per_call_outputs_match_reference_cpu(oracle, golden_dir, sample):
+    """Same fixtures, checked stage by stage: sampler COO, Populate/MapNodes unique list, MapEdges."""
+    g = _load(golden_dir, f"{sample}_pipeline.npz")
+    indptr = g["indptr"]
+    indices = g["indices"].copy()
+    fanouts = [int(x) for x in g["fanouts"]]
+    fn = oracle.sample_khop0 if sample == "khop0" else oracle.sample_khop2
+    rng = oracle.make_rng(oracle.RNG_MT_CPU_TWIN)
+    ht = oracle.HashTable(len(indptr) - 1, len(indptr) - 1)
+    for b in range(3):
+        ht.reset()
+        assert ht.fill_unique(g[f"b{b}_seeds"]) == 0
+        cur = g[f"b{b}_seeds"]
+        for li in range(len(fanouts) - 1, -1, -1):
+            p = f"b{b}_l{li}"
+            src, dst = fn(indptr, indices, cur, fanouts[li], rng, b, li)
+            np.testing.assert_array_equal(src, g[p + "_out_src"])
+            np.testing.assert_array_equal(dst, g[p + "_out_dst"])
+            uniq = ht.fill_duplicates(dst)
+            np.testing.assert_array_equal(uniq, g[p + "_unique"])
+            np.testing.assert_array_equal(uniq[:len(cur)], cur)  # next input starts with previous seeds
+            ns, nd = ht.map_edges(src, dst)
+            np.testing.assert_array_equal(ns, g[p + "_col"])
+            np.testing.assert_array_equal(nd, g[p + "_row"])
+            cur = uniq
+
+
+def test_edge_cases_match_reference_cpu(oracle, golden_dir):
+    g = _load(golden_dir, "edge_cases.npz")
+    indptr = g["indptr"]
+    indices = g["indices"].copy()
+    rng = oracle.make_rng(oracle.RNG_MT_CPU_TWIN)
+    for tag in g["order"]:
+        tag = str(tag)
+        sample, iname, f = tag.split("_")
+        fanout = int(f[1:])
+        fn = oracle.sample_khop0 if sample == "khop0" else oracle.sample_khop2
+        src, dst = fn(indptr, indices, g["in_" + iname], fanout, rng)
+        np.testing.assert_array_equal(src, g[tag + "_src"], err_msg=tag)
+        np.testing.assert_array_equal(dst, g[tag + "_dst"], err_msg=tag)
+    np.testing.assert_array_equal(indices, g["indices_after"])
+    # CPUHashTable2::Populate with duplicates inside one call and across calls
+    ht = oracle.HashTable(7, 16)
+    np.testing.assert_array_equal(ht.fill_duplicates(g["dup"]), g["dup_unique"])
+    np.testing.assert_array_equal(ht.fill_duplicates(g["more"]), g["more_unique"])
+    ns, _ = ht.map_edges(g["dup"], g["dup"])
+    np.testing.assert_array_equal(ns, g["dupmap"])
+
+
+def test_extract_matches_reference_cpu(oracle, golden_dir):
+    g = _load(golden_dir, "extract.npz")
+    for name in ("f32_d7", "f32_d100", "i64_d1", "u8_d3", "f16_d5"):
+        out = oracle.extract(g[name + "_src"], g["index"])
+        assert out.tobytes() == g[name + "_out"].tobytes(), name
+
+
+def test_shuffle_matches_libstdcxx(oracle, golden_dir):
+    """Shufflers' Fisher-Yates with std::default_random_engine(epoch) (dist/dist_shuffler.cc:112-131):
+    cumulative over epochs, seed = epoch."""
+    g = _load(golden_dir, "shuffle.npz")
+    for key in g.files:
+        n = int(key[1:])
+        data = np.arange(n, dtype=np.uint32)
+        for epoch, want in enumerate(g[key]):
+            data = oracle.shuffle_minstd0(data, epoch)
+            np.testing.assert_array_equal(data, want, err_msg=f"{key} epoch {epoch}")
+
+
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_formulas(oracle):
+    # PredictNumNodes (common.cc:330-339): SURVEY 8: bs 8000, [25,10] -> 2 288 000; GCN [5,10,15] -> 8 448 000
+    assert oracle.predict_num_nodes(8000, [25, 10]) == 2288000
+    assert oracle.predict_num_nodes(8000, [5, 10, 15]) == 8448000
+    assert oracle.predict_num_nodes(8000, [25, 10], 1) == 8000 * 26
+    # TableSize (cuda_hashtable.cu:125-128): 2 288 000 -> 2^21 << 2 = 8 388 608; TableSize(75,3) = 512
+    assert oracle.table_size(2288000, 2) == 8388608
+    assert oracle.table_size(75, 3) == 512
+    assert oracle.table_size(8448000, 2) == 32 * 1024 * 1024
+    # DistShuffler partition (dist_shuffler.cc:36-79) for papers100M: 151 steps, 2 samplers -> 75 + 76
+    p0 = oracle.dist_shuffler_partition(1207179, 8000, 0, 2)
+    p1 = oracle.dist_shuffler_partition(1207179, 8000, 1, 2)
+    assert p0["epoch_step"] == 151 and p0["num_local_step"] == 75 and p1["num_local_step"] == 76
+    assert p0["dataset_offset"] == 0 and p1["dataset_offset"] == 75 * 8000
+    assert p0["last_batch_size"] == 8000 and p1["last_batch_size"] == 1207179 % 8000
+    assert p0["local_data_size"] == 75 * 8000 and p1["local_data_size"] == 1207179 - 75 * 8000
+
+
+def test_cache_split_and_rank(oracle):
+    # presample rank (dist/pre_sampler.cc:131-162): freq desc, node id desc on ties
+    freq = np.array([3, 0, 5, 3, 0, 1], dtype=np.uint32)
+    rank = oracle.presample_rank(freq)
+    np.testing.assert_array_equal(rank, [2, 3, 0, 5, 4, 1])
+    table = oracle.cache_table_build(rank, 3, 6)
+    np.testing.assert_array_equal(table, [2, oracle.EMPTY, 0, 1, oracle.EMPTY, oracle.EMPTY])
+    nodes = np.array([5, 3, 1, 2, 0, 4], dtype=np.uint32)
+    ms, md, cs, cd = oracle.get_miss_cache_index(table, nodes)
+    np.testing.assert_array_equal(ms, [5, 1, 4])      # global ids of misses, in batch order
+    np.testing.assert_array_equal(md, [0, 2, 5])      # their batch positions
+    np.testing.assert_array_equal(cs, [1, 0, 2])      # cache slots of hits
+    np.testing.assert_array_equal(cd, [1, 3, 4])
+    feat = np.arange(6 * 4, dtype=np.float32).reshape(6, 4)
+    cache = oracle.extract(feat, rank[:3])
+    out = np.zeros((6, 4), dtype=np.float32)
+    oracle.combine(out, oracle.extract(feat, ms), None, md)
+    oracle.combine(out, cache, cs, cd)
+    np.testing.assert_array_equal(out, feat[nodes])
+
+
+def test_python_constants_fixture_present(golden_dir):
+    with open(os.path.join(golden_dir, "py_constants.json")) as f:
+        c = json.load(f)
+    assert c["constants"]["kKHop2"] == 5 and c["constants"]["kArch5"] == 5
