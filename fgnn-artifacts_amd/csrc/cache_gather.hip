@@ -1,0 +1,225 @@
+// cache_gather.hip -- cache hit/miss index split and row gathers for gfx950.
+//
+// Replaces GetMissCacheIndex (reference samgraph/common/cuda/cuda_cache.cu:33-234, duplicated in
+// cuda_cache_manager_device.cu:38-163,266-337), GPUExtract (cuda_extraction.cu:30-117) and
+// CombineMissData / CombineCacheData (cuda_cache_manager_device.cu:165-210,339-442;
+// dist/dist_cache_manager_device.cu:38-183).
+//
+// MI355X design
+//  * split: the reference reads table[nodes[i]] five times per node over three kernels and two
+//    device scans.  Here: one kernel reads it once, keeps the slot in scratch and emits per-workgroup
+//    miss counts; a one-workgroup scan; one kernel writes BOTH output lists (the hit position follows
+//    from the miss rank: hits_before = items_before - misses_before), ranks by wave ballots;
+//  * gathers: rows are moved as 16-byte chunks by a flat chunk index (chunk c of row r), so every
+//    lane of a wave is busy for any feature width (D=100 -> 25 chunks, D=128 -> 32, D=256 -> 64) and
+//    several independent 16-byte loads are in flight per lane; a scalar path covers rows whose byte
+//    length is not a multiple of 16 (labels: dim 1 x 8 B).
+#include "fgnn_device.h"
+
+namespace fgnn {
+namespace {
+
+__global__ __launch_bounds__(kBlock) void cache_count_kernel(const uint32_t *__restrict__ table,
+                                                             const uint32_t *__restrict__ nodes, size_t n_host,
+                                                             const uint32_t *d_n, size_t cap,
+                                                             uint32_t *__restrict__ slot,
+                                                             uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  uint32_t miss = 0;
+#pragma unroll
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    if (i < n) {
+      const uint32_t s = table[nodes[i]];
+      slot[i] = s;
+      miss += (s == FGNN_EMPTY_KEY);
+    }
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan<kWavesPerBlock>(miss, sh, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void cache_split_kernel(const uint32_t *__restrict__ nodes, size_t n_host,
+                                                             const uint32_t *d_n, size_t cap,
+                                                             const uint32_t *__restrict__ slot,
+                                                             const uint32_t *__restrict__ block_offsets,
+                                                             const uint32_t *__restrict__ d_total_miss,
+                                                             uint32_t *__restrict__ miss_src,
+                                                             uint32_t *__restrict__ miss_dst,
+                                                             uint32_t *__restrict__ cache_src,
+                                                             uint32_t *__restrict__ cache_dst,
+                                                             uint32_t *__restrict__ d_counts) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  uint32_t miss_before = block_offsets[blockIdx.x];
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t row0 = tile0 + (size_t)r * kBlock;
+    const size_t i = row0 + threadIdx.x;
+    uint32_t s = 0;
+    bool is_miss = false;
+    if (i < n) {
+      s = slot[i];
+      is_miss = (s == FGNN_EMPTY_KEY);
+    }
+    uint32_t tot;
+    const uint32_t mrank = block_exclusive_rank<kWavesPerBlock>(is_miss, sh, &tot);
+    if (i < n) {
+      if (is_miss) {
+        const uint32_t p = miss_before + mrank;
+        miss_dst[p] = (uint32_t)i;
+        miss_src[p] = nodes[i];
+      } else {
+        // hits before i = items before i - misses before i
+        const uint32_t p = (uint32_t)(row0 - miss_before) + (threadIdx.x - mrank);
+        cache_dst[p] = (uint32_t)i;
+        cache_src[p] = s;
+      }
+    }
+    miss_before += tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t m = *d_total_miss;
+    d_counts[0] = m;
+    d_counts[1] = (uint32_t)n - m;
+  }
+}
+
+struct alignas(16) chunk16 { uint32_t a, b, c, d; };
+
+// flat 16-byte-chunk gather; chunks_per_row = row_bytes / 16
+template <int UNROLL>
+__global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restrict__ out,
+                                                               const chunk16 *__restrict__ src,
+                                                               const uint32_t *__restrict__ src_index,
+                                                               const uint32_t *__restrict__ dst_index, size_t n_host,
+                                                               const uint32_t *d_n, size_t cap, uint32_t cpr) {
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t total = n * cpr;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; c + (UNROLL - 1) * stride < total; c += UNROLL * stride) {
+    chunk16 v[UNROLL];
+    size_t dsts[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const size_t cc = c + u * stride;
+      const size_t row = cc / cpr;
+      const uint32_t col = (uint32_t)(cc - row * cpr);
+      const size_t srow = src_index ? src_index[row] : row;
+      const size_t drow = dst_index ? dst_index[row] : row;
+      v[u] = src[srow * cpr + col];
+      dsts[u] = drow * cpr + col;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) out[dsts[u]] = v[u];
+  }
+  for (; c < total; c += stride) {
+    const size_t row = c / cpr;
+    const uint32_t col = (uint32_t)(c - row * cpr);
+    const size_t srow = src_index ? src_index[row] : row;
+    const size_t drow = dst_index ? dst_index[row] : row;
+    out[drow * cpr + col] = src[srow * cpr + col];
+  }
+}
+
+// generic element gather (element = 1, 2, 4 or 8 bytes)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gather_rows_elem_kernel(T *__restrict__ out, const T *__restrict__ src,
+                                                                  const uint32_t *__restrict__ src_index,
+                                                                  const uint32_t *__restrict__ dst_index,
+                                                                  size_t n_host, const uint32_t *d_n, size_t cap,
+                                                                  size_t dim) {
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t total = n * dim;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+    const size_t row = e / dim;
+    const size_t col = e - row * dim;
+    const size_t srow = src_index ? src_index[row] : row;
+    const size_t drow = dst_index ? dst_index[row] : row;
+    out[drow * dim + col] = src[srow * dim + col];
+  }
+}
+
+size_t dtype_bytes(int dtype) {
+  switch (dtype) {
+    case FGNN_I8: case FGNN_U8: return 1;
+    case FGNN_F16: return 2;
+    case FGNN_F32: case FGNN_I32: return 4;
+    case FGNN_F64: case FGNN_I64: return 8;
+    default: return 0;
+  }
+}
+
+}  // namespace
+}  // namespace fgnn
+
+using namespace fgnn;
+
+extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
+                                         const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
+                                         uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst,
+                                         uint32_t *d_counts, void *ws, size_t ws_bytes, void *stream) {
+  auto s = static_cast<hipStream_t>(stream);
+  size_t cap = d_num_nodes ? num_nodes_cap : num_nodes;
+  if (!d_counts) return FGNN_EINVAL;
+  if (cap == 0) {
+    FGNN_HIP_CHECK(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint32_t), s));
+    return FGNN_OK;
+  }
+  if (!table || !nodes || !miss_src || !miss_dst || !cache_src || !cache_dst || cap > 0xffffffffull)
+    return FGNN_EINVAL;
+  const size_t nb = div_up(cap, kTile);
+  // scratch: slot[cap] | block_sums[nb] | total_miss[1]
+  if (ws_bytes < (cap + nb + 2) * sizeof(uint32_t)) return FGNN_ENOSPC;
+  uint32_t *slot = static_cast<uint32_t *>(ws);
+  uint32_t *sums = slot + cap;
+  uint32_t *total = sums + nb;
+  hipLaunchKernelGGL(cache_count_kernel, dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes, d_num_nodes, cap, slot,
+                     sums);
+  if (launch_scan_block_sums(sums, nb, nullptr, total, nullptr, nullptr, s) != FGNN_OK) return FGNN_EHIP;
+  hipLaunchKernelGGL(cache_split_kernel, dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes, d_num_nodes, cap, slot, sums,
+                     total, miss_src, miss_dst, cache_src, cache_dst, d_counts);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
+
+extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
+                                size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, void *stream) {
+  auto s = static_cast<hipStream_t>(stream);
+  const size_t esz = dtype_bytes(dtype);
+  size_t cap = d_n ? n_cap : n;
+  if (esz == 0 || dim == 0) return FGNN_EINVAL;
+  if (cap == 0) return FGNN_OK;
+  if (!out || !src) return FGNN_EINVAL;
+  const size_t row_bytes = dim * esz;
+  const bool vec = (row_bytes % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(src) % 16 == 0) && row_bytes / 16 <= 0xffffffffull;
+  if (vec) {
+    const uint32_t cpr = (uint32_t)(row_bytes / 16);
+    const size_t total = cap * cpr;
+    constexpr int U = 4;
+    size_t blocks = div_up(total, (size_t)kBlock * U);
+    if (blocks > 256 * 16) blocks = 256 * 16;  // 16 workgroups per CU, grid-stride the rest
+    hipLaunchKernelGGL((gather_rows16_kernel<U>), dim3(blocks), dim3(kBlock), 0, s, static_cast<chunk16 *>(out),
+                       static_cast<const chunk16 *>(src), src_index, dst_index, n, d_n, cap, cpr);
+  } else {
+    const size_t total = cap * dim;
+    size_t blocks = div_up(total, kBlock);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define FGNN_ELEM(T)                                                                                              \
+  hipLaunchKernelGGL((gather_rows_elem_kernel<T>), dim3(blocks), dim3(kBlock), 0, s, static_cast<T *>(out),       \
+                     static_cast<const T *>(src), src_index, dst_index, n, d_n, cap, dim)
+    switch (esz) {
+      case 1: FGNN_ELEM(uint8_t); break;
+      case 2: FGNN_ELEM(uint16_t); break;
+      case 4: FGNN_ELEM(uint32_t); break;
+      default: FGNN_ELEM(unsigned long long); break;
+    }
+#undef FGNN_ELEM
+  }
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}

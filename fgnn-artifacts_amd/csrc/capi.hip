@@ -1,0 +1,15 @@
+// capi.hip -- small entry points of libfgnn_hip.so that are not tied to one kernel file.
+#include "fgnn_device.h"
+
+extern "C" const char *fgnn_version(void) { return "fgnn-hip 0.1 (gfx950)"; }
+
+extern "C" int fgnn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// Largest layout any call needs: one uint32 per item + one per workgroup + slack.
+extern "C" size_t fgnn_scratch_bytes(size_t n_cap) {
+  return (n_cap + fgnn::div_up(n_cap, 64) + 64) * sizeof(uint32_t);
+}

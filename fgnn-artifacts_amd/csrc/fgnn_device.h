@@ -1,0 +1,129 @@
+// fgnn_device.h -- device-side building blocks shared by the gfx950 kernels: Philox draws,
+// wave64 ballot/prefix compaction, block scans.  CDNA4 only: wavefront = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fgnn_hip.h"
+
+namespace fgnn {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kItemsPerThread = 8;   // edge-parallel kernels: 2048 items per workgroup
+constexpr int kTile = kBlock * kItemsPerThread;
+
+#define FGNN_HIP_CHECK(expr)                      \
+  do {                                            \
+    hipError_t _e = (expr);                       \
+    if (_e != hipSuccess) return FGNN_EHIP;       \
+  } while (0)
+
+// ---- Philox4x32-10, addressed exactly like oracle/fgnn_oracle.c:fgnn_philox_draw ------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox_block(uint64_t seed, uint64_t batch_key, uint32_t tag,
+                                              uint32_t item, uint32_t block) {
+  uint32_t c0 = block, c1 = item, c2 = tag, c3 = (uint32_t)batch_key;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(batch_key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ uint32_t pick_word(const u32x4 &b, uint32_t j) {
+  const uint32_t lo = (j & 1u) ? b.y : b.x;
+  const uint32_t hi = (j & 1u) ? b.w : b.z;
+  return (j & 2u) ? hi : lo;
+}
+
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t batch_key, uint32_t tag,
+                                               uint32_t item, uint32_t j) {
+  return pick_word(philox_block(seed, batch_key, tag, item, j >> 2), j);
+}
+
+// ---- wave64 / block primitives ----------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// rank of this lane among the lanes whose predicate is set, and the wave total (ballot + popcount)
+__device__ __forceinline__ uint32_t wave_rank(bool pred, uint32_t *total) {
+  const unsigned long long m = __ballot(pred);
+  *total = (uint32_t)__popcll(m);
+  return (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+}
+
+// inclusive wave scan by shuffles
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d, kWave);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive block scan of one value per thread (NW waves per block); *block_total gets the sum.
+// `sh` needs NW words.  Contains two barriers.
+template <int NW = kWavesPerBlock>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh, uint32_t *block_total) {
+  const uint32_t inc = wave_inclusive_scan(v);
+  if (lane_id() == kWave - 1) sh[wave_id()] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t t = sh[w];
+    if (w < wave_id()) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *block_total = tot;
+  return base + inc - v;
+}
+
+// exclusive block scan of a 0/1 flag per thread using ballots (cheaper than the shuffle scan)
+template <int NW = kWavesPerBlock>
+__device__ __forceinline__ uint32_t block_exclusive_rank(bool pred, uint32_t *sh, uint32_t *block_total) {
+  uint32_t wt;
+  const uint32_t r = wave_rank(pred, &wt);
+  if (lane_id() == 0) sh[wave_id()] = wt;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t t = sh[w];
+    if (w < wave_id()) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *block_total = tot;
+  return base + r;
+}
+
+__device__ __forceinline__ size_t resolve_count(size_t n_host, const uint32_t *d_n, size_t cap) {
+  size_t n = d_n ? (size_t)(*d_n) : n_host;
+  return n < cap ? n : cap;
+}
+__device__ __forceinline__ size_t resolve_count64(size_t n_host, const size_t *d_n, size_t cap) {
+  size_t n = d_n ? *d_n : n_host;
+  return n < cap ? n : cap;
+}
+
+// Exclusive scan of `n` block sums by ONE workgroup of 1024 threads, in place (defined in
+// scan.hip).  total -> *total64 and *total32 (either may be null).  If accum != null the kernel also
+// does *accum_out = *accum + total (used to advance the hash table's item count on the device).
+int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *total32,
+                           const uint32_t *accum, uint32_t *accum_out, hipStream_t stream);
+
+inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+
+}  // namespace fgnn

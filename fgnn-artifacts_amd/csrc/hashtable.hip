@@ -1,0 +1,313 @@
+// hashtable.hip -- frontier dedup / compaction / remap for gfx950.
+//
+// Replaces OrderedHashTable (reference samgraph/common/cuda/cuda_hashtable.{h,cu}) and the
+// dst half of GPUMapEdges (cuda_mapping.cu:31-81).  Observable behaviour == oracle
+// fgnn_oracle_ht_* : new nodes get local ids in order of FIRST occurrence (a legal outcome of the
+// reference's CAS race, and what its CPU twin CPUHashTable2 produces with one thread).
+//
+// MI355X design
+//  * bucket = ONE 64-bit word {key:hi32, value:lo32} instead of the reference's 16-byte
+//    {key,local,index,version}: a whole insert is a single 8-byte CAS, duplicates resolve to the
+//    minimum index with one 8-byte atomicMin (the key half is identical, so u64 min == value min);
+//    half the table footprint keeps the table inside the 256 MiB Infinity Cache;
+//  * value = 0x80000000|i while item i is the pending first occurrence of a new key, a local id
+//    (< 2^31) once assigned -- replaces the `version` field and the per-batch version bump;
+//  * device-scope atomics on CDNA4 execute at the memory side (~20 G scattered atomics/s chip-wide),
+//    so the insert first READS the bucket and only issues an atomic when it can change something:
+//    a key that is already present with a smaller value costs one 8-byte load, no atomic.
+//    Stale reads (per-XCD L2s are not coherent inside a launch) can only show an older state, which
+//    at worst causes a redundant atomic, never a wrong decision;
+//  * the insert remembers each item's bucket in `pos[]`, so the later passes (owner flag, local-id
+//    assignment, remap) read the bucket directly instead of re-probing (the reference re-probes in
+//    count_hashmap, compact_hashmap and map_edge_ids);
+//  * owner ranks come from wave ballots + a one-workgroup scan of per-workgroup counts.
+#include "fgnn_device.h"
+
+struct fgnn_hashtable {
+  unsigned long long *table;  // capacity buckets
+  uint32_t *n2o;              // max_items
+  uint32_t *d_num_items;      // [2]: current, scratch for "old" value during a fill
+  size_t capacity;            // power of two
+  size_t max_items;
+  uint32_t shift;             // 32 - log2(capacity)
+};
+
+namespace fgnn {
+namespace {
+
+constexpr unsigned long long kEmpty64 = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kPending = 0x80000000u;
+constexpr uint32_t kNoBucket = 0x7FFFFFFFu;  // capacity <= 2^31, so never a real bucket index
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t shift, uint32_t mask) {
+  return ((id * 0x9E3779B1u) >> shift) & mask;
+}
+
+// Inserts (id, value) keeping the minimum value per key.  Returns the bucket index.
+__device__ __forceinline__ uint32_t ht_insert_min(unsigned long long *table, uint32_t shift, uint32_t mask,
+                                                  uint32_t id, uint32_t value) {
+  const unsigned long long mine = ((unsigned long long)id << 32) | value;
+  uint32_t h = hash_slot(id, shift, mask);
+  // load factor <= 0.5 by construction; the bound only keeps a violated contract (more distinct
+  // keys than max_items) from hanging the GPU
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    unsigned long long cur = table[h];
+    if (cur == kEmpty64) {
+      cur = atomicCAS(&table[h], kEmpty64, mine);
+      if (cur == kEmpty64) return h;
+    }
+    if ((uint32_t)(cur >> 32) == id) {
+      if ((uint32_t)cur > value) atomicMin(&table[h], mine);
+      return h;
+    }
+    h = (h + 1) & mask;
+  }
+  return kNoBucket;
+}
+
+__device__ __forceinline__ uint32_t ht_find(const unsigned long long *table, uint32_t shift, uint32_t mask,
+                                            uint32_t id, uint32_t *bucket) {
+  uint32_t h = hash_slot(id, shift, mask);
+  // the key is present by contract; bound the probe anyway so a violated contract cannot hang the GPU
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    const unsigned long long cur = table[h];
+    if ((uint32_t)(cur >> 32) == id) { *bucket = h; return (uint32_t)cur; }
+    if (cur == kEmpty64) break;
+    h = (h + 1) & mask;
+  }
+  *bucket = 0;
+  return FGNN_EMPTY_KEY;
+}
+
+// FillWithUnique: item i -> local id base + i
+__global__ __launch_bounds__(kBlock) void ht_fill_unique_kernel(unsigned long long *table, uint32_t shift,
+                                                                uint32_t mask, const uint32_t *__restrict__ items,
+                                                                size_t n, uint32_t *__restrict__ n2o,
+                                                                uint32_t *d_num_items, size_t max_items) {
+  const uint32_t base = d_num_items[0];
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n && base + i < max_items) {
+    const uint32_t id = items[i];
+    (void)ht_insert_min(table, shift, mask, id, (uint32_t)(base + i));
+    n2o[base + i] = id;
+  }
+}
+
+__global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_items[0] += add; }
+
+// pass 1: insert every item with value PENDING|i; remember its bucket
+__global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *table, uint32_t shift, uint32_t mask,
+                                                           const uint32_t *__restrict__ items, size_t n_host,
+                                                           const size_t *d_n, size_t cap,
+                                                           uint32_t *__restrict__ pos) {
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    if (i < n) pos[i] = ht_insert_min(table, shift, mask, items[i], kPending | (uint32_t)i);
+  }
+}
+
+// pass 2: owner(i) <=> bucket value == PENDING|i ; per-workgroup owner counts; flag kept in pos bit 31
+__global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long long *__restrict__ table,
+                                                          size_t n_host, const size_t *d_n, size_t cap,
+                                                          uint32_t *__restrict__ pos,
+                                                          uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    if (i < n) {
+      const uint32_t b = pos[i];
+      const bool owner = b != kNoBucket && (uint32_t)table[b] == (kPending | (uint32_t)i);
+      if (owner) { pos[i] = b | kPending; ++cnt; }
+    }
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan<kWavesPerBlock>(cnt, sh, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// pass 3: owners take local id = old_num_items + rank (rank in item order) and append to N2O
+__global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *table,
+                                                           const uint32_t *__restrict__ items, size_t n_host,
+                                                           const size_t *d_n, size_t cap,
+                                                           const uint32_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ block_offsets,
+                                                           const uint32_t *d_old_num_items,
+                                                           uint32_t *__restrict__ n2o, size_t max_items) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  uint32_t running = *d_old_num_items + block_offsets[blockIdx.x];
+  // item order inside the tile is r-major: i = tile0 + r*kBlock + tid
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    uint32_t b = 0;
+    bool owner = false;
+    if (i < n) {
+      b = pos[i];
+      owner = (b & kPending) != 0;
+    }
+    uint32_t tot;
+    const uint32_t rank = block_exclusive_rank<kWavesPerBlock>(owner, sh, &tot);
+    if (owner) {
+      const uint32_t local = running + rank;
+      if (local < max_items) {
+        // low half of the little-endian 64-bit bucket = value
+        reinterpret_cast<uint32_t *>(&table[b & ~kPending])[0] = local;
+        n2o[local] = items[i];
+      }
+    }
+    running += tot;
+  }
+}
+
+// pass 4: mapped[i] = local id of items[i] (bucket known)
+__global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long long *__restrict__ table,
+                                                            size_t n_host, const size_t *d_n, size_t cap,
+                                                            const uint32_t *__restrict__ pos,
+                                                            uint32_t *__restrict__ mapped) {
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    if (i < n) {
+      const uint32_t b = pos[i] & ~kPending;
+      mapped[i] = b != kNoBucket ? (uint32_t)table[b] : FGNN_EMPTY_KEY;
+    }
+  }
+}
+
+// GPUMapEdges for ids without a remembered bucket
+__global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(const unsigned long long *__restrict__ table,
+                                                              uint32_t shift, uint32_t mask,
+                                                              const uint32_t *__restrict__ items, size_t n_host,
+                                                              const size_t *d_n, size_t cap,
+                                                              uint32_t *__restrict__ mapped) {
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t tile0 = (size_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int r = 0; r < kItemsPerThread; ++r) {
+    const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
+    if (i < n) {
+      uint32_t b;
+      mapped[i] = ht_find(table, shift, mask, items[i], &b);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace fgnn
+
+using namespace fgnn;
+
+extern "C" fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err) {
+  auto fail = [&](int code) -> fgnn_hashtable * {
+    if (h_err) *h_err = code;
+    return nullptr;
+  };
+  if (max_items == 0 || max_items >= 0x7fffffffull) return fail(FGNN_EINVAL);
+  size_t cap = 1024;
+  uint32_t lg = 10;
+  while (cap < 2 * max_items) { cap <<= 1; ++lg; }
+  auto *ht = new fgnn_hashtable();
+  ht->capacity = cap;
+  ht->max_items = max_items;
+  ht->shift = 32 - lg;
+  ht->table = nullptr;
+  ht->n2o = nullptr;
+  ht->d_num_items = nullptr;
+  if (hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&ht->n2o, max_items * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&ht->d_num_items, 2 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(ht->table, 0xFF, cap * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ht->d_num_items, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
+    fgnn_hashtable_destroy(ht);
+    return fail(FGNN_EHIP);
+  }
+  if (h_err) *h_err = FGNN_OK;
+  return ht;
+}
+
+extern "C" void fgnn_hashtable_destroy(fgnn_hashtable *ht) {
+  if (!ht) return;
+  if (ht->table) (void)hipFree(ht->table);
+  if (ht->n2o) (void)hipFree(ht->n2o);
+  if (ht->d_num_items) (void)hipFree(ht->d_num_items);
+  delete ht;
+}
+
+extern "C" size_t fgnn_hashtable_capacity(const fgnn_hashtable *ht) { return ht ? ht->capacity : 0; }
+extern "C" const uint32_t *fgnn_hashtable_n2o(const fgnn_hashtable *ht) { return ht ? ht->n2o : nullptr; }
+extern "C" const uint32_t *fgnn_hashtable_d_num_items(const fgnn_hashtable *ht) {
+  return ht ? ht->d_num_items : nullptr;
+}
+
+extern "C" int fgnn_hashtable_reset(fgnn_hashtable *ht, void *stream) {
+  if (!ht) return FGNN_EINVAL;
+  auto s = static_cast<hipStream_t>(stream);
+  FGNN_HIP_CHECK(hipMemsetAsync(ht->table, 0xFF, ht->capacity * sizeof(unsigned long long), s));
+  FGNN_HIP_CHECK(hipMemsetAsync(ht->d_num_items, 0, 2 * sizeof(uint32_t), s));
+  return FGNN_OK;
+}
+
+extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                          void *stream) {
+  if (!ht || (!items && num_items)) return FGNN_EINVAL;
+  if (num_items == 0) return FGNN_OK;
+  if (num_items > ht->max_items) return FGNN_EINVAL;
+  auto s = static_cast<hipStream_t>(stream);
+  const uint32_t mask = (uint32_t)(ht->capacity - 1);
+  hipLaunchKernelGGL(ht_fill_unique_kernel, dim3(div_up(num_items, kBlock)), dim3(kBlock), 0, s, ht->table, ht->shift,
+                     mask, items, num_items, ht->n2o, ht->d_num_items, ht->max_items);
+  hipLaunchKernelGGL(ht_advance_kernel, dim3(1), dim3(1), 0, s, ht->d_num_items, (uint32_t)num_items);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
+
+extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                              const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped,
+                                              void *ws, size_t ws_bytes, void *stream) {
+  if (!ht) return FGNN_EINVAL;
+  size_t cap = d_num_items ? num_items_cap : num_items;
+  if (cap == 0) return FGNN_OK;
+  if (!items || cap >= 0x80000000ull) return FGNN_EINVAL;
+  auto s = static_cast<hipStream_t>(stream);
+  const size_t nb = div_up(cap, kTile);
+  // scratch layout: pos[cap] | block_sums[nb + 1]
+  const size_t need = (cap + nb + 2) * sizeof(uint32_t);
+  if (ws_bytes < need) return FGNN_ENOSPC;
+  uint32_t *pos = static_cast<uint32_t *>(ws);
+  uint32_t *sums = pos + cap;
+  const uint32_t mask = (uint32_t)(ht->capacity - 1);
+  hipLaunchKernelGGL(ht_insert_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, ht->shift, mask, items, num_items,
+                     d_num_items, cap, pos);
+  hipLaunchKernelGGL(ht_count_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos, sums);
+  // d_num_items[1] keeps the old count for pass 3; d_num_items[0] advances
+  FGNN_HIP_CHECK(hipMemcpyAsync(ht->d_num_items + 1, ht->d_num_items, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s) != FGNN_OK)
+    return FGNN_EHIP;
+  hipLaunchKernelGGL(ht_assign_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, items, num_items, d_num_items, cap, pos,
+                     sums, ht->d_num_items + 1, ht->n2o, ht->max_items);
+  if (mapped)
+    hipLaunchKernelGGL(ht_map_pos_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos,
+                       mapped);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
+
+extern "C" int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *stream) {
+  if (!ht) return FGNN_EINVAL;
+  size_t cap = d_num_items ? num_items_cap : num_items;
+  if (cap == 0) return FGNN_OK;
+  if (!items || !mapped) return FGNN_EINVAL;
+  const uint32_t mask = (uint32_t)(ht->capacity - 1);
+  hipLaunchKernelGGL(ht_map_probe_kernel, dim3(div_up(cap, kTile)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     ht->table, ht->shift, mask, items, num_items, d_num_items, cap, mapped);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}

@@ -1,0 +1,256 @@
+// sample_khop.hip -- fixed-fanout uniform neighbour sampling without replacement for gfx950.
+//
+// Replaces GPUSampleKHop0 (reference samgraph/common/cuda/cuda_sampling_khop0.cu:41-253) and
+// GPUSampleKHop2 (cuda_sampling_khop2.cu:41-252).  Results are bit-identical to
+// oracle/fgnn_oracle.c (Philox mode), including khop2's in-place mutation of the CSR row.
+//
+// MI355X design (not the reference's thread-per-seed + pad + count + compact pipeline):
+//  * the number of edges a seed emits, min(deg, fanout), is known from indptr alone, so the output
+//    offsets are computed BEFORE sampling (count kernel -> one-workgroup scan) and the sampler
+//    writes the compacted COO directly: no padded temporaries, no compaction pass;
+//  * inside the sampler a workgroup owns S consecutive seeds.  Phase A (one lane per long row)
+//    resolves WHICH CSR positions are emitted -- for khop2 by simulating the partial Fisher-Yates
+//    on positions only (LDS-resident swap log, no memory traffic), for khop0 by a wave-parallel
+//    reservoir (LDS atomicMax of the winning j per slot).  Phase B is output-slot-parallel: lane p
+//    handles output edge p, so the writes of out_src/out_dst are fully coalesced and the CSR reads of
+//    short rows are contiguous; every lane has independent loads in flight.  Phase C (khop2) applies
+//    the row mutation with the values phase B already fetched;
+//  * sizes may live on the device (d_num_input) so layers chain without a host round trip.
+#include "fgnn_device.h"
+
+namespace fgnn {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// count: c_i = min(deg(input[i]), fanout); one partial sum per workgroup of S seeds
+template <int S>
+__global__ __launch_bounds__(S) void khop_count_kernel_s(const uint32_t *__restrict__ indptr,
+                                                         const uint32_t *__restrict__ input, size_t num_input,
+                                                         const uint32_t *d_num_input, size_t cap, uint32_t fanout,
+                                                         uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t sh[S / kWave];
+  const size_t n = resolve_count(num_input, d_num_input, cap);
+  const size_t i = (size_t)blockIdx.x * S + threadIdx.x;
+  uint32_t c = 0;
+  if (i < n) {
+    const uint32_t rid = input[i];
+    const uint32_t len = indptr[rid + 1] - indptr[rid];
+    c = len < fanout ? len : fanout;
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan<S / kWave>(c, sh, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// locate the seed that owns output slot p: largest k with lo[k] <= p   (lo has S+1 entries)
+template <int S>
+__device__ __forceinline__ int owner_of_slot(const uint32_t *lo, uint32_t p) {
+  int a = 0, b = S;  // invariant: lo[a] <= p < lo[b]
+#pragma unroll
+  for (int step = S; step > 1; step >>= 1) {
+    const int mid = (a + b) >> 1;
+    if (lo[mid] <= p) a = mid; else b = mid;
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KHOP2 == false : reservoir sampling (khop0.cu:41-90), CSR untouched
+// KHOP2 == true  : partial Fisher-Yates in place (khop2.cu:41-89)
+// S seeds per workgroup, S threads.  Dynamic LDS: KHOP2 ? 3*F*S words : F*S words.
+template <int S, bool KHOP2>
+__global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restrict__ indptr, uint32_t *indices,
+                                                        const uint32_t *__restrict__ input, size_t num_input,
+                                                        const uint32_t *d_num_input, size_t cap, uint32_t F,
+                                                        const uint32_t *__restrict__ block_offsets,
+                                                        uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
+                                                        int src_mode, uint64_t seed, uint64_t batch_key,
+                                                        uint32_t tag) {
+  constexpr int NW = S / kWave;
+  extern __shared__ uint32_t dyn[];
+  __shared__ uint32_t sh_scan[NW > 0 ? NW : 1];
+  __shared__ uint32_t sh_off[S], sh_len[S], sh_rid[S], sh_lo[S + 1];
+
+  uint32_t *sh_o = dyn;                         // [F][S] khop2: origin position, then fetched value
+  uint32_t *sh_s = dyn + (size_t)F * S;         // [F][S] khop2: swap-log position s_j
+  uint32_t *sh_w = dyn + (size_t)2 * F * S;     // [F][S] khop2: origin written to s_j, then its value
+
+  const int tid = threadIdx.x;
+  const size_t n = resolve_count(num_input, d_num_input, cap);
+  const size_t first = (size_t)blockIdx.x * S;
+  if (first >= n) return;  // whole workgroup exits together
+  const size_t i = first + tid;
+
+  uint32_t rid = 0, off = 0, len = 0;
+  if (i < n) {
+    rid = input[i];
+    off = indptr[rid];
+    len = indptr[rid + 1] - off;
+  }
+  const uint32_t c = len < F ? len : F;
+  uint32_t total;
+  const uint32_t lo = block_exclusive_scan<NW>(c, sh_scan, &total);
+  sh_off[tid] = off;
+  sh_len[tid] = len;
+  sh_rid[tid] = rid;
+  sh_lo[tid] = lo;
+  if (tid == 0) sh_lo[S] = total;
+  const bool big = len > F;
+
+  // ---- phase A: which CSR positions does a long row emit? ---------------------------------
+  if (KHOP2) {
+    if (big) {
+      // Simulate `for j: sel = draw % (len-j); emit A[sel]; swap(A[sel], A[len-1-j])` on POSITIONS.
+      // Content of a position p at step j = origin written by the last earlier step i with
+      // s_i == p, else p itself (a consumed tail position len-1-i is never touched again).
+      //   o_j = content(sel_j)      -> emitted origin
+      //   w_j = content(len-1-j)    -> origin that moves into position sel_j
+      u32x4 blk{0, 0, 0, 0};
+      for (uint32_t j = 0; j < F; ++j) {
+        if ((j & 3u) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 2);
+        const uint32_t sel = pick_word(blk, j) % (len - j);
+        const uint32_t t = len - 1 - j;
+        uint32_t o = sel, w = t;
+        for (uint32_t q = 0; q < j; ++q) {
+          const uint32_t sq = sh_s[q * S + tid];
+          const uint32_t wq = sh_w[q * S + tid];
+          if (sq == sel) o = wq;
+          if (sq == t) w = wq;
+        }
+        sh_s[j * S + tid] = sel;
+        sh_w[j * S + tid] = w;
+        sh_o[j * S + tid] = o;
+      }
+    }
+  } else {
+    // reservoir: slot k ends up with A[max{j >= F : draw_j % (j+1) == k}], or A[k] if none.
+    for (uint32_t q = 0; q < F; ++q) sh_o[q * S + tid] = q;
+    __syncthreads();
+    // wave-parallel over each long row of this workgroup (rows can be millions long)
+    for (int k = wave_id(); k < S; k += NW) {
+      const uint32_t klen = sh_len[k];
+      if (klen <= F) continue;  // wave-uniform
+      const uint32_t item = (uint32_t)(first + k);
+      // lane handles 4 consecutive j (one Philox block): j4 = 4*(F/4 + lane + 64*it)
+      for (uint32_t jb = (F >> 2) + lane_id(); (jb << 2) < klen; jb += kWave) {
+        const u32x4 blk = philox_block(seed, batch_key, tag, item, jb);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t j = (jb << 2) + u;
+          if (j >= F && j < klen) {
+            const uint32_t kk = pick_word(blk, u) % (j + 1);
+            if (kk < F) atomicMax(&sh_o[kk * S + k], j);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: one lane per output edge --------------------------------------------------
+  const size_t base = block_offsets[blockIdx.x];
+  for (uint32_t p = tid; p < total; p += S) {
+    const int k = owner_of_slot<S>(sh_lo, p);
+    const uint32_t j = p - sh_lo[k];
+    const uint32_t koff = sh_off[k];
+    const bool kbig = sh_len[k] > F;
+    const uint32_t pos = kbig ? sh_o[j * S + k] : j;
+    const uint32_t v = indices[koff + pos];
+    out_dst[base + p] = v;
+    out_src[base + p] = src_mode == FGNN_SRC_LOCAL ? (uint32_t)(first + k) : sh_rid[k];
+    if (KHOP2 && kbig) {
+      const uint32_t wv = indices[koff + sh_w[j * S + k]];
+      sh_o[j * S + k] = v;    // value that lands in the consumed tail slot len-1-j
+      sh_w[j * S + k] = wv;   // value that lands in position s_j
+    }
+  }
+
+  // ---- phase C (khop2): apply the swaps to the CSR row ---------------------------------------
+  if (KHOP2) {
+    __syncthreads();  // every read of the old row contents above has been consumed
+    for (uint32_t p = tid; p < total; p += S) {
+      const int k = owner_of_slot<S>(sh_lo, p);
+      const uint32_t klen = sh_len[k];
+      if (klen <= F) continue;
+      const uint32_t j = p - sh_lo[k];
+      const uint32_t koff = sh_off[k];
+      indices[koff + klen - 1 - j] = sh_o[j * S + k];
+      const uint32_t s = sh_s[j * S + k];
+      if (s < klen - F) {  // positions >= len-F are consumed tail slots, written above
+        bool last = true;
+        for (uint32_t q = j + 1; q < F; ++q) last = last && (sh_s[q * S + k] != s);
+        if (last) indices[koff + s] = sh_w[j * S + k];
+      }
+    }
+  }
+}
+
+template <bool KHOP2>
+int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
+                size_t ws_bytes, hipStream_t stream) {
+  if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
+  if (!d_num_input) cap = num_input;
+  if (cap == 0) {
+    if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), stream));
+    return FGNN_OK;
+  }
+  if (cap > 0xffffffffull) return FGNN_EINVAL;
+  const uint32_t F = (uint32_t)fanout;
+  const uint32_t tag = ((KHOP2 ? FGNN_KHOP2 : FGNN_KHOP0) << 8) | (layer & 0xffu);
+  const size_t words_per_seed = (KHOP2 ? 3u : 1u) * (size_t)F;
+  // seeds per workgroup: as many as fit in ~120 KiB of LDS (160 KiB per CU on gfx950)
+  int S = 256;
+  while (S > 64 && words_per_seed * S * 4 > 120 * 1024) S >>= 1;
+  if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
+  const size_t nb = div_up(cap, (size_t)S);
+  if (ws_bytes < (nb + 1) * sizeof(uint32_t)) return FGNN_ENOSPC;
+  uint32_t *sums = static_cast<uint32_t *>(ws);
+  const size_t lds = words_per_seed * S * sizeof(uint32_t);
+
+#define FGNN_LAUNCH_KHOP(SS)                                                                                   \
+  do {                                                                                                         \
+    hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,     \
+                       d_num_input, cap, F, sums);                                                             \
+    if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream) != FGNN_OK)             \
+      return FGNN_EHIP;                                                                                        \
+    static bool attr_done_##SS = false;                                                                        \
+    if (!attr_done_##SS) {                                                                                     \
+      FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, KHOP2>),       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
+      attr_done_##SS = true;                                                                                   \
+    }                                                                                                          \
+    hipLaunchKernelGGL((khop_sample_kernel<SS, KHOP2>), dim3(nb), dim3(SS), lds, stream, indptr, indices,      \
+                       input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
+                       batch_key, tag);                                                                        \
+  } while (0)
+
+  if (S == 256) FGNN_LAUNCH_KHOP(256);
+  else if (S == 128) FGNN_LAUNCH_KHOP(128);
+  else FGNN_LAUNCH_KHOP(64);
+#undef FGNN_LAUNCH_KHOP
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
+
+}  // namespace
+}  // namespace fgnn
+
+extern "C" int fgnn_sample_khop0(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                                 size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                 uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed,
+                                 uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes, void *stream) {
+  return fgnn::launch_khop<false>(indptr, const_cast<uint32_t *>(indices), input, num_input, d_num_input,
+                                  num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed, batch_key, layer,
+                                  ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fgnn_sample_khop2(const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                                 const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
+                                 uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                                 uint32_t layer, void *ws, size_t ws_bytes, void *stream) {
+  return fgnn::launch_khop<true>(indptr, indices, input, num_input, d_num_input, num_input_cap, fanout, out_src,
+                                 out_dst, d_num_out, src_mode, seed, batch_key, layer, ws, ws_bytes,
+                                 static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,37 @@
+// scan.hip -- single-workgroup exclusive scan of per-block partial sums (<= a few 100k entries).
+// Replaces cub::DeviceScan::ExclusiveSum at the reference's call sites
+// (cuda_sampling_khop2.cu:221-229, cuda_hashtable.cu:757-768, cuda_cache.cu:193-205).
+#include "fgnn_device.h"
+
+namespace fgnn {
+
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(uint32_t *sums, size_t n, size_t *total64,
+                                                                    uint32_t *total32, const uint32_t *accum,
+                                                                    uint32_t *accum_out) {
+  __shared__ uint32_t sh[kScanBlock / kWave];
+  uint32_t carry = 0;
+  for (size_t base = 0; base < n; base += kScanBlock) {
+    const size_t i = base + threadIdx.x;
+    const uint32_t v = i < n ? sums[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<kScanBlock / kWave>(v, sh, &tot);
+    if (i < n) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    if (total64) *total64 = carry;
+    if (total32) *total32 = carry;
+    if (accum_out) *accum_out = (accum ? *accum : 0u) + carry;
+  }
+}
+
+int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *total32, const uint32_t *accum,
+                           uint32_t *accum_out, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream, sums, n, total64, total32, accum,
+                     accum_out);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
+
+}  // namespace fgnn

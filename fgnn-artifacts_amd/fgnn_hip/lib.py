@@ -1,0 +1,213 @@
+"""ctypes binding of fgnn-artifacts_amd/lib/libfgnn_hip.so (include/fgnn_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call below takes torch CUDA
+(ROCm) tensors, passes their raw device pointers through the C ABI and enqueues HIP kernels on the
+current torch stream.  There is NO fallback: if the library is missing, or no GPU is present, the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip.so")
+
+SRC_GLOBAL, SRC_LOCAL = 0, 1
+EMPTY = 0xFFFFFFFF
+F32, F64, F16, U8, I32, I8, I64 = range(7)
+_T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8: U8, torch.int32: I32,
+         torch.int8: I8, torch.int64: I64}
+
+EXPORTS = [
+    "fgnn_version", "fgnn_device_count", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
+    "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
+    "fgnn_hashtable_d_num_items", "fgnn_get_miss_cache_index", "fgnn_gather_rows",
+]
+
+_lib = None
+
+
+class FgnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FgnnError(f"{LIB_PATH} is missing: build it with `make -C fgnn-artifacts_amd/csrc` "
+                            "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.fgnn_version.restype = C.c_char_p
+        L.fgnn_scratch_bytes.restype = C.c_size_t
+        L.fgnn_scratch_bytes.argtypes = [C.c_size_t]
+        L.fgnn_hashtable_create.restype = C.c_void_p
+        L.fgnn_hashtable_create.argtypes = [C.c_size_t, C.POINTER(C.c_int)]
+        L.fgnn_hashtable_destroy.argtypes = [C.c_void_p]
+        L.fgnn_hashtable_capacity.restype = C.c_size_t
+        L.fgnn_hashtable_capacity.argtypes = [C.c_void_p]
+        L.fgnn_hashtable_n2o.restype = C.c_void_p
+        L.fgnn_hashtable_n2o.argtypes = [C.c_void_p]
+        L.fgnn_hashtable_d_num_items.restype = C.c_void_p
+        L.fgnn_hashtable_d_num_items.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        raise FgnnError(f"{what} failed with code {code}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FgnnError("fgnn_hip kernels need device tensors (no CPU fallback)")
+
+
+def _as_u32(t):
+    """uint32 storage viewed through torch.int32 (torch has no native uint32 arithmetic)."""
+    assert t.dtype in (torch.int32, torch.uint32) and t.is_contiguous()
+    return t
+
+
+def scratch(n_cap, device):
+    return torch.empty(load().fgnn_scratch_bytes(int(n_cap)), dtype=torch.uint8, device=device)
+
+
+def sample_khop(kind, indptr, indices, inp, fanout, seed, batch_key, layer, src_mode=SRC_GLOBAL, d_num_input=None,
+                ws=None):
+    """kind in {'khop0','khop2'}.  Returns (out_src, out_dst, d_num_out) -- device tensors, sized for the
+    worst case num_input*fanout; d_num_out is an int64[1] device scalar.  Asynchronous."""
+    L = load()
+    _need_gpu(indptr, indices, inp)
+    n = inp.numel()
+    dev = inp.device
+    out_src = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    d_num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    if ws is None:
+        ws = scratch(n, dev)
+    fn = L.fgnn_sample_khop0 if kind == "khop0" else L.fgnn_sample_khop2
+    code = fn(_ptr(indptr), _ptr(indices), _ptr(inp), C.c_size_t(n), _ptr(d_num_input), C.c_size_t(n),
+              C.c_size_t(fanout), _ptr(out_src), _ptr(out_dst), _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed),
+              C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws), C.c_size_t(ws.numel()), _stream())
+    _check(code, "fgnn_sample_" + kind)
+    return out_src, out_dst, d_num_out
+
+
+class HashTable:
+    """OrderedHashTable (cuda_hashtable.h:99-149) on the GPU."""
+
+    def __init__(self, max_items, device="cuda:0"):
+        L = load()
+        torch.cuda.set_device(device)
+        err = C.c_int(0)
+        self.h = C.c_void_p(L.fgnn_hashtable_create(C.c_size_t(max_items), C.byref(err)))
+        if not self.h:
+            raise FgnnError(f"fgnn_hashtable_create failed with code {err.value}")
+        self.max_items = max_items
+        self.device = torch.device(device)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.fgnn_hashtable_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        _check(load().fgnn_hashtable_reset(self.h, _stream()), "fgnn_hashtable_reset")
+
+    def fill_unique(self, items):
+        _need_gpu(items)
+        _check(load().fgnn_hashtable_fill_unique(self.h, _ptr(items), C.c_size_t(items.numel()), _stream()),
+               "fgnn_hashtable_fill_unique")
+
+    def fill_duplicates(self, items, num_items=None, d_num_items=None, want_mapped=True, ws=None):
+        """Returns mapped (int32 device tensor, local id per item) or None."""
+        _need_gpu(items)
+        cap = items.numel()
+        n = cap if num_items is None else num_items
+        mapped = torch.empty(max(cap, 1), dtype=torch.int32, device=items.device) if want_mapped else None
+        if ws is None:
+            ws = scratch(cap, items.device)
+        _check(load().fgnn_hashtable_fill_duplicates(self.h, _ptr(items), C.c_size_t(n), _ptr(d_num_items),
+                                                     C.c_size_t(cap), _ptr(mapped), _ptr(ws), C.c_size_t(ws.numel()),
+                                                     _stream()), "fgnn_hashtable_fill_duplicates")
+        return mapped
+
+    def map(self, items):
+        _need_gpu(items)
+        mapped = torch.empty(max(items.numel(), 1), dtype=torch.int32, device=items.device)
+        _check(load().fgnn_hashtable_map(self.h, _ptr(items), C.c_size_t(items.numel()), C.c_void_p(0),
+                                         C.c_size_t(items.numel()), _ptr(mapped), _stream()), "fgnn_hashtable_map")
+        return mapped[:items.numel()]
+
+    def num_items(self):
+        """Synchronises."""
+        p = load().fgnn_hashtable_d_num_items(self.h)
+        t = _wrap_device_u32(p, 1, self.device)
+        return int(t.cpu()[0])
+
+    def d_num_items_ptr(self):
+        return load().fgnn_hashtable_d_num_items(self.h)
+
+    def unique(self, n=None):
+        """Copy of the N2O list (first n entries; default all current items).  Synchronises if n is None."""
+        if n is None:
+            n = self.num_items()
+        p = load().fgnn_hashtable_n2o(self.h)
+        return _wrap_device_u32(p, n, self.device).clone()
+
+
+class _DevArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _wrap_device_u32(ptr, n, device):
+    if n == 0:
+        return torch.empty(0, dtype=torch.int32, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, "<i4"), device=device)
+
+
+def get_miss_cache_index(table, nodes, num_nodes=None, d_num_nodes=None, ws=None):
+    """Returns (miss_src, miss_dst, cache_src, cache_dst, d_counts[2]) device tensors sized len(nodes)."""
+    _need_gpu(table, nodes)
+    cap = nodes.numel()
+    n = cap if num_nodes is None else num_nodes
+    dev = nodes.device
+    outs = [torch.empty(max(cap, 1), dtype=torch.int32, device=dev) for _ in range(4)]
+    d_counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    if ws is None:
+        ws = scratch(cap, dev)
+    _check(load().fgnn_get_miss_cache_index(_ptr(table), _ptr(nodes), C.c_size_t(n), _ptr(d_num_nodes),
+                                            C.c_size_t(cap), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                            _ptr(outs[3]), _ptr(d_counts), _ptr(ws), C.c_size_t(ws.numel()),
+                                            _stream()), "fgnn_get_miss_cache_index")
+    return outs[0], outs[1], outs[2], outs[3], d_counts
+
+
+def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
+    """out[dst_index[i] or i] = src[src_index[i] or i]; rows are the trailing dims."""
+    _need_gpu(out)
+    if n is None:
+        n = (src_index if src_index is not None else dst_index if dst_index is not None else src).shape[0]
+    dim = 1
+    for s in out.shape[1:]:
+        dim *= s
+    assert out.dtype == src.dtype and out.is_contiguous() and src.is_contiguous()
+    _check(load().fgnn_gather_rows(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), C.c_size_t(n), _ptr(d_n),
+                                   C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]), _stream()),
+           "fgnn_gather_rows")
+    return out

@@ -1,0 +1,95 @@
+"""Host-side mirror of the reference's samgraph/common/__init__.py (enum block :47-265, ctypes binding
+:268-500): same constant names and values, same `SamGraphBasics` method surface, bound to the
+`samgraph_*` C ABI of this repo's HIP engine library instead of the CUDA extension.
+
+The numeric values are part of the API contract (scripts index profiler tables with them); they are
+pinned by tests/test_python_constants.py against tests/golden/py_constants.json, which was produced by
+importing the reference module in the build container.
+"""
+import ctypes
+import os
+import sys
+
+_THIS = sys.modules[__name__]
+
+
+def _enum(names, start=0):
+    for i, n in enumerate(names):
+        setattr(_THIS, n, start + i)
+    return len(names)
+
+
+# DeviceType, SampleType, RunArch, CachePolicy -- common.h:38-92
+_enum(["kCPU", "kMMAP", "kGPU"])
+_enum(["kKHop0", "kKHop1", "kWeightedKHop", "kRandomWalk", "kWeightedKHopPrefix", "kKHop2", "kWeightedKHopHashDedup"])
+_enum(["kArch%d" % i for i in range(8)])
+_enum(["kCacheByDegree", "kCacheByHeuristic", "kCacheByPreSample", "kCacheByDegreeHop", "kCacheByPreSampleStatic",
+       "kCacheByFakeOptimal", "kDynamicCache", "kCacheByRandom"])
+
+
+def cpu(device_id=0):
+    return "cpu:{:}".format(device_id)
+
+
+def gpu(device_id=0):
+    return "cuda:{:}".format(device_id)
+
+
+def simple_hash(x):
+    return hash(x)
+
+
+sample_types = {
+    "khop0": kKHop0, "khop1": kKHop1, "khop2": kKHop2, "random_walk": kRandomWalk,  # noqa: F821
+    "weighted_khop": kWeightedKHop, "weighted_khop_prefix": kWeightedKHopPrefix,  # noqa: F821
+    "weighted_khop_hash_dedup": kWeightedKHopHashDedup,  # noqa: F821
+}
+
+builtin_archs = {
+    "arch0": {"arch": kArch0, "sampler_ctx": cpu(), "trainer_ctx": gpu(0)},  # noqa: F821
+    "arch1": {"arch": kArch1, "sampler_ctx": gpu(0), "trainer_ctx": gpu(0)},  # noqa: F821
+    "arch2": {"arch": kArch2, "sampler_ctx": gpu(0), "trainer_ctx": gpu(0)},  # noqa: F821
+    "arch3": {"arch": kArch3, "sampler_ctx": gpu(0), "trainer_ctx": gpu(1)},  # noqa: F821
+    "arch4": {"arch": kArch4, "sampler_ctx": gpu(1), "trainer_ctx": gpu(0)},  # noqa: F821
+    "arch5": {"arch": kArch5},  # noqa: F821
+    "arch6": {"arch": kArch6},  # noqa: F821
+    "arch7": {"arch": kArch7},  # noqa: F821
+}
+
+cache_policies = {
+    "degree": kCacheByDegree, "heuristic": kCacheByHeuristic, "pre_sample": kCacheByPreSample,  # noqa: F821
+    "degree_hop": kCacheByDegreeHop, "presample_static": kCacheByPreSampleStatic,  # noqa: F821
+    "fake_optimal": kCacheByFakeOptimal, "dynamic_cache": kDynamicCache, "random": kCacheByRandom,  # noqa: F821
+}
+
+# profiler.h:30-131 -- init / step / epoch log items and trace events
+_INIT_ITEMS = ["L1Common", "L1Sampler", "L1Trainer", "L2LoadDataset", "L2DistQueue", "L2Presample", "L2InternalState",
+               "L2BuildCache", "L3LoadDatasetMMap", "L3LoadDatasetCopy", "L3DistQueueAlloc", "L3DistQueuePin",
+               "L3DistQueuePush", "L3PresampleInit", "L3PresampleSample", "L3PresampleCopy", "L3PresampleCount",
+               "L3PresampleSort", "L3PresampleReset", "L3PresampleGetRank", "L3InternalStateCreateCtx",
+               "L3InternalStateCreateStream"]
+kNumLogInitItems = _enum(["kLogInit" + n for n in _INIT_ITEMS])
+
+_STEP_ITEMS = (["L1NumSample", "L1NumNode", "L1SampleTime", "L1SendTime", "L1RecvTime", "L1CopyTime", "L1ConvertTime",
+                "L1TrainTime", "L1FeatureBytes", "L1LabelBytes", "L1IdBytes", "L1GraphBytes", "L1MissBytes",
+                "L1PrefetchAdvanced", "L1GetNeighbourTime", "L2ShuffleTime", "L2LastLayerTime", "L2LastLayerSize",
+                "L2CoreSampleTime", "L2IdRemapTime", "L2GraphCopyTime", "L2IdCopyTime", "L2ExtractTime",
+                "L2FeatCopyTime", "L2CacheCopyTime", "L3KHopSampleCooTime", "L3KHopSampleSortCooTime",
+                "L3KHopSampleCountEdgeTime", "L3KHopSampleCompactEdgesTime", "L3RandomWalkSampleCooTime",
+                "L3RandomWalkTopKTime"] + ["L3RandomWalkTopKStep%dTime" % i for i in range(1, 12)] +
+               ["L3RemapFillUniqueTime", "L3RemapPopulateTime", "L3RemapMapNodeTime", "L3RemapMapEdgeTime",
+                "L3CacheGetIndexTime", "L3CacheCopyIndexTime", "L3CacheExtractMissTime", "L3CacheCopyMissTime",
+                "L3CacheCombineMissTime", "L3CacheCombineCacheTime"])
+# the reference spells two names with a capital K (common/__init__.py:225,235); scripts use those spellings
+_enum([("KLog" if n == "L3CacheCopyIndexTime" else "kLog") + n for n in _STEP_ITEMS])
+
+_EPOCH_ITEMS = ["SampleTime", "SampleGetCacheMissIndexTime", "SampleSendTime", "SampleTotalTime", "CopyTime",
+                "ConvertTime", "TrainTime", "TotalTime", "FeatureBytes", "MissBytes"]
+_enum([("KLogEpoch" if n == "SampleGetCacheMissIndexTime" else "kLogEpoch") + n for n in _EPOCH_ITEMS])
+
+_enum(["kL0Event_Train_Step", "kL1Event_Sample", "kL2Event_Sample_Shuffle", "kL2Event_Sample_Core",
+       "kL2Event_Sample_IdRemap", "kL1Event_Copy", "kL2Event_Copy_Id", "kL2Event_Copy_Graph", "kL2Event_Copy_Extract",
+       "kL2Event_Copy_FeatCopy", "kL2Event_Copy_CacheCopy", "kL3Event_Copy_CacheCopy_GetIndex",
+       "kL3Event_Copy_CacheCopy_CopyIndex", "kL3Event_Copy_CacheCopy_ExtractMiss", "kL3Event_Copy_CacheCopy_CopyMiss",
+       "kL3Event_Copy_CacheCopy_CombineMiss", "kL3Event_Copy_CacheCopy_CombineCache", "kL1Event_Convert",
+       "kL1Event_Train"])

@@ -37,11 +37,17 @@ void fgnn_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void fgnn_philox_draw(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t draw,
+void fgnn_philox_draw(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t block,
                       uint32_t out[4]) {
-  uint32_t ctr[4] = {draw, item, tag, (uint32_t)batch_key};
+  uint32_t ctr[4] = {block, item, tag, (uint32_t)batch_key};
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(batch_key >> 32)};
   fgnn_philox4x32_10(ctr, key, out);
+}
+
+uint32_t fgnn_philox_u32(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t j) {
+  uint32_t r[4];
+  fgnn_philox_draw(seed, batch_key, tag, item, j >> 2, r);
+  return r[j & 3u];
 }
 
 /* ------------------------------------------------------------------ mt19937 ---------------- */
@@ -168,9 +174,7 @@ void fgnn_oracle_sample_khop0(const uint32_t *indptr, const uint32_t *indices, c
           k = fgnn_mt19937_uniform_int(&rng->mt, 0, (uint32_t)(j + 1));
         } else {
           /* cuda_sampling_khop0.cu:80: curand() % (j + 1) */
-          uint32_t r[4];
-          fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
-          k = r[0] % (uint32_t)(j + 1);
+          k = fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j) % (uint32_t)(j + 1);
         }
         if (k < fanout) d[k] = indices[off + j];
       }
@@ -203,9 +207,7 @@ void fgnn_oracle_sample_khop2(const uint32_t *indptr, uint32_t *indices, const u
           sel = fgnn_mt19937_uniform_int(&rng->mt, 0, (uint32_t)(len - j - 1));
         } else {
           /* cuda_sampling_khop2.cu:75: curand() % (len - j) */
-          uint32_t r[4];
-          fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
-          sel = r[0] % (uint32_t)(len - j);
+          sel = fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j) % (uint32_t)(len - j);
         }
         const uint32_t picked = indices[off + sel];
         s[j] = rid;
@@ -260,9 +262,8 @@ void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint3
       continue;
     }
     const float upbound = prob_prefix[off + len - 1];
-    uint32_t r[4];
-    fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j, r);
-    const float x = philox_uniform_float(r[0]) * upbound;
+    const float x =
+        philox_uniform_float(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j)) * upbound;
     uint32_t pick;
     if (x <= prob_prefix[off]) {
       pick = indices[off];
@@ -325,12 +326,14 @@ void fgnn_oracle_sample_random_walk(const uint32_t *indptr, const uint32_t *indi
         const uint32_t off = indptr[node];
         const uint32_t len = indptr[node + 1] - off;
         if (len == 0) { visited[pos] = FGNN_EMPTY_KEY; node = FGNN_EMPTY_KEY; continue; }
-        uint32_t r[4];
-        fgnn_philox_draw(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)(walk * walk_len + step), r);
-        const uint32_t k = r[0] % len;
+        /* two draws per step: 2d picks the neighbour, 2d+1 decides the restart */
+        const uint32_t d = (uint32_t)(walk * walk_len + step);
+        const uint32_t k = fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * d) % len;
         node = indices[off + k];
         visited[pos] = node;
-        if (philox_uniform_double(r[1]) < restart_prob) node = FGNN_EMPTY_KEY;
+        if (philox_uniform_double(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * d + 1u)) <
+            restart_prob)
+          node = FGNN_EMPTY_KEY;
       }
     }
     /* FrequencyHashmap::GetTopK: distinct (seed, dst) with counts, (count desc, first pos asc) */

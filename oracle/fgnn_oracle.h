@@ -52,9 +52,13 @@ enum { FGNN_RNG_MT_CPU_TWIN = 0, FGNN_RNG_PHILOX = 1 };
 /* Philox4x32-10 (Salmon et al., SC'11; the same generator cuRAND/rocRAND ship as "Philox").  */
 void fgnn_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* The build's draw addressing.  tag = (sample_type << 8) | layer. */
-void fgnn_philox_draw(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t draw,
+/* The build's draw addressing.  tag = (sample_type << 8) | layer; `item` = position of the seed in
+ * the layer's input list.  One Philox block = counter (block, item, tag, lo32(batch_key)) under key
+ * (lo32(seed), hi32(seed) ^ hi32(batch_key)); draw number j of an item is word (j & 3) of block
+ * (j >> 2), so a consumer of consecutive draws pays one Philox evaluation per four draws. */
+void fgnn_philox_draw(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t block,
                       uint32_t out[4]);
+uint32_t fgnn_philox_u32(uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t item, uint32_t j);
 
 /* std::mt19937 (default seed 5489) + libstdc++-11 uniform_int_distribution<uint32_t>(lo,hi). */
 typedef struct {

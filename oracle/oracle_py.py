@@ -86,10 +86,10 @@ def philox(ctr, key):
     return list(o)
 
 
-def philox_draw(seed, batch_key, tag, item, draw):
+def philox_draw(seed, batch_key, tag, item, block):
     o = (C.c_uint32 * 4)()
     lib().fgnn_philox_draw(C.c_uint64(seed), C.c_uint64(batch_key), C.c_uint32(tag), C.c_uint32(item),
-                           C.c_uint32(draw), o)
+                           C.c_uint32(block), o)
     return list(o)
 
 

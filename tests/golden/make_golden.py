@@ -162,7 +162,7 @@ def golden_constants():
     spec = importlib.util.spec_from_file_location("ref_samgraph_common", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    consts = {k: v for k, v in vars(mod).items() if k.startswith("k") and isinstance(v, int)}
+    consts = {k: v for k, v in vars(mod).items() if k[:1] in "kK" and k[1:2].isupper() and isinstance(v, int)}
     consts_extra = dict(sample_types=mod.sample_types, cache_policies=getattr(mod, "cache_policies", None),
                         builtin_archs=mod.builtin_archs)
     with open(os.path.join(HERE, "py_constants.json"), "w") as f:

@@ -1,0 +1,234 @@
+"""GPU parity: the HIP path (through the C ABI of libfgnn_hip.so) against the oracle (Philox mode) on the
+same seeded inputs.  Bar: bit-exact -- all of this is integer / index / byte work."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5A4D47
+
+
+def dev(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).cuda()
+
+
+def host_u32(t, n=None):
+    a = t.cpu().numpy()
+    if n is not None:
+        a = a[:n]
+    return a.view(np.uint32) if a.dtype == np.int32 else a
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from fgnn_hip import lib
+    lib.load()
+    assert torch.cuda.is_available()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def graph():
+    from fgnn_hip import synth
+    return synth.powerlaw_csr(3000, 60000, seed=21)
+
+
+def _seeds(n, num_node, seed=1):
+    return np.random.default_rng(seed).permutation(num_node)[:n].astype(np.uint32)
+
+
+@pytest.mark.parametrize("kind", ["khop0", "khop2"])
+@pytest.mark.parametrize("fanout", [1, 3, 10, 25, 45, 90])
+def test_sampler_matches_oracle(hip, oracle, graph, kind, fanout):
+    indptr, indices = graph
+    d_indptr, d_indices = dev(indptr), dev(indices.copy())
+    o_indices = indices.copy()
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    ofn = oracle.sample_khop0 if kind == "khop0" else oracle.sample_khop2
+    # three calls in a row: khop2's CSR mutation must carry identically on both sides
+    for call, (n, layer) in enumerate([(700, 1), (1300, 0), (5, 1)]):
+        inp = _seeds(n, len(indptr) - 1, seed=call)
+        for src_mode in (hip.SRC_GLOBAL, hip.SRC_LOCAL) if call == 0 else (hip.SRC_GLOBAL,):
+            if src_mode == hip.SRC_LOCAL and kind == "khop2":
+                continue  # a second khop2 call would mutate the CSR again
+            out_src, out_dst, d_num = hip.sample_khop(kind, d_indptr, d_indices, dev(inp), fanout, SEED, 77 + call,
+                                                      layer, src_mode)
+            if src_mode == hip.SRC_GLOBAL:
+                o_src, o_dst = ofn(indptr, o_indices, inp, fanout, rng, 77 + call, layer)
+            ne = int(d_num.cpu()[0])
+            assert ne == len(o_dst)
+            np.testing.assert_array_equal(host_u32(out_dst, ne), o_dst)
+            if src_mode == hip.SRC_GLOBAL:
+                np.testing.assert_array_equal(host_u32(out_src, ne), o_src)
+            else:
+                pos = {int(v): i for i, v in enumerate(inp)}
+                np.testing.assert_array_equal(host_u32(out_src, ne), [pos[int(v)] for v in o_src])
+        np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+    if kind == "khop2" and fanout < 45:
+        assert (o_indices != indices).any()
+
+
+@pytest.mark.parametrize("kind", ["khop0", "khop2"])
+def test_sampler_edge_cases(hip, oracle, kind):
+    # rows: 0,3,0,1,5,0,6 neighbours -- isolated nodes, rows shorter / equal / longer than the fanout
+    indptr = np.array([0, 0, 3, 3, 4, 9, 9, 15], dtype=np.uint32)
+    indices = np.array([4, 6, 1, 0, 1, 2, 3, 5, 6, 0, 1, 2, 3, 4, 5], dtype=np.uint32)
+    ofn = oracle.sample_khop0 if kind == "khop0" else oracle.sample_khop2
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    d_indptr, d_indices = dev(indptr), dev(indices.copy())
+    o_indices = indices.copy()
+    for inp in (np.array([], dtype=np.uint32), np.arange(7, dtype=np.uint32), np.array([6, 5, 4], dtype=np.uint32),
+                np.array([0, 2, 5], dtype=np.uint32)):
+        for fanout in (1, 3, 5, 6, 8):
+            o_src, o_dst = ofn(indptr, o_indices, inp, fanout, rng, 5, 0)
+            d_inp = dev(inp) if len(inp) else torch.empty(0, dtype=torch.int32, device="cuda")
+            out_src, out_dst, d_num = hip.sample_khop(kind, d_indptr, d_indices, d_inp, fanout, SEED, 5, 0)
+            ne = int(d_num.cpu()[0])
+            assert ne == len(o_dst)
+            np.testing.assert_array_equal(host_u32(out_dst, ne), o_dst)
+            np.testing.assert_array_equal(host_u32(out_src, ne), o_src)
+            np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+def test_sampler_device_side_count(hip, oracle, graph):
+    """d_num_input overrides the host count: grids are sized by the cap, surplus workgroups exit."""
+    indptr, indices = graph
+    inp = _seeds(1000, len(indptr) - 1, seed=9)
+    d_n = torch.tensor([333], dtype=torch.int32, device="cuda")
+    out_src, out_dst, d_num = hip.sample_khop("khop0", dev(indptr), dev(indices), dev(inp), 7, SEED, 1, 0,
+                                              d_num_input=d_n)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_src, o_dst = oracle.sample_khop0(indptr, indices, inp[:333], 7, rng, 1, 0)
+    ne = int(d_num.cpu()[0])
+    assert ne == len(o_dst)
+    np.testing.assert_array_equal(host_u32(out_dst, ne), o_dst)
+
+
+def test_hashtable_matches_oracle(hip, oracle):
+    rs = np.random.default_rng(3)
+    num_node = 50000
+    seeds = rs.permutation(num_node)[:2000].astype(np.uint32)
+    ht = hip.HashTable(40000)
+    oht = oracle.HashTable(num_node, 40000)
+    for rep in range(2):  # second round after a reset
+        ht.reset()
+        oht.reset()
+        ht.fill_unique(dev(seeds))
+        assert oht.fill_unique(seeds) == 0
+        for n in (0, 1, 7000, 30000):
+            # skewed ids: many duplicates inside a call and against earlier calls
+            items = np.minimum((num_node * rs.random(n) ** 3).astype(np.uint32), num_node - 1)
+            d_items = dev(items) if n else torch.empty(0, dtype=torch.int32, device="cuda")
+            mapped = ht.fill_duplicates(d_items)
+            uniq = oht.fill_duplicates(items)
+            _, o_map = oht.map_edges(items, items)
+            assert ht.num_items() == len(uniq)
+            np.testing.assert_array_equal(host_u32(ht.unique()), uniq)
+            np.testing.assert_array_equal(host_u32(mapped, n), o_map)
+            if n:
+                np.testing.assert_array_equal(host_u32(ht.map(d_items)), o_map)
+        np.testing.assert_array_equal(host_u32(ht.unique())[:len(seeds)], seeds)
+
+
+def test_hashtable_device_side_count(hip, oracle):
+    rs = np.random.default_rng(4)
+    items = rs.integers(0, 5000, size=10000).astype(np.uint32)
+    ht = hip.HashTable(6000)
+    d_n = torch.tensor([4321], dtype=torch.int64, device="cuda")
+    mapped = ht.fill_duplicates(dev(items), d_num_items=d_n)
+    oht = oracle.HashTable(5000, 6000)
+    uniq = oht.fill_duplicates(items[:4321])
+    np.testing.assert_array_equal(host_u32(ht.unique()), uniq)
+    np.testing.assert_array_equal(host_u32(mapped, 4321), oht.map_edges(items[:4321], items[:4321])[1])
+
+
+@pytest.mark.parametrize("n,frac", [(0, 0.5), (1, 1.0), (5000, 0.0), (5000, 1.0), (70001, 0.3)])
+def test_cache_split_matches_oracle(hip, oracle, n, frac):
+    rs = np.random.default_rng(8)
+    num_node = 200000
+    rank = rs.permutation(num_node).astype(np.uint32)
+    table = oracle.cache_table_build(rank, int(num_node * frac), num_node)
+    nodes = rs.permutation(num_node)[:n].astype(np.uint32)
+    d_nodes = dev(nodes) if n else torch.empty(0, dtype=torch.int32, device="cuda")
+    ms, md, cs, cd, d_counts = hip.get_miss_cache_index(dev(table), d_nodes)
+    o = oracle.get_miss_cache_index(table, nodes)
+    nm, nc = [int(x) for x in d_counts.cpu()]
+    assert (nm, nc) == (len(o[0]), len(o[2])) and nm + nc == n
+    for got, want, k in ((ms, o[0], nm), (md, o[1], nm), (cs, o[2], nc), (cd, o[3], nc)):
+        np.testing.assert_array_equal(host_u32(got, k), want)
+
+
+@pytest.mark.parametrize("dtype,dim", [(np.float32, 100), (np.float32, 128), (np.float32, 256), (np.float32, 7),
+                                       (np.int64, 1), (np.float16, 24), (np.float16, 5), (np.uint8, 3),
+                                       (np.float64, 2)])
+def test_gather_matches_oracle(hip, oracle, dtype, dim):
+    rs = np.random.default_rng(2)
+    n_src, n = 5000, 3777
+    src = (rs.standard_normal((n_src, dim)) * 1000).astype(dtype)
+    idx = rs.integers(0, n_src, size=n).astype(np.uint32)
+    want = oracle.extract(src, idx)
+    got = torch.empty((n, dim), dtype=torch.from_numpy(src).dtype, device="cuda")
+    hip.gather_rows(got, dev(src), src_index=dev(idx))
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    # CombineMissData + CombineCacheData reassemble the batch feature tensor
+    table = oracle.cache_table_build(rs.permutation(n_src).astype(np.uint32), n_src // 3, n_src)
+    nodes = rs.permutation(n_src)[:n].astype(np.uint32)
+    ms, md, cs, cd = oracle.get_miss_cache_index(table, nodes)
+    cache_rows = np.zeros((n_src // 3, dim), dtype=dtype)
+    cache_rows[table[table != oracle.EMPTY]] = src[np.nonzero(table != oracle.EMPTY)[0]]
+    out = torch.zeros((n, dim), dtype=got.dtype, device="cuda")
+    miss_rows = dev(oracle.extract(src, ms))
+    if len(ms):
+        hip.gather_rows(out, miss_rows, src_index=None, dst_index=dev(md), n=len(ms))
+    if len(cs):
+        hip.gather_rows(out, dev(cache_rows), src_index=dev(cs), dst_index=dev(cd), n=len(cs))
+    assert out.cpu().numpy().tobytes() == src[nodes].tobytes()
+
+
+@pytest.mark.parametrize("kind,fanouts,batch", [("khop2", [25, 10], 2000), ("khop0", [5, 10, 15], 300),
+                                                ("khop2", [10, 5], 1)])
+def test_layered_pipeline_matches_oracle(hip, oracle, kind, fanouts, batch):
+    """DoGPUSample order (cuda_loops.cc:50-267) chained on the device with device-side counts only:
+    Reset, FillWithUnique, then per layer sample -> FillWithDuplicates(+map)."""
+    from fgnn_hip import synth
+    num_node = 100000
+    indptr, indices = synth.powerlaw_csr(num_node, 1500000, seed=5)
+    d_indptr, d_indices = dev(indptr), dev(indices.copy())
+    o_indices = indices.copy()
+    st = oracle.KHOP0 if kind == "khop0" else oracle.KHOP2
+    max_items = oracle.predict_num_nodes(batch, fanouts)
+    ht = hip.HashTable(max_items)
+    oht = oracle.HashTable(num_node, max_items)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for b in range(3):
+        seeds = _seeds(batch, num_node, seed=100 + b)
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, st, rng, b, oht)
+        ht.reset()
+        d_seeds = dev(seeds)
+        ht.fill_unique(d_seeds)
+        cap = batch
+        cur, d_cur_n = d_seeds, None
+        got = {}
+        for li in range(len(fanouts) - 1, -1, -1):
+            col, dst, d_ne = hip.sample_khop(kind, d_indptr, d_indices, cur, fanouts[li], SEED, b, li, hip.SRC_LOCAL,
+                                             d_num_input=d_cur_n)
+            row = ht.fill_duplicates(dst, d_num_items=d_ne)
+            got[li] = (row, col, d_ne)
+            cap = cap * (1 + fanouts[li])
+            # next layer's input = the table's N2O list; its length lives on the device
+            n2o_ptr = hip.load().fgnn_hashtable_n2o(ht.h)
+            cur = hip._wrap_device_u32(n2o_ptr, min(cap, max_items), ht.device)
+            d_cur_n = hip._wrap_device_u32(ht.d_num_items_ptr(), 1, ht.device)
+        torch.cuda.synchronize()
+        for li in range(len(fanouts)):
+            row, col, d_ne = got[li]
+            ne = int(d_ne.cpu()[0])
+            assert ne == want["graphs"][li]["num_edge"]
+            np.testing.assert_array_equal(host_u32(row, ne), want["graphs"][li]["row"])
+            np.testing.assert_array_equal(host_u32(col, ne), want["graphs"][li]["col"])
+        np.testing.assert_array_equal(host_u32(ht.unique()), want["input_nodes"])
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
