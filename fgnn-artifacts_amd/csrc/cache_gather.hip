@@ -184,7 +184,7 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
   if (launch_scan_block_sums(sums, nb, nullptr, total, nullptr, nullptr, s) != FGNN_OK) return FGNN_EHIP;
   hipLaunchKernelGGL(cache_split_kernel, dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes, d_num_nodes, cap, slot, sums,
                      total, miss_src, miss_dst, cache_src, cache_dst, d_counts);
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }
 
 extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
@@ -221,5 +221,5 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
     }
 #undef FGNN_ELEM
   }
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }

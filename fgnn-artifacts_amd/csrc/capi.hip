@@ -1,6 +1,17 @@
 // capi.hip -- small entry points of libfgnn_hip.so that are not tied to one kernel file.
 #include "fgnn_device.h"
 
+#include <cstdio>
+
+namespace fgnn {
+static thread_local char g_last_error[512] = "";
+void set_last_error(const char *what, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+}
+}  // namespace fgnn
+
+extern "C" const char *fgnn_last_error(void) { return fgnn::g_last_error; }
+
 extern "C" const char *fgnn_version(void) { return "fgnn-hip 0.1 (gfx950)"; }
 
 extern "C" int fgnn_device_count(void) {

@@ -14,11 +14,27 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kItemsPerThread = 8;   // edge-parallel kernels: 2048 items per workgroup
 constexpr int kTile = kBlock * kItemsPerThread;
 
+// records "<what>: <hip error string>" for fgnn_last_error(); defined in capi.hip
+void set_last_error(const char *what, hipError_t e);
+
 #define FGNN_HIP_CHECK(expr)                      \
   do {                                            \
     hipError_t _e = (expr);                       \
-    if (_e != hipSuccess) return FGNN_EHIP;       \
+    if (_e != hipSuccess) {                       \
+      ::fgnn::set_last_error(#expr, _e);          \
+      return FGNN_EHIP;                           \
+    }                                             \
   } while (0)
+
+// after a batch of hipLaunchKernelGGL calls
+inline int launch_status(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error(what, e);
+    return FGNN_EHIP;
+  }
+  return FGNN_OK;
+}
 
 // ---- Philox4x32-10, addressed exactly like oracle/fgnn_oracle.c:fgnn_philox_draw ------------
 struct u32x4 { uint32_t x, y, z, w; };

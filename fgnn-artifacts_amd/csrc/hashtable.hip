@@ -267,7 +267,7 @@ extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *it
   hipLaunchKernelGGL(ht_fill_unique_kernel, dim3(div_up(num_items, kBlock)), dim3(kBlock), 0, s, ht->table, ht->shift,
                      mask, items, num_items, ht->n2o, ht->d_num_items, ht->max_items);
   hipLaunchKernelGGL(ht_advance_kernel, dim3(1), dim3(1), 0, s, ht->d_num_items, (uint32_t)num_items);
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }
 
 extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
@@ -297,7 +297,7 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
   if (mapped)
     hipLaunchKernelGGL(ht_map_pos_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos,
                        mapped);
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }
 
 extern "C" int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
@@ -309,5 +309,5 @@ extern "C" int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *item
   const uint32_t mask = (uint32_t)(ht->capacity - 1);
   hipLaunchKernelGGL(ht_map_probe_kernel, dim3(div_up(cap, kTile)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                      ht->table, ht->shift, mask, items, num_items, d_num_items, cap, mapped);
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }

@@ -219,7 +219,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     static bool attr_done_##SS = false;                                                                        \
     if (!attr_done_##SS) {                                                                                     \
       FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, KHOP2>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
       attr_done_##SS = true;                                                                                   \
     }                                                                                                          \
     hipLaunchKernelGGL((khop_sample_kernel<SS, KHOP2>), dim3(nb), dim3(SS), lds, stream, indptr, indices,      \
@@ -231,7 +231,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   else if (S == 128) FGNN_LAUNCH_KHOP(128);
   else FGNN_LAUNCH_KHOP(64);
 #undef FGNN_LAUNCH_KHOP
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }
 
 }  // namespace

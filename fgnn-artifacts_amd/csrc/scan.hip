@@ -31,7 +31,7 @@ int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *
                            uint32_t *accum_out, hipStream_t stream) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream, sums, n, total64, total32, accum,
                      accum_out);
-  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+  return launch_status(__func__);
 }
 
 }  // namespace fgnn

@@ -20,7 +20,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
          torch.int8: I8, torch.int64: I64}
 
 EXPORTS = [
-    "fgnn_version", "fgnn_device_count", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_get_miss_cache_index", "fgnn_gather_rows",
@@ -42,6 +42,7 @@ def load():
                             "(there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
         L.fgnn_version.restype = C.c_char_p
+        L.fgnn_last_error.restype = C.c_char_p
         L.fgnn_scratch_bytes.restype = C.c_size_t
         L.fgnn_scratch_bytes.argtypes = [C.c_size_t]
         L.fgnn_hashtable_create.restype = C.c_void_p
@@ -59,7 +60,8 @@ def load():
 
 def _check(code, what):
     if code != 0:
-        raise FgnnError(f"{what} failed with code {code}")
+        detail = load().fgnn_last_error().decode() if code == -3 else ""
+        raise FgnnError(f"{what} failed with code {code} {detail}")
 
 
 def _ptr(t):

@@ -43,6 +43,8 @@ enum { FGNN_SRC_GLOBAL = 0, /* seed's global id, as the reference emits (khop2.c
                                the engine skip the src half of GPUMapEdges (cuda_mapping.cu:56-66) */ };
 
 const char *fgnn_version(void);
+/* text of the last HIP runtime failure on this thread (FGNN_EHIP) */
+const char *fgnn_last_error(void);
 int fgnn_device_count(void);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
