@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- sampled-edges/sec of the sampling-and-extraction hot path on MI355X.
+
+One "step" = one mini-batch through the whole path on one GPU, inputs resident in HBM:
+    batch slice of the shuffled train set -> k-hop sampling (khop2) -> dedup/compaction -> remap
+    -> cache-index split -> feature gather + label gather -> batch summary to pinned host memory.
+Workload at N=1 (default): papers100M-shaped synthetic graph (BASELINE.json metric: GraphSAGE fanout
+[25,10], batch 8000, N=111 059 956, E=1 615 685 872, D=128 f32), full feature table resident in HBM.
+For N>1 every rank holds a full replica and samples its own DistShuffler step range
+(dist/dist_shuffler.cc:59-79); there is no collective on the data path (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+
+from fgnn_hip import lib, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: shape + run config (reference defaults: batch 8000, common_config.py:63; fanout train_graphsage.py:77)
+    "papers100M": dict(**synth.DATASET_SHAPES["papers100M"], fanout=[25, 10], batch_size=8000),
+    "products": dict(**synth.DATASET_SHAPES["products"], fanout=[25, 10], batch_size=8000),
+    "small": dict(num_node=1_000_000, num_edge=20_000_000, feat_dim=128, num_class=47, num_train=100_000,
+                  fanout=[25, 10], batch_size=8000),
+}
+
+
+def gen_graph_on_gpu(num_node, num_edge, seed, device):
+    """Same construction as synth.powerlaw_csr (power-law row lengths, hub-skewed neighbour ids), done with
+    torch on the GPU in chunks so that a 1.6 G-edge CSR is built in seconds without host memory."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.rand(num_node, generator=g, device=device, dtype=torch.float64)
+    raw = (1.0 - u).pow(-1.0 / 1.8) - 1.0 + 0.05
+    raw[torch.rand(num_node, generator=g, device=device) < 0.02] = 0.0
+    deg = torch.floor(raw * (num_edge / raw.sum())).to(torch.int64)
+    # heavy tail: cap a single row at 2^24 entries and spread the remainder uniformly
+    deg.clamp_(max=1 << 24)
+    short = int(num_edge - int(deg.sum()))
+    if short > 0:
+        bump = torch.randint(0, num_node, (short,), generator=g, device=device)
+        deg.index_add_(0, bump, torch.ones_like(bump))
+    elif short < 0:
+        big = torch.nonzero(deg > 0).flatten()
+        take = big[torch.randperm(big.numel(), generator=g, device=device)[:(-short)]]
+        deg[take] -= 1
+    indptr64 = torch.zeros(num_node + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=indptr64[1:])
+    total = int(indptr64[-1])
+    assert total < 2**32
+    indptr = (indptr64 & 0xFFFFFFFF).to(torch.int32) if total >= 2**31 else indptr64.to(torch.int32)
+    mul = 2654435761 % num_node
+    while np.gcd(mul, num_node) != 1:
+        mul += 1
+    indices = torch.empty(total, dtype=torch.int32, device=device)
+    chunk = 1 << 26
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        x = torch.rand(b - a, generator=g, device=device, dtype=torch.float64)
+        ids = torch.clamp((num_node * x * x).to(torch.int64), max=num_node - 1)
+        ids = (ids * mul) % num_node
+        indices[a:b] = ids.to(torch.int32)
+        del x, ids
+    del deg, indptr64, raw, u
+    return indptr, indices, total
+
+
+def gen_features_on_gpu(num_node, dim, device):
+    feat = torch.empty((num_node, dim), dtype=torch.float32, device=device)
+    rows = max(1, (1 << 28) // dim)
+    col = torch.arange(dim, device=device, dtype=torch.int32)[None, :] * 7
+    for a in range(0, num_node, rows):
+        b = min(num_node, a + rows)
+        r = torch.arange(a, b, device=device, dtype=torch.int32)[:, None] * 131
+        feat[a:b] = ((r + col) & 0xFFFF).to(torch.float32) * (1.0 / 65536.0)
+    return feat
+
+
+def algorithmic_bytes(metas, feat_dim, batch_size):
+    """per batch, 4-byte ids.  Returns dict of per-stage algorithmic bytes (sums)."""
+    sample = dedup = split = gather = 0
+    for m in metas:
+        L = m.num_layers
+        for l in range(L):
+            S, E = m.num_dst[l], m.num_edge[l]
+            n_new = m.num_src[l] - m.num_dst[l]
+            sample += S * 12 + E * 12
+            dedup += E * 16 + n_new * 4
+        U = m.num_input
+        split += U * 16
+        gather += U * (4 + 8 * feat_dim) + m.num_output * 20
+    return dict(sample=sample, dedup_remap=dedup, cache_split=split, gather=gather)
+
+
+def cpu_baseline(w, indptr, indices, feat, train, steps_budget_s=20.0):
+    """The reference's CPU sampling path restated in oracle/ (CPUSampleKHop2 + CPUHashTable2 + CPUExtract,
+    cpu/cpu_loops.cc:55-227), timed on this host on a bounded number of batches of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as oracle
+    oracle.build()
+    t0 = time.time()
+    h_indptr = indptr.cpu().numpy().view(np.uint32)
+    h_indices = indices.cpu().numpy().view(np.uint32).copy()
+    mock_bits = min(24, int(np.floor(np.log2(feat.shape[0]))))
+    h_feat = feat[:1 << mock_bits].cpu().numpy()
+    copy_s = time.time() - t0
+    num_node = h_indptr.shape[0] - 1
+    fan, bs = w["fanout"], w["batch_size"]
+    ht = oracle.HashTable(num_node, oracle.predict_num_nodes(bs, fan))
+    rng = oracle.make_rng(oracle.RNG_MT_CPU_TWIN)
+    h_train = train.cpu().numpy().view(np.uint32)
+    edges = rows = 0
+    t_sample = t_extract = 0.0
+    nb = 0
+    mask = np.uint32((1 << mock_bits) - 1)
+    while t_sample + t_extract < steps_budget_s and (nb + 1) * bs <= len(h_train):
+        seeds = h_train[nb * bs:(nb + 1) * bs]
+        t1 = time.time()
+        task = oracle.do_sample(h_indptr, h_indices, seeds, fan, oracle.KHOP2, rng, nb, ht)
+        t2 = time.time()
+        oracle.extract(h_feat, task["input_nodes"] & mask)
+        t3 = time.time()
+        t_sample += t2 - t1
+        t_extract += t3 - t2
+        edges += task["total_edges"]
+        rows += len(task["input_nodes"])
+        nb += 1
+    return {
+        "value": edges / (t_sample + t_extract), "unit": "sampled-edges/s", "cores": 1, "kind": "port",
+        "sample": f"{nb} batches of {bs} seeds, fanout {fan}, same graph; sample+dedup+remap {t_sample:.2f}s, "
+                  f"extract {t_extract:.2f}s (feature table masked to 2^{mock_bits} rows like SAMGRAPH_EMPTY_FEAT); "
+                  f"host copy of CSR/features {copy_s:.1f}s not counted; single-thread oracle "
+                  f"(CPUSampleKHop2 + CPUHashTable2 + CPUExtract restatement, mt19937 twin mode)",
+        "sample_only_edges_per_s": edges / t_sample, "extract_rows_per_s": rows / max(t_extract, 1e-9),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=151)   # one papers100M epoch at batch 8000
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
+    ap.add_argument("--cache-ratio", type=float, default=0.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    lib.load()
+
+    w = WORKLOADS[args.workload]
+    t_setup = time.time()
+    indptr, indices, num_edge = gen_graph_on_gpu(w["num_node"], w["num_edge"], 42, dev)
+    feat = gen_features_on_gpu(w["num_node"], w["feat_dim"], dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    label = torch.randint(0, w["num_class"], (w["num_node"],), generator=g, device=dev, dtype=torch.int64)
+    train = torch.randperm(w["num_node"], generator=g, device=dev)[:w["num_train"]].to(torch.int32)
+    # cache table: top cache_ratio*N nodes by in-degree (stand-in rank list; the split kernel does not care)
+    deg = (indptr[1:].to(torch.int64) - indptr[:-1].to(torch.int64)) & 0xFFFFFFFF
+    n_cached = int(w["num_node"] * args.cache_ratio)
+    table = torch.full((w["num_node"],), -1, dtype=torch.int32, device=dev)
+    if n_cached:
+        top = torch.argsort(deg, descending=True)[:n_cached]
+        table[top] = torch.arange(n_cached, device=dev, dtype=torch.int32)
+        del top
+    del deg
+    # one epoch's shuffle (identical on every rank, like DistShuffler's seed = epoch); each rank takes a step range
+    g.manual_seed(0)
+    train = train[torch.randperm(train.numel(), generator=g, device=dev)]
+    bs = w["batch_size"]
+    steps_per_epoch = (train.numel() + bs - 1) // bs
+    local_first = (steps_per_epoch // world) * rank
+
+    sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
+    batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(2)]
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    ev_pairs = []
+
+    def run_step(i, timed):
+        step = (local_first + i) % steps_per_epoch
+        seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
+        bt = batches[i % 2]
+        if i >= 2:
+            bt.wait()  # the buffers of step i-2 are about to be reused; its summary was already collected
+        sampler.sample(seeds, step, bt)
+        bt.cache_index(table)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bt.extract(feat, None)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        else:
+            bt.extract(feat, None)
+        bt.extract(None, label)
+        bt.finish()
+        return bt
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        run_step(i, False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    metas = []
+    t0 = time.perf_counter()
+    pending = []
+    for i in range(args.warmup, args.warmup + args.steps):
+        bt = run_step(i, True)
+        pending.append(bt)
+        if len(pending) == 2:  # collect the summary of step i-1 while step i runs
+            metas.append(pending.pop(0).wait())
+    for bt in pending:
+        metas.append(bt.wait())
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # metas hold ctypes structs that alias nothing (copied by value in wait())
+    edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+    rows = sum(int(m.num_input) for m in metas)
+    overflow = any(m.overflow for m in metas)
+    gather_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    ab = algorithmic_bytes(metas, w["feat_dim"], bs)
+    # dominant kernel = feature gather: U*(4 + 8*D) bytes per launch (index read + row read + row write)
+    gather_feat_bytes = sum(int(m.num_input) * (4 + 8 * w["feat_dim"]) for m in metas)
+    gather_avg_ms = float(np.mean(gather_ms))
+    achieved = gather_feat_bytes / len(metas) / (gather_avg_ms * 1e-3) / 1e9
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        e = torch.tensor([edges, rows], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.SUM)
+        elapsed, edges, rows = float(t[0]), float(e[0]), float(e[1])
+
+    if rank == 0:
+        out = {
+            "metric": "sampled-edges/sec (GraphSAGE fanout 25/10, batch 8000, full hot path: sample + dedup + remap + "
+                      "cache-index split + feature/label gather)",
+            "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped synthetic power-law CSR, N={w['num_node']}, "
+                                   f"E={num_edge}, feat f32[N,{w['feat_dim']}] resident in HBM, khop2 fanout "
+                                   f"{w['fanout']}, batch {bs}, cache table ratio {args.cache_ratio}, "
+                                   f"1 process per GPU, full replica per GPU, disjoint step ranges",
+                       "global_batch": bs * world, "parallelism": f"dp{world} (independent samplers)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
+                         "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas)},
+            "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps / world,
+            "input_nodes_per_step": rows / args.steps / world,
+            "algorithmic_bytes_per_step": {k: v / len(metas) for k, v in ab.items()},
+            "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
+            if world == 1 else None,
+            "overflow": bool(overflow), "setup_s": t_setup,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,328 @@
+// engine.hip -- per-batch driver: the MI355X restatement of DoGPUSample
+// (reference samgraph/common/cuda/cuda_loops.cc:50-267), DoGetCacheMissIndex
+// (dist/dist_loops.cc:271-323) and DoGPUFeatureExtract (cuda_loops.cc:726-770).
+//
+// Everything a batch needs is enqueued on one stream with device-resident sizes; the host gets one
+// pinned fgnn_batch_meta per batch.  Bit-identical to oracle fgnn_oracle_do_sample.
+#include <cstring>
+#include <new>
+
+#include "fgnn_device.h"
+
+struct fgnn_sampler {
+  fgnn_sampler_config cfg;
+  fgnn_hashtable *ht;
+  size_t max_nodes;                       // PredictNumNodes(batch, fanout, L)
+  size_t in_cap[FGNN_MAX_LAYERS];         // worst-case #seeds of layer l
+  size_t edge_cap[FGNN_MAX_LAYERS];       // worst-case #edges of layer l
+  size_t max_edge_cap;
+  uint32_t *tmp_dst;                      // [max_edge_cap] sampled neighbours (global ids)
+  void *ws;                               // kernel scratch
+  size_t ws_bytes;
+};
+
+struct fgnn_batch {
+  const fgnn_sampler *owner;
+  uint32_t *row[FGNN_MAX_LAYERS], *col[FGNN_MAX_LAYERS], *data[FGNN_MAX_LAYERS];
+  uint32_t *input_nodes, *output_nodes;
+  uint32_t *cidx[4];                      // miss_src, miss_dst, cache_src, cache_dst
+  void *feat, *label;
+  size_t feat_dim, feat_rows_cap;
+  int feat_dtype, label_dtype;
+  size_t num_output;                      // host copy of the batch size
+  fgnn_batch_meta *d_meta, *h_meta;
+  void *ws;                               // scratch for the cache split
+  size_t ws_bytes;
+  hipEvent_t done;
+};
+
+namespace fgnn {
+namespace {
+
+size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case FGNN_I8: case FGNN_U8: return 1;
+    case FGNN_F16: return 2;
+    case FGNN_F32: case FGNN_I32: return 4;
+    case FGNN_F64: case FGNN_I64: return 8;
+    default: return 0;
+  }
+}
+
+__global__ void meta_begin_kernel(fgnn_batch_meta *m, uint64_t key, uint32_t num_layers, uint32_t num_output) {
+  m->key = key;
+  m->num_layers = num_layers;
+  m->num_output = num_output;
+  m->num_input = 0;
+  m->num_miss = 0;
+  m->num_cache = 0;
+  m->overflow = 0;
+}
+
+// after layer l: num_dst = #items before the fill (kept in d_num_items[1]), num_src = #items now
+__global__ void meta_layer_kernel(fgnn_batch_meta *m, int layer, const uint32_t *d_num_items, size_t edge_cap,
+                                  size_t node_cap) {
+  m->num_dst[layer] = d_num_items[1];
+  m->num_src[layer] = d_num_items[0];
+  m->num_input = d_num_items[0];
+  if (m->num_edge[layer] > edge_cap || d_num_items[0] > node_cap) m->overflow = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void copy_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
+                                                          const uint32_t *d_n, size_t cap) {
+  const size_t n = resolve_count(0, d_n, cap);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+__global__ void meta_counts_kernel(fgnn_batch_meta *m, const uint32_t *d_counts) {
+  m->num_miss = d_counts[0];
+  m->num_cache = d_counts[1];
+}
+
+}  // namespace
+}  // namespace fgnn
+
+using namespace fgnn;
+
+extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err) {
+  auto fail = [&](int code) -> fgnn_sampler * {
+    if (h_err) *h_err = code;
+    return nullptr;
+  };
+  if (!cfg || !cfg->indptr || !cfg->indices || cfg->num_layers == 0 || cfg->num_layers > FGNN_MAX_LAYERS ||
+      cfg->max_batch_size == 0)
+    return fail(FGNN_EINVAL);
+  if (cfg->sample_type != FGNN_KHOP0 && cfg->sample_type != FGNN_KHOP2) return fail(FGNN_EINVAL);
+  auto *s = new (std::nothrow) fgnn_sampler();
+  if (!s) return fail(FGNN_EHIP);
+  s->cfg = *cfg;
+  s->ht = nullptr;
+  s->tmp_dst = nullptr;
+  s->ws = nullptr;
+  // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
+  size_t count = cfg->max_batch_size;
+  s->max_edge_cap = 0;
+  for (long l = (long)cfg->num_layers - 1; l >= 0; --l) {
+    if (cfg->fanout[l] == 0) { delete s; return fail(FGNN_EINVAL); }
+    s->in_cap[l] = count;
+    s->edge_cap[l] = count * cfg->fanout[l];
+    if (s->edge_cap[l] > s->max_edge_cap) s->max_edge_cap = s->edge_cap[l];
+    count += s->edge_cap[l];
+  }
+  s->max_nodes = count;
+  if (s->max_edge_cap >= 0x7fffffffull || s->max_nodes >= 0x7fffffffull) { delete s; return fail(FGNN_EINVAL); }
+  int err = FGNN_OK;
+  s->ht = fgnn_hashtable_create(s->max_nodes, &err);
+  if (!s->ht) { delete s; return fail(err); }
+  s->ws_bytes = fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes);
+  if (hipMalloc(&s->tmp_dst, s->max_edge_cap * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) {
+    fgnn_sampler_destroy(s);
+    return fail(FGNN_EHIP);
+  }
+  if (h_err) *h_err = FGNN_OK;
+  return s;
+}
+
+extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
+  if (!s) return;
+  if (s->ht) fgnn_hashtable_destroy(s->ht);
+  if (s->tmp_dst) (void)hipFree(s->tmp_dst);
+  if (s->ws) (void)hipFree(s->ws);
+  delete s;
+}
+
+extern "C" size_t fgnn_sampler_max_nodes(const fgnn_sampler *s) { return s ? s->max_nodes : 0; }
+extern "C" size_t fgnn_sampler_max_edges(const fgnn_sampler *s, int layer) {
+  return (s && layer >= 0 && (size_t)layer < s->cfg.num_layers) ? s->edge_cap[layer] : 0;
+}
+
+extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
+  if (!b) return;
+  for (int l = 0; l < FGNN_MAX_LAYERS; ++l) {
+    if (b->row[l]) (void)hipFree(b->row[l]);
+    if (b->col[l]) (void)hipFree(b->col[l]);
+    if (b->data[l]) (void)hipFree(b->data[l]);
+  }
+  for (int k = 0; k < 4; ++k)
+    if (b->cidx[k]) (void)hipFree(b->cidx[k]);
+  if (b->input_nodes) (void)hipFree(b->input_nodes);
+  if (b->output_nodes) (void)hipFree(b->output_nodes);
+  if (b->feat) (void)hipFree(b->feat);
+  if (b->label) (void)hipFree(b->label);
+  if (b->d_meta) (void)hipFree(b->d_meta);
+  if (b->h_meta) (void)hipHostFree(b->h_meta);
+  if (b->ws) (void)hipFree(b->ws);
+  if (b->done) (void)hipEventDestroy(b->done);
+  delete b;
+}
+
+extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim, int feat_dtype, int label_dtype,
+                                         size_t feat_rows_cap, int *h_err) {
+  auto fail = [&](int code, fgnn_batch *b) -> fgnn_batch * {
+    if (b) fgnn_batch_destroy(b);
+    if (h_err) *h_err = code;
+    return nullptr;
+  };
+  if (!s) return fail(FGNN_EINVAL, nullptr);
+  if (feat_dim && (dtype_size(feat_dtype) == 0 || dtype_size(label_dtype) == 0)) return fail(FGNN_EINVAL, nullptr);
+  auto *b = new (std::nothrow) fgnn_batch();
+  if (!b) return fail(FGNN_EHIP, nullptr);
+  std::memset(static_cast<void *>(b), 0, sizeof(*b));
+  b->owner = s;
+  b->feat_dim = feat_dim;
+  b->feat_dtype = feat_dtype;
+  b->label_dtype = label_dtype;
+  b->feat_rows_cap = feat_rows_cap ? feat_rows_cap : s->max_nodes;
+  if (b->feat_rows_cap > s->max_nodes) b->feat_rows_cap = s->max_nodes;
+  bool ok = true;
+  for (size_t l = 0; l < s->cfg.num_layers && ok; ++l) {
+    ok = ok && hipMalloc(&b->row[l], s->edge_cap[l] * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&b->col[l], s->edge_cap[l] * sizeof(uint32_t)) == hipSuccess;
+  }
+  ok = ok && hipMalloc(&b->input_nodes, s->max_nodes * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&b->output_nodes, s->cfg.max_batch_size * sizeof(uint32_t)) == hipSuccess;
+  for (int k = 0; k < 4 && ok; ++k) ok = hipMalloc(&b->cidx[k], s->max_nodes * sizeof(uint32_t)) == hipSuccess;
+  if (feat_dim) {
+    ok = ok && hipMalloc(&b->feat, b->feat_rows_cap * feat_dim * dtype_size(feat_dtype)) == hipSuccess;
+    ok = ok && hipMalloc(&b->label, s->cfg.max_batch_size * dtype_size(label_dtype)) == hipSuccess;
+  }
+  ok = ok && hipMalloc(&b->d_meta, sizeof(fgnn_batch_meta)) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b->h_meta), sizeof(fgnn_batch_meta), hipHostMallocDefault) ==
+                 hipSuccess;
+  b->ws_bytes = fgnn_scratch_bytes(s->max_nodes);
+  ok = ok && hipMalloc(&b->ws, b->ws_bytes) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&b->done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) return fail(FGNN_EHIP, b);
+  if (hipMemset(b->d_meta, 0, sizeof(fgnn_batch_meta)) != hipSuccess) return fail(FGNN_EHIP, b);
+  std::memset(b->h_meta, 0, sizeof(fgnn_batch_meta));
+  if (h_err) *h_err = FGNN_OK;
+  return b;
+}
+
+extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                                   fgnn_batch *out, void *stream) {
+  if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
+    return FGNN_EINVAL;
+  auto st = static_cast<hipStream_t>(stream);
+  const size_t L = s->cfg.num_layers;
+  out->num_output = num_seeds;
+  FGNN_HIP_CHECK(hipMemsetAsync(out->d_meta, 0, sizeof(fgnn_batch_meta), st));
+  hipLaunchKernelGGL(meta_begin_kernel, dim3(1), dim3(1), 0, st, out->d_meta, batch_key, (uint32_t)L,
+                     (uint32_t)num_seeds);
+  int rc = fgnn_hashtable_reset(s->ht, stream);
+  if (rc != FGNN_OK) return rc;
+  if (num_seeds == 0) return launch_status(__func__);
+  FGNN_HIP_CHECK(hipMemcpyAsync(out->output_nodes, d_seeds, num_seeds * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  rc = fgnn_hashtable_fill_unique(s->ht, d_seeds, num_seeds, stream);
+  if (rc != FGNN_OK) return rc;
+
+  const uint32_t *cur = d_seeds;
+  const uint32_t *d_cur_n = nullptr;  // first layer: host count
+  size_t cur_n_host = num_seeds;
+  // tighter caps than the create-time worst case when this batch is smaller than max_batch_size
+  size_t in_cap = num_seeds;
+  for (long l = (long)L - 1; l >= 0; --l) {
+    const size_t fan = s->cfg.fanout[l];
+    const size_t ecap = in_cap * fan;
+    size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
+    if (s->cfg.sample_type == FGNN_KHOP2)
+      rc = fgnn_sample_khop2(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
+                             s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
+                             stream);
+    else
+      rc = fgnn_sample_khop0(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
+                             s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
+                             stream);
+    if (rc != FGNN_OK) return rc;
+    rc = fgnn_hashtable_fill_duplicates(s->ht, s->tmp_dst, 0, d_ne, ecap, out->row[l], s->ws, s->ws_bytes, stream);
+    if (rc != FGNN_OK) return rc;
+    in_cap += ecap;
+    hipLaunchKernelGGL(meta_layer_kernel, dim3(1), dim3(1), 0, st, out->d_meta, (int)l,
+                       fgnn_hashtable_d_num_items(s->ht), ecap, in_cap);
+    cur = fgnn_hashtable_n2o(s->ht);
+    d_cur_n = fgnn_hashtable_d_num_items(s->ht);
+    cur_n_host = 0;
+  }
+  // input_nodes = unique (cuda_loops.cc:258)
+  size_t blocks = div_up(in_cap, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_u32_kernel, dim3(blocks), dim3(kBlock), 0, st, out->input_nodes, fgnn_hashtable_n2o(s->ht),
+                     fgnn_hashtable_d_num_items(s->ht), in_cap);
+  return launch_status(__func__);
+}
+
+extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
+  if (!b || !cache_table) return FGNN_EINVAL;
+  auto st = static_cast<hipStream_t>(stream);
+  // d_counts lives at the tail of the scratch block
+  uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(b->ws) + b->ws_bytes) - 2;
+  int rc = fgnn_get_miss_cache_index(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
+                                     b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], d_counts, b->ws,
+                                     b->ws_bytes - 2 * sizeof(uint32_t), stream);
+  if (rc != FGNN_OK) return rc;
+  hipLaunchKernelGGL(meta_counts_kernel, dim3(1), dim3(1), 0, st, b->d_meta, d_counts);
+  return launch_status(__func__);
+}
+
+extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream) {
+  if (!b || !b->feat_dim) return FGNN_EINVAL;
+  int rc = FGNN_OK;
+  if (feat)
+    rc = fgnn_gather_rows(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
+                          b->feat_dim, b->feat_dtype, stream);
+  if (rc == FGNN_OK && label && b->num_output)
+    rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
+                          b->label_dtype, stream);
+  return rc;
+}
+
+extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void *full_feat,
+                                         const void *label, void *stream) {
+  if (!b || !b->feat_dim) return FGNN_EINVAL;
+  int rc = FGNN_OK;
+  if (full_feat)  // CombineMissData with the row fetch fused in
+    rc = fgnn_gather_rows(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss, b->feat_rows_cap,
+                          b->feat_dim, b->feat_dtype, stream);
+  if (rc == FGNN_OK && cache_rows)  // CombineCacheData
+    rc = fgnn_gather_rows(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,
+                          b->feat_dim, b->feat_dtype, stream);
+  if (rc == FGNN_OK && label && b->num_output)
+    rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
+                          b->label_dtype, stream);
+  return rc;
+}
+
+extern "C" int fgnn_batch_finish(fgnn_batch *b, void *stream) {
+  if (!b) return FGNN_EINVAL;
+  auto st = static_cast<hipStream_t>(stream);
+  FGNN_HIP_CHECK(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(fgnn_batch_meta), hipMemcpyDeviceToHost, st));
+  FGNN_HIP_CHECK(hipEventRecord(b->done, st));
+  return FGNN_OK;
+}
+
+extern "C" int fgnn_batch_wait(fgnn_batch *b, fgnn_batch_meta *h_meta) {
+  if (!b) return FGNN_EINVAL;
+  FGNN_HIP_CHECK(hipEventSynchronize(b->done));
+  if (h_meta) *h_meta = *b->h_meta;
+  return FGNN_OK;
+}
+
+extern "C" const uint32_t *fgnn_batch_row(const fgnn_batch *b, int l) {
+  return (b && l >= 0 && l < FGNN_MAX_LAYERS) ? b->row[l] : nullptr;
+}
+extern "C" const uint32_t *fgnn_batch_col(const fgnn_batch *b, int l) {
+  return (b && l >= 0 && l < FGNN_MAX_LAYERS) ? b->col[l] : nullptr;
+}
+extern "C" const uint32_t *fgnn_batch_data(const fgnn_batch *b, int l) {
+  return (b && l >= 0 && l < FGNN_MAX_LAYERS) ? b->data[l] : nullptr;
+}
+extern "C" const uint32_t *fgnn_batch_input_nodes(const fgnn_batch *b) { return b ? b->input_nodes : nullptr; }
+extern "C" const uint32_t *fgnn_batch_output_nodes(const fgnn_batch *b) { return b ? b->output_nodes : nullptr; }
+extern "C" const void *fgnn_batch_feat(const fgnn_batch *b) { return b ? b->feat : nullptr; }
+extern "C" const void *fgnn_batch_label(const fgnn_batch *b) { return b ? b->label : nullptr; }
+extern "C" const uint32_t *fgnn_batch_cache_index_ptr(const fgnn_batch *b, int which) {
+  return (b && which >= 0 && which < 4) ? b->cidx[which] : nullptr;
+}
+extern "C" const fgnn_batch_meta *fgnn_batch_device_meta(const fgnn_batch *b) { return b ? b->d_meta : nullptr; }

@@ -213,3 +213,169 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
                                    C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]), _stream()),
            "fgnn_gather_rows")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch driver (fgnn_sampler / fgnn_batch)
+
+MAX_LAYERS = 8
+KHOP0, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2 = 0, 3, 4, 5
+
+EXPORTS += [
+    "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
+    "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_batch_cache_index", "fgnn_batch_extract",
+    "fgnn_batch_extract_cached", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
+    "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
+    "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta",
+]
+
+
+class SamplerConfig(C.Structure):
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("prob_prefix", C.c_void_p),
+                ("num_node", C.c_size_t), ("sample_type", C.c_int), ("num_layers", C.c_size_t),
+                ("fanout", C.c_size_t * MAX_LAYERS), ("max_batch_size", C.c_size_t), ("seed", C.c_uint64),
+                ("walk_len", C.c_size_t), ("num_walks", C.c_size_t), ("restart_prob", C.c_double)]
+
+
+class BatchMeta(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("num_edge", C.c_uint64 * MAX_LAYERS), ("num_src", C.c_uint32 * MAX_LAYERS),
+                ("num_dst", C.c_uint32 * MAX_LAYERS), ("num_layers", C.c_uint32), ("num_input", C.c_uint32),
+                ("num_output", C.c_uint32), ("num_miss", C.c_uint32), ("num_cache", C.c_uint32),
+                ("overflow", C.c_uint32)]
+
+
+_TORCH_OF = {F32: torch.float32, F64: torch.float64, F16: torch.float16, U8: torch.uint8, I32: torch.int32,
+             I8: torch.int8, I64: torch.int64}
+_TYPESTR = {F32: "<f4", F64: "<f8", F16: "<f2", U8: "|u1", I32: "<i4", I8: "|i1", I64: "<i8"}
+
+
+def _wrap_device(ptr, shape, dtype_code, device):
+    n = 1
+    for s in shape:
+        n *= s
+    if n == 0:
+        return torch.empty(shape, dtype=_TORCH_OF[dtype_code], device=device)
+
+    class _A:
+        __cuda_array_interface__ = {"shape": tuple(shape), "typestr": _TYPESTR[dtype_code], "data": (ptr, False),
+                                    "version": 2}
+    return torch.as_tensor(_A(), device=device)
+
+
+class Sampler:
+    """DoGPUSample / DoGetCacheMissIndex / DoGPUFeatureExtract on one GPU, no host round trips."""
+
+    def __init__(self, indptr, indices, fanout, max_batch_size, sample_type=KHOP2, seed=0x5A4D47, prob_prefix=None,
+                 walk_len=0, num_walks=0, restart_prob=0.0):
+        L = load()
+        _need_gpu(indptr, indices)
+        L.fgnn_sampler_create.restype = C.c_void_p
+        L.fgnn_sampler_max_nodes.restype = C.c_size_t
+        L.fgnn_sampler_max_edges.restype = C.c_size_t
+        L.fgnn_batch_create.restype = C.c_void_p
+        for name in ("fgnn_batch_row", "fgnn_batch_col", "fgnn_batch_data", "fgnn_batch_input_nodes",
+                     "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label", "fgnn_batch_cache_index_ptr",
+                     "fgnn_batch_device_meta"):
+            getattr(L, name).restype = C.c_void_p
+        self.device = indptr.device
+        torch.cuda.set_device(self.device)
+        self._keep = (indptr, indices, prob_prefix)
+        cfg = SamplerConfig()
+        cfg.indptr, cfg.indices = indptr.data_ptr(), indices.data_ptr()
+        cfg.prob_prefix = prob_prefix.data_ptr() if prob_prefix is not None else 0
+        cfg.num_node = indptr.numel() - 1
+        cfg.sample_type = sample_type
+        cfg.num_layers = len(fanout)
+        for i, f in enumerate(fanout):
+            cfg.fanout[i] = f
+        cfg.max_batch_size, cfg.seed = max_batch_size, seed
+        cfg.walk_len, cfg.num_walks, cfg.restart_prob = walk_len, num_walks, restart_prob
+        err = C.c_int(0)
+        self.h = C.c_void_p(L.fgnn_sampler_create(C.byref(cfg), C.byref(err)))
+        if not self.h:
+            raise FgnnError(f"fgnn_sampler_create failed with code {err.value} {L.fgnn_last_error().decode()}")
+        self.fanout = list(fanout)
+        self.max_batch_size = max_batch_size
+        self.max_nodes = L.fgnn_sampler_max_nodes(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.fgnn_sampler_destroy(self.h)
+            self.h = None
+
+    def max_edges(self, layer):
+        return load().fgnn_sampler_max_edges(self.h, C.c_int(layer))
+
+    def new_batch(self, feat_dim=0, feat_dtype=F32, label_dtype=I64, feat_rows_cap=0):
+        return Batch(self, feat_dim, feat_dtype, label_dtype, feat_rows_cap)
+
+    def sample(self, seeds, batch_key, batch):
+        _need_gpu(seeds)
+        _check(load().fgnn_sampler_sample(self.h, _ptr(seeds), C.c_size_t(seeds.numel()), C.c_uint64(batch_key),
+                                          batch.h, _stream()), "fgnn_sampler_sample")
+
+
+class Batch:
+    def __init__(self, sampler, feat_dim, feat_dtype, label_dtype, feat_rows_cap):
+        L = load()
+        err = C.c_int(0)
+        self.sampler = sampler
+        self.h = C.c_void_p(L.fgnn_batch_create(sampler.h, C.c_size_t(feat_dim), C.c_int(feat_dtype),
+                                                C.c_int(label_dtype), C.c_size_t(feat_rows_cap), C.byref(err)))
+        if not self.h:
+            raise FgnnError(f"fgnn_batch_create failed with code {err.value} {L.fgnn_last_error().decode()}")
+        self.feat_dim, self.feat_dtype, self.label_dtype = feat_dim, feat_dtype, label_dtype
+        self.meta = None
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.fgnn_batch_destroy(self.h)
+            self.h = None
+
+    def cache_index(self, table):
+        _check(load().fgnn_batch_cache_index(self.h, _ptr(table), _stream()), "fgnn_batch_cache_index")
+
+    def extract(self, feat=None, label=None):
+        _check(load().fgnn_batch_extract(self.h, _ptr(feat), _ptr(label), _stream()), "fgnn_batch_extract")
+
+    def extract_cached(self, cache_rows, full_feat, label=None):
+        _check(load().fgnn_batch_extract_cached(self.h, _ptr(cache_rows), _ptr(full_feat), _ptr(label), _stream()),
+               "fgnn_batch_extract_cached")
+
+    def finish(self):
+        _check(load().fgnn_batch_finish(self.h, _stream()), "fgnn_batch_finish")
+
+    def wait(self):
+        m = BatchMeta()
+        _check(load().fgnn_batch_wait(self.h, C.byref(m)), "fgnn_batch_wait")
+        self.meta = m
+        return m
+
+    # views of the device buffers, sized by the (waited-for) summary
+    def graph(self, layer):
+        m, L, dev = self.meta, load(), self.sampler.device
+        ne = int(m.num_edge[layer])
+        row = _wrap_device(L.fgnn_batch_row(self.h, layer), (ne,), I32, dev)
+        col = _wrap_device(L.fgnn_batch_col(self.h, layer), (ne,), I32, dev)
+        return row, col, int(m.num_src[layer]), int(m.num_dst[layer])
+
+    def input_nodes(self):
+        return _wrap_device(load().fgnn_batch_input_nodes(self.h), (int(self.meta.num_input),), I32,
+                            self.sampler.device)
+
+    def output_nodes(self):
+        return _wrap_device(load().fgnn_batch_output_nodes(self.h), (int(self.meta.num_output),), I32,
+                            self.sampler.device)
+
+    def feat(self):
+        return _wrap_device(load().fgnn_batch_feat(self.h), (int(self.meta.num_input), self.feat_dim),
+                            self.feat_dtype, self.sampler.device)
+
+    def label(self):
+        return _wrap_device(load().fgnn_batch_label(self.h), (int(self.meta.num_output),), self.label_dtype,
+                            self.sampler.device)
+
+    def cache_index_arrays(self):
+        m, L, dev = self.meta, load(), self.sampler.device
+        n = [int(m.num_miss), int(m.num_miss), int(m.num_cache), int(m.num_cache)]
+        return [_wrap_device(L.fgnn_batch_cache_index_ptr(self.h, k), (n[k],), I32, dev) for k in range(4)]

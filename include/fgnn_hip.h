@@ -117,6 +117,90 @@ int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size
 int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
                      size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, void *stream);
 
+/* ---- batch driver -------------------------------------------------------------------------
+ * One object per sampler GPU that enqueues a whole mini-batch without a single host round trip:
+ * DoGPUSample (cuda_loops.cc:50-267 == dist/dist_loops.cc:51-269), DoGetCacheMissIndex
+ * (dist_loops.cc:271-323) and DoGPUFeatureExtract (cuda_loops.cc:726-770).  The reference allocates
+ * every intermediate from a pool and synchronises ~40 times per layer; here all buffers are sized
+ * once for the worst case (PredictNumNodes, common.cc:330-339), counts stay on the device, and the
+ * host reads one small pinned summary per batch. */
+
+#define FGNN_MAX_LAYERS 8
+
+typedef struct fgnn_sampler fgnn_sampler;
+typedef struct fgnn_batch fgnn_batch;
+
+typedef struct {
+  const uint32_t *indptr;   /* device, u32[num_node + 1] */
+  uint32_t *indices;        /* device, u32[num_edge]; mutated by khop2 like the reference */
+  const float *prob_prefix; /* device, f32[num_edge] or NULL (weighted_khop_prefix only) */
+  size_t num_node;
+  int sample_type;          /* SampleType, common.h:50-58 */
+  size_t num_layers;
+  size_t fanout[FGNN_MAX_LAYERS];
+  size_t max_batch_size;
+  uint64_t seed;            /* Philox seed (replaces the clock seed of cuda_random_states.cu:105-107) */
+  size_t walk_len, num_walks; /* random walk: RunConfig::random_walk_length / num_random_walk */
+  double restart_prob;
+} fgnn_sampler_config;
+
+/* Host-visible summary of one batch (Task / TrainGraph / MissCacheIndex sizes, common.h:186-222);
+ * valid after fgnn_batch_wait. */
+typedef struct {
+  uint64_t key;
+  uint64_t num_edge[FGNN_MAX_LAYERS]; /* TrainGraph::num_edge */
+  uint32_t num_src[FGNN_MAX_LAYERS];  /* TrainGraph::num_src = #unique after the layer */
+  uint32_t num_dst[FGNN_MAX_LAYERS];  /* TrainGraph::num_dst = #seeds of the layer */
+  uint32_t num_layers;
+  uint32_t num_input;                 /* |input_nodes| */
+  uint32_t num_output;                /* |output_nodes| = batch size */
+  uint32_t num_miss, num_cache;
+  uint32_t overflow;                  /* non-zero if a capacity was exceeded (results truncated) */
+} fgnn_batch_meta;
+
+fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);
+void fgnn_sampler_destroy(fgnn_sampler *s);
+size_t fgnn_sampler_max_nodes(const fgnn_sampler *s);            /* PredictNumNodes(batch, fanout, L) */
+size_t fgnn_sampler_max_edges(const fgnn_sampler *s, int layer); /* worst-case edges of graphs[layer] */
+
+/* Output buffers of one in-flight batch.  feat_rows_cap = 0 sizes the feature buffer for the worst
+ * case; feat_dim = 0 skips feature/label buffers (sampler-only use). */
+fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim, int feat_dtype, int label_dtype,
+                              size_t feat_rows_cap, int *h_err);
+void fgnn_batch_destroy(fgnn_batch *b);
+
+/* DoGPUSample: Reset, FillWithUnique(seeds), then per layer (last fanout first) sample ->
+ * FillWithDuplicates -> remap.  graphs[l]: row = local id of the sampled neighbour, col = local id of
+ * the seed, data = random-walk visit count.  input_nodes = final unique list. */
+int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                        fgnn_batch *out, void *stream);
+/* DoGetCacheMissIndex on input_nodes against a direct-map table u32[num_node]. */
+int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream);
+/* DoGPUFeatureExtract: feat_out[i,:] = feat[input_nodes[i],:], label_out[i] = label[output_nodes[i]].
+ * Either source may be NULL to skip it. */
+int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream);
+/* Trainer-side DoCacheFeatureCopy (dist_loops.cc:713-846) with the miss rows gathered by the GPU:
+ * feat_out[cache_dst] = cache_rows[cache_src]; feat_out[miss_dst] = full_feat[miss_src] where
+ * full_feat is device-accessible (HBM, or pinned / registered host memory read over the host link). */
+int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void *full_feat, const void *label,
+                              void *stream);
+/* async copy of the summary to pinned host memory + event */
+int fgnn_batch_finish(fgnn_batch *b, void *stream);
+/* blocks until the batch's event; copies the summary to *h_meta (may be NULL) */
+int fgnn_batch_wait(fgnn_batch *b, fgnn_batch_meta *h_meta);
+
+/* device pointers into a batch */
+const uint32_t *fgnn_batch_row(const fgnn_batch *b, int layer);
+const uint32_t *fgnn_batch_col(const fgnn_batch *b, int layer);
+const uint32_t *fgnn_batch_data(const fgnn_batch *b, int layer);
+const uint32_t *fgnn_batch_input_nodes(const fgnn_batch *b);
+const uint32_t *fgnn_batch_output_nodes(const fgnn_batch *b);
+const void *fgnn_batch_feat(const fgnn_batch *b);
+const void *fgnn_batch_label(const fgnn_batch *b);
+/* which: 0 miss_src, 1 miss_dst, 2 cache_src, 3 cache_dst */
+const uint32_t *fgnn_batch_cache_index_ptr(const fgnn_batch *b, int which);
+const fgnn_batch_meta *fgnn_batch_device_meta(const fgnn_batch *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,57 @@ def test_layered_pipeline_matches_oracle(hip, oracle, kind, fanouts, batch):
             np.testing.assert_array_equal(host_u32(col, ne), want["graphs"][li]["col"])
         np.testing.assert_array_equal(host_u32(ht.unique()), want["input_nodes"])
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.parametrize("kind,fanouts,batch,dim", [("khop2", [25, 10], 3000, 128), ("khop0", [5, 10, 15], 200, 100),
+                                                    ("khop2", [3], 17, 4)])
+def test_batch_driver_matches_oracle(hip, oracle, kind, fanouts, batch, dim):
+    """fgnn_sampler_sample + cache_index + extract (the C++ per-batch driver) against
+    oracle do_sample + get_miss_cache_index + extract, three batches in a row, last one short."""
+    from fgnn_hip import synth
+    num_node = 120000
+    indptr, indices = synth.powerlaw_csr(num_node, 2000000, seed=6)
+    feat = synth.node_features(num_node, dim)
+    label = np.random.default_rng(1).integers(0, 47, size=num_node).astype(np.int64)
+    rank = np.random.default_rng(2).permutation(num_node).astype(np.uint32)
+    table = oracle.cache_table_build(rank, num_node // 4, num_node)
+    cache_rows = oracle.extract(feat, rank[:num_node // 4])
+    d_indices = dev(indices.copy())
+    st = hip.KHOP0 if kind == "khop0" else hip.KHOP2
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=st, seed=SEED)
+    assert sampler.max_nodes == oracle.predict_num_nodes(batch, fanouts)
+    batches = [sampler.new_batch(dim, hip.F32, hip.I64) for _ in range(2)]
+    d_feat, d_label, d_table, d_cache = dev(feat), dev(label), dev(table), dev(cache_rows)
+    o_indices = indices.copy()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    ost = oracle.KHOP0 if kind == "khop0" else oracle.KHOP2
+    for b, n in enumerate([batch, batch, max(1, batch // 3)]):
+        seeds = _seeds(n, num_node, seed=200 + b)
+        bt = batches[b % 2]
+        sampler.sample(dev(seeds), 1000 + b, bt)
+        bt.cache_index(d_table)
+        if b == 1:
+            bt.extract_cached(d_cache, d_feat, d_label)  # cache rows from the HBM cache + miss rows by GPU gather
+        else:
+            bt.extract(d_feat, d_label)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, 1000 + b, oht)
+        assert m.key == 1000 + b and m.num_layers == len(fanouts) and m.overflow == 0 and m.num_output == n
+        for li in range(len(fanouts)):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        nodes = host_u32(bt.input_nodes())
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        np.testing.assert_array_equal(host_u32(bt.output_nodes()), seeds)
+        o_split = oracle.get_miss_cache_index(table, nodes)
+        for got, w in zip(bt.cache_index_arrays(), o_split):
+            np.testing.assert_array_equal(host_u32(got), w)
+        assert m.num_miss + m.num_cache == m.num_input
+        assert bt.feat().cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
+        np.testing.assert_array_equal(bt.label().cpu().numpy(), label[seeds])
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
