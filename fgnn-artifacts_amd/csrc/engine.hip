@@ -93,7 +93,19 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   if (!cfg || !cfg->indptr || !cfg->indices || cfg->num_layers == 0 || cfg->num_layers > FGNN_MAX_LAYERS ||
       cfg->max_batch_size == 0)
     return fail(FGNN_EINVAL);
-  if (cfg->sample_type != FGNN_KHOP0 && cfg->sample_type != FGNN_KHOP2) return fail(FGNN_EINVAL);
+  switch (cfg->sample_type) {
+    case FGNN_KHOP0:
+    case FGNN_KHOP2:
+      break;
+    case FGNN_WEIGHTED_KHOP_PREFIX:
+      if (!cfg->prob_prefix) return fail(FGNN_EINVAL);
+      break;
+    case FGNN_RANDOM_WALK:
+      if (cfg->walk_len == 0 || cfg->num_walks == 0) return fail(FGNN_EINVAL);
+      break;
+    default:
+      return fail(FGNN_EINVAL);  // khop1 / weighted_khop / hash_dedup: not built yet
+  }
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
@@ -116,6 +128,12 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   s->ht = fgnn_hashtable_create(s->max_nodes, &err);
   if (!s->ht) { delete s; return fail(err); }
   s->ws_bytes = fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes);
+  for (size_t l = 0; l < cfg->num_layers; ++l) {
+    size_t need = 0;
+    if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX) need = fgnn_weighted_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
+    if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
+    if (need > s->ws_bytes) s->ws_bytes = need;
+  }
   if (hipMalloc(&s->tmp_dst, s->max_edge_cap * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) {
     fgnn_sampler_destroy(s);
@@ -180,6 +198,8 @@ extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim,
   for (size_t l = 0; l < s->cfg.num_layers && ok; ++l) {
     ok = ok && hipMalloc(&b->row[l], s->edge_cap[l] * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&b->col[l], s->edge_cap[l] * sizeof(uint32_t)) == hipSuccess;
+    if (s->cfg.sample_type == FGNN_RANDOM_WALK)
+      ok = ok && hipMalloc(&b->data[l], s->edge_cap[l] * sizeof(uint32_t)) == hipSuccess;
   }
   ok = ok && hipMalloc(&b->input_nodes, s->max_nodes * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&b->output_nodes, s->cfg.max_batch_size * sizeof(uint32_t)) == hipSuccess;
@@ -227,7 +247,17 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     const size_t fan = s->cfg.fanout[l];
     const size_t ecap = in_cap * fan;
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
-    if (s->cfg.sample_type == FGNN_KHOP2)
+    if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX)
+      rc = fgnn_sample_weighted_khop_prefix(s->cfg.indptr, s->cfg.indices, s->cfg.prob_prefix, cur, cur_n_host,
+                                            d_cur_n, in_cap, fan, out->col[l], s->tmp_dst, d_ne, FGNN_SRC_LOCAL,
+                                            s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes, stream);
+    else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
+      // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
+      rc = fgnn_sample_random_walk(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
+                                   s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], s->tmp_dst, out->data[l],
+                                   d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
+                                   stream);
+    else if (s->cfg.sample_type == FGNN_KHOP2)
       rc = fgnn_sample_khop2(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
                              s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
                              stream);

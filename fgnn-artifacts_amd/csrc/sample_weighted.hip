@@ -1,0 +1,194 @@
+// sample_weighted.hip -- weighted neighbour sampling with replacement via per-row prefix sums.
+//
+// Replaces GPUSampleWeightedKHopPrefix (reference samgraph/common/cuda/
+// cuda_sampling_weighted_khop_prefix.cu:41-255): every (seed, slot) draws x = U(0,1] * rowsum and
+// binary-searches the row's inclusive prefix-sum table; the reference then radix-sorts ALL
+// num_input*fanout (src,dst) pairs by src and drops ADJACENT duplicates.  Bit-identical to oracle
+// fgnn_oracle_sample_weighted_khop_prefix.
+//
+// MI355X design: seeds are unique, so the stable sort of the pairs by src is just the seeds' groups
+// reordered by seed id -- only the num_input seeds are sorted (rocPRIM radix sort, fanout x fewer
+// keys than the reference sorts), the draws are one-lane-per-draw (all 64 lanes busy, independent
+// binary searches in flight), adjacent-duplicate removal is a per-seed count known before the
+// compaction, and the offsets come from a scan in sorted-seed order.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fgnn_device.h"
+
+namespace fgnn {
+namespace {
+
+__device__ __forceinline__ float uniform_float(uint32_t x) {
+  return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1], 24 bits, as the oracle
+}
+
+// one lane per (seed, slot)
+__global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *__restrict__ indptr,
+                                                               const uint32_t *__restrict__ indices,
+                                                               const float *__restrict__ prefix,
+                                                               const uint32_t *__restrict__ input, size_t n_host,
+                                                               const uint32_t *d_n, size_t cap, uint32_t F,
+                                                               uint32_t *__restrict__ tmp_dst, uint64_t seed,
+                                                               uint64_t batch_key, uint32_t tag) {
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t total = n * F;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const size_t i = t / F;
+    const uint32_t j = (uint32_t)(t - i * F);
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    uint32_t pick = FGNN_EMPTY_KEY;
+    if (len != 0) {
+      const float up = prefix[off + len - 1];
+      const float x = uniform_float(philox_u32(seed, batch_key, tag, (uint32_t)i, j)) * up;
+      if (x <= prefix[off]) {
+        pick = indices[off];
+      } else {
+        size_t lo = off, hi = (size_t)off + len - 1;
+        while (hi - lo >= 2) {
+          const size_t mid = (lo + hi) >> 1;
+          if (prefix[mid] >= x) hi = mid; else lo = mid;
+        }
+        pick = indices[hi];
+      }
+    }
+    tmp_dst[t] = pick;
+  }
+}
+
+// one lane per seed: sort key (seed id, kEmptyKey for empty rows / padding) and #edges kept after
+// removing a draw equal to the NEXT draw of the same seed (count_edge, prefix.cu:94-112)
+__global__ __launch_bounds__(kBlock) void weighted_count_kernel(const uint32_t *__restrict__ indptr,
+                                                                const uint32_t *__restrict__ input, size_t n_host,
+                                                                const uint32_t *d_n, size_t cap, uint32_t F,
+                                                                const uint32_t *__restrict__ tmp_dst,
+                                                                uint32_t *__restrict__ keys,
+                                                                uint32_t *__restrict__ vals,
+                                                                uint32_t *__restrict__ cnt) {
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  uint32_t key = FGNN_EMPTY_KEY, c = 0;
+  if (i < n) {
+    const uint32_t rid = input[i];
+    if (indptr[rid + 1] != indptr[rid]) {
+      key = rid;
+      const uint32_t *d = tmp_dst + i * F;
+      uint32_t prev = d[0];
+      for (uint32_t j = 1; j < F; ++j) {
+        const uint32_t cur = d[j];
+        c += (prev != cur);
+        prev = cur;
+      }
+      c += 1;  // the last draw of a seed is always kept
+    }
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+  cnt[i] = c;
+}
+
+// per-workgroup sums of cnt in sorted-seed order
+__global__ __launch_bounds__(kBlock) void weighted_sorted_sums_kernel(const uint32_t *__restrict__ order,
+                                                                      const uint32_t *__restrict__ cnt, size_t cap,
+                                                                      uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = r < cap ? cnt[order[r]] : 0u;
+  uint32_t tot;
+  (void)block_exclusive_scan<kWavesPerBlock>(c, sh, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void weighted_emit_kernel(const uint32_t *__restrict__ input,
+                                                               const uint32_t *__restrict__ order,
+                                                               const uint32_t *__restrict__ cnt, size_t cap,
+                                                               uint32_t F, const uint32_t *__restrict__ tmp_dst,
+                                                               const uint32_t *__restrict__ block_offsets,
+                                                               uint32_t *__restrict__ out_src,
+                                                               uint32_t *__restrict__ out_dst, int src_mode) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t i = 0, c = 0;
+  if (r < cap) {
+    i = order[r];
+    c = cnt[i];
+  }
+  uint32_t tot;
+  const uint32_t lo = block_exclusive_scan<kWavesPerBlock>(c, sh, &tot);
+  if (c == 0) return;
+  size_t w = (size_t)block_offsets[blockIdx.x] + lo;
+  const uint32_t src = src_mode == FGNN_SRC_LOCAL ? i : input[i];
+  const uint32_t *d = tmp_dst + (size_t)i * F;
+  uint32_t cur = d[0];
+  for (uint32_t j = 0; j < F; ++j) {
+    const uint32_t nxt = (j + 1 < F) ? d[j + 1] : ~cur;  // ~cur != cur: last one always kept
+    if (cur != nxt) {
+      out_src[w] = src;
+      out_dst[w] = cur;
+      ++w;
+    }
+    cur = nxt;
+  }
+}
+
+}  // namespace
+}  // namespace fgnn
+
+using namespace fgnn;
+
+// scratch layout for cap seeds, fanout F (all uint32 unless noted):
+//   tmp_dst[cap*F] | keys[cap] | vals[cap] | keys_out[cap] | order[cap] | cnt[cap] | sums[nb+1] | rocprim temp
+extern "C" size_t fgnn_weighted_scratch_bytes(size_t num_input_cap, size_t fanout) {
+  size_t temp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (uint32_t *)nullptr, num_input_cap ? num_input_cap : 1, 0, 32, (hipStream_t)0);
+  const size_t nb = div_up(num_input_cap, kBlock);
+  return (num_input_cap * fanout + 5 * num_input_cap + nb + 8) * sizeof(uint32_t) + temp + 256;
+}
+
+extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,
+                                                const uint32_t *input, size_t num_input,
+                                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                                uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
+                                                uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
+                                                size_t ws_bytes, void *stream) {
+  auto st = static_cast<hipStream_t>(stream);
+  size_t cap = d_num_input ? num_input_cap : num_input;
+  if (fanout == 0 || fanout > 0xffffu) return FGNN_EINVAL;
+  if (cap == 0) {
+    if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), st));
+    return FGNN_OK;
+  }
+  if (!indptr || !indices || !prefix || !input || cap * fanout >= 0x7fffffffull) return FGNN_EINVAL;
+  if (ws_bytes < fgnn_weighted_scratch_bytes(cap, fanout)) return FGNN_ENOSPC;
+  const uint32_t F = (uint32_t)fanout;
+  const uint32_t tag = ((uint32_t)FGNN_WEIGHTED_KHOP_PREFIX << 8) | (layer & 0xffu);
+  const size_t nb = div_up(cap, kBlock);
+  uint32_t *tmp_dst = static_cast<uint32_t *>(ws);
+  uint32_t *keys = tmp_dst + cap * F;
+  uint32_t *vals = keys + cap;
+  uint32_t *keys_out = vals + cap;
+  uint32_t *order = keys_out + cap;
+  uint32_t *cnt = order + cap;
+  uint32_t *sums = cnt + cap;
+  void *temp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(sums + nb + 8) + 255) & ~uintptr_t(255));
+  size_t temp_bytes = ws_bytes - (static_cast<char *>(temp) - static_cast<char *>(ws));
+
+  size_t blocks = div_up(cap * F, kBlock);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(weighted_draw_kernel, dim3(blocks), dim3(kBlock), 0, st, indptr, indices, prefix, input, num_input,
+                     d_num_input, cap, F, tmp_dst, seed, batch_key, tag);
+  hipLaunchKernelGGL(weighted_count_kernel, dim3(nb), dim3(kBlock), 0, st, indptr, input, num_input, d_num_input, cap, F,
+                     tmp_dst, keys, vals, cnt);
+  FGNN_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, vals, order, cap, 0, 32, st));
+  hipLaunchKernelGGL(weighted_sorted_sums_kernel, dim3(nb), dim3(kBlock), 0, st, order, cnt, cap, sums);
+  if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
+  hipLaunchKernelGGL(weighted_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, order, cnt, cap, F, tmp_dst, sums,
+                     out_src, out_dst, src_mode);
+  return launch_status(__func__);
+}

@@ -21,6 +21,8 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
 
 EXPORTS = [
     "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
+    "fgnn_sample_random_walk",
     "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_get_miss_cache_index", "fgnn_gather_rows",
@@ -107,6 +109,44 @@ def sample_khop(kind, indptr, indices, inp, fanout, seed, batch_key, layer, src_
               C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws), C.c_size_t(ws.numel()), _stream())
     _check(code, "fgnn_sample_" + kind)
     return out_src, out_dst, d_num_out
+
+
+def sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, seed, batch_key, layer, src_mode=SRC_GLOBAL,
+                                d_num_input=None):
+    L = load()
+    _need_gpu(indptr, indices, prefix, inp)
+    L.fgnn_weighted_scratch_bytes.restype = C.c_size_t
+    n, dev = inp.numel(), inp.device
+    out_src = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    d_num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.fgnn_weighted_scratch_bytes(C.c_size_t(max(n, 1)), C.c_size_t(fanout)), dtype=torch.uint8,
+                     device=dev)
+    _check(L.fgnn_sample_weighted_khop_prefix(_ptr(indptr), _ptr(indices), _ptr(prefix), _ptr(inp), C.c_size_t(n),
+                                              _ptr(d_num_input), C.c_size_t(n), C.c_size_t(fanout), _ptr(out_src),
+                                              _ptr(out_dst), _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed),
+                                              C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws),
+                                              C.c_size_t(ws.numel()), _stream()), "fgnn_sample_weighted_khop_prefix")
+    return out_src, out_dst, d_num_out
+
+
+def sample_random_walk(indptr, indices, inp, walk_len, restart_prob, num_walks, K, seed, batch_key, layer,
+                       src_mode=SRC_GLOBAL, d_num_input=None):
+    L = load()
+    _need_gpu(indptr, indices, inp)
+    L.fgnn_random_walk_scratch_bytes.restype = C.c_size_t
+    n, dev = inp.numel(), inp.device
+    outs = [torch.empty(max(n * K, 1), dtype=torch.int32, device=dev) for _ in range(3)]
+    d_num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.fgnn_random_walk_scratch_bytes(C.c_size_t(max(n, 1)), C.c_size_t(K)), dtype=torch.uint8,
+                     device=dev)
+    _check(L.fgnn_sample_random_walk(_ptr(indptr), _ptr(indices), _ptr(inp), C.c_size_t(n), _ptr(d_num_input),
+                                     C.c_size_t(n), C.c_size_t(walk_len), C.c_double(restart_prob),
+                                     C.c_size_t(num_walks), C.c_size_t(K), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                     _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed), C.c_uint64(batch_key),
+                                     C.c_uint32(layer), _ptr(ws), C.c_size_t(ws.numel()), _stream()),
+           "fgnn_sample_random_walk")
+    return outs[0], outs[1], outs[2], d_num_out
 
 
 class HashTable:
@@ -358,6 +398,12 @@ class Batch:
         row = _wrap_device(L.fgnn_batch_row(self.h, layer), (ne,), I32, dev)
         col = _wrap_device(L.fgnn_batch_col(self.h, layer), (ne,), I32, dev)
         return row, col, int(m.num_src[layer]), int(m.num_dst[layer])
+
+    def graph_data(self, layer):
+        p = load().fgnn_batch_data(self.h, layer)
+        if not p:
+            return None
+        return _wrap_device(p, (int(self.meta.num_edge[layer]),), I32, self.sampler.device)
 
     def input_nodes(self):
         return _wrap_device(load().fgnn_batch_input_nodes(self.h), (int(self.meta.num_input),), I32,

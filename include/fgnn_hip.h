@@ -69,6 +69,28 @@ int fgnn_sample_khop2(const uint32_t *indptr, uint32_t *indices, const uint32_t 
                       uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
                       void *stream);
 
+/* GPUSampleWeightedKHopPrefix (cuda_sampling_weighted_khop_prefix.cu:148-255): with replacement,
+ * x = U(0,1] * rowsum binary-searched in the per-row inclusive prefix sums `prob_prefix`; output
+ * ordered by seed id ascending (the reference's stable radix sort by src), draws of a seed in draw
+ * order with a draw dropped when it equals the seed's NEXT draw.  Scratch: fgnn_weighted_scratch_bytes. */
+size_t fgnn_weighted_scratch_bytes(size_t num_input_cap, size_t fanout);
+int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prob_prefix,
+                                     const uint32_t *input, size_t num_input, const uint32_t *d_num_input,
+                                     size_t num_input_cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                                     size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                                     uint32_t layer, void *ws, size_t ws_bytes, void *stream);
+
+/* GPUSampleRandomWalk + FrequencyHashmap::GetTopK (cuda_sampling_random_walk.cu:113-161,
+ * cuda_frequency_hashmap.cu:1143-1367): num_walks restart walks of walk_len steps per seed; per seed
+ * the K most frequently visited nodes (count desc, first visit asc); out_data = visit count.
+ * Scratch: fgnn_random_walk_scratch_bytes. */
+size_t fgnn_random_walk_scratch_bytes(size_t num_input_cap, size_t K);
+int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                            size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t walk_len,
+                            double restart_prob, size_t num_walks, size_t K, uint32_t *out_src, uint32_t *out_dst,
+                            uint32_t *out_data, size_t *d_num_out, int src_mode, uint64_t seed,
+                            uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- dedup / remap: OrderedHashTable (cuda_hashtable.h:99-149) ---------------------------- */
 
 typedef struct fgnn_hashtable fgnn_hashtable;

@@ -286,3 +286,87 @@ def test_batch_driver_matches_oracle(hip, oracle, kind, fanouts, batch, dim):
         assert bt.feat().cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
         np.testing.assert_array_equal(bt.label().cpu().numpy(), label[seeds])
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.parametrize("fanout", [1, 5, 15])
+def test_weighted_prefix_matches_oracle(hip, oracle, fanout):
+    from fgnn_hip import synth
+    num_node = 4000
+    indptr, indices = synth.powerlaw_csr(num_node, 70000, seed=31)
+    prefix = synth.prob_prefix_table(indptr, indices)
+    d = [dev(indptr), dev(indices), dev(prefix)]
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for call, n in enumerate([1500, 1, 0, 777]):
+        inp = _seeds(n, num_node, seed=40 + call)
+        d_inp = dev(inp) if n else torch.empty(0, dtype=torch.int32, device="cuda")
+        o_src, o_dst = oracle.sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, rng, 9 + call, 2)
+        src, dst, d_ne = hip.sample_weighted_khop_prefix(d[0], d[1], d[2], d_inp, fanout, SEED, 9 + call, 2)
+        ne = int(d_ne.cpu()[0])
+        assert ne == len(o_dst)
+        np.testing.assert_array_equal(host_u32(src, ne), o_src)
+        np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
+        if n > 1:
+            assert (np.diff(o_src.astype(np.int64)) >= 0).all()  # ordered by seed id (stable radix sort by src)
+
+
+@pytest.mark.parametrize("walk_len,num_walks,K,restart", [(3, 4, 5, 0.5), (3, 25, 5, 0.5), (2, 70, 3, 0.0),
+                                                          (4, 3, 20, 0.9)])
+def test_random_walk_matches_oracle(hip, oracle, walk_len, num_walks, K, restart):
+    from fgnn_hip import synth
+    num_node = 3000
+    indptr, indices = synth.powerlaw_csr(num_node, 40000, seed=33)
+    d_indptr, d_indices = dev(indptr), dev(indices)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for call, n in enumerate([1000, 3, 0]):
+        inp = _seeds(n, num_node, seed=50 + call)
+        d_inp = dev(inp) if n else torch.empty(0, dtype=torch.int32, device="cuda")
+        o = oracle.sample_random_walk(indptr, indices, inp, walk_len, restart, num_walks, K, rng, 3 + call, 1)
+        src, dst, dat, d_ne = hip.sample_random_walk(d_indptr, d_indices, d_inp, walk_len, restart, num_walks, K, SEED,
+                                                     3 + call, 1)
+        ne = int(d_ne.cpu()[0])
+        assert ne == len(o[0])
+        np.testing.assert_array_equal(host_u32(src, ne), o[0])
+        np.testing.assert_array_equal(host_u32(dst, ne), o[1])
+        np.testing.assert_array_equal(host_u32(dat, ne), o[2])
+
+
+@pytest.mark.parametrize("mode", ["weighted", "random_walk"])
+def test_batch_driver_other_samplers(hip, oracle, mode):
+    """BASELINE configs 4/5 in miniature: GCN [5,10,15] weighted-prefix; PinSAGE random walk, 3 layers, K=5."""
+    from fgnn_hip import synth
+    num_node = 30000
+    indptr, indices = synth.powerlaw_csr(num_node, 500000, seed=35)
+    batch = 150
+    if mode == "weighted":
+        prefix = synth.prob_prefix_table(indptr, indices)
+        fanouts = [5, 10, 15]
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.WEIGHTED_KHOP_PREFIX,
+                              seed=SEED, prob_prefix=dev(prefix))
+        okw = dict(prob_prefix=prefix)
+        ost = oracle.WEIGHTED_KHOP_PREFIX
+    else:
+        fanouts = [5, 5, 5]
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.RANDOM_WALK, seed=SEED,
+                              walk_len=3, num_walks=25, restart_prob=0.5)
+        okw = dict(walk_len=3, num_walks=25, num_neighbor=5, restart_prob=0.5)
+        ost = oracle.RANDOM_WALK
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    for b in range(2):
+        seeds = _seeds(batch - 13 * b, num_node, seed=60 + b)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht, **okw)
+        assert m.overflow == 0
+        for li in range(3):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+            if mode == "random_walk":
+                np.testing.assert_array_equal(host_u32(bt.graph_data(li)), g["data"])
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
