@@ -1,0 +1,49 @@
+// eng_config.h -- RunConfig (reference run_config.h:31-94, operation.cc:45-169, run_config.cc:78-101)
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "eng_common.h"
+
+namespace sam {
+
+enum RunArch { kArch0 = 0, kArch1, kArch2, kArch3, kArch4, kArch5, kArch6, kArch7 };
+enum SampleType { kKHop0 = 0, kKHop1, kWeightedKHop, kRandomWalk, kWeightedKHopPrefix, kKHop2, kWeightedKHopHashDedup };
+enum CachePolicy {
+  kCacheByDegree = 0, kCacheByHeuristic, kCacheByPreSample, kCacheByDegreeHop, kCacheByPreSampleStatic,
+  kCacheByFakeOptimal, kDynamicCache, kCacheByRandom
+};
+
+struct RunConfig {
+  std::unordered_map<std::string, std::string> raw;
+  std::string dataset_path;
+  int run_arch = kArch1;
+  int sample_type = kKHop2;
+  size_t batch_size = 0, num_epoch = 0;
+  Context sampler_ctx, trainer_ctx;
+  int cache_policy = kCacheByPreSample;
+  double cache_percentage = 0.0;
+  size_t max_sampling_jobs = 1, max_copying_jobs = 1;
+  std::vector<size_t> fanout;
+  size_t random_walk_length = 0, num_random_walk = 0, num_neighbor = 0, num_layer = 0;
+  double random_walk_restart_prob = 0.0;
+  size_t num_sample_worker = 1, num_train_worker = 1;
+  bool have_switcher = false;
+  int barriered_epoch = 0, presample_epoch = 0;
+  int omp_thread_num = 1;
+  uint64_t seed = 0x5A4D47;
+  bool is_configured = false;
+  // environment (run_config.cc:78-101)
+  int profile_level = 0;
+  bool option_dump_trace = false, option_sanity_check = false;
+  size_t option_empty_feat = 0;
+  size_t mq_budget_bytes = 8ull << 30;  // SAMGRAPH_MQ_BYTES: total size of the shared queue
+
+  bool UseGPUCache() const { return cache_percentage > 0 && run_arch != kArch1; }  // run_config.h:84-86
+  void Parse(const char **keys, const char **vals, size_t n);
+};
+
+RunConfig &RC();
+
+}  // namespace sam

@@ -1,0 +1,129 @@
+#include "eng_dataset.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <fstream>
+#include <unordered_map>
+
+namespace sam {
+
+void *SharedAnonymous(size_t bytes) {
+  if (bytes == 0) bytes = 4096;
+  void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  SAM_CHECK(p != MAP_FAILED) << "mmap of " << bytes << " bytes failed";
+  return p;
+}
+
+HostArray MapFile(const std::string &path, size_t expect_bytes, bool required) {
+  HostArray a;
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) {
+    SAM_CHECK(!required) << "cannot open " << path;
+    return a;
+  }
+  struct stat st;
+  SAM_CHECK(fstat(fd, &st) == 0);
+  SAM_CHECK_EQ((size_t)st.st_size, expect_bytes) << path << " has the wrong size ";
+  if (expect_bytes) {
+    // PRIVATE + writable: khop2 never writes the host copy, but keep the mapping independent of the file
+    a.ptr = mmap(nullptr, expect_bytes, PROT_READ, MAP_SHARED, fd, 0);
+    SAM_CHECK(a.ptr != MAP_FAILED) << "mmap " << path;
+  }
+  close(fd);
+  a.bytes = expect_bytes;
+  a.from_file = true;
+  return a;
+}
+
+// Reads a whole file into MAP_SHARED|MAP_ANONYMOUS memory: unlike a file-backed mapping it can be
+// hipHostRegister'ed (the trainers' gather kernels read miss rows straight from it) and it is shared by
+// the forked children without copies.  The reference locks its file mappings in RAM as well
+// (MAP_LOCKED, common.cc:98).
+static HostArray ReadFileShared(const std::string &path, size_t expect_bytes) {
+  HostArray a;
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return a;
+  struct stat st;
+  SAM_CHECK(fstat(fd, &st) == 0);
+  SAM_CHECK_EQ((size_t)st.st_size, expect_bytes) << path << " has the wrong size ";
+  a.ptr = SharedAnonymous(expect_bytes);
+  a.bytes = expect_bytes;
+  a.from_file = true;
+  size_t done = 0;
+  while (done < expect_bytes) {
+    ssize_t r = pread(fd, static_cast<char *>(a.ptr) + done, expect_bytes - done, (off_t)done);
+    SAM_CHECK(r > 0) << "short read from " << path;
+    done += (size_t)r;
+  }
+  close(fd);
+  return a;
+}
+
+void Dataset::Load(const RunConfig &rc) {
+  std::string dir = rc.dataset_path;
+  if (dir.back() != '/') dir.push_back('/');
+  std::unordered_map<std::string, size_t> meta;
+  std::ifstream mf(dir + "meta.txt");
+  SAM_CHECK(mf.good()) << "cannot open " << dir << "meta.txt";
+  std::string k;
+  size_t v;
+  while (mf >> k >> v) meta[k] = v;
+  for (const char *key : {"NUM_NODE", "NUM_EDGE", "FEAT_DIM", "NUM_CLASS", "NUM_TRAIN_SET", "NUM_TEST_SET",
+                          "NUM_VALID_SET"})
+    SAM_CHECK(meta.count(key)) << "meta.txt lacks " << key;
+  num_node = meta["NUM_NODE"];
+  num_edge = meta["NUM_EDGE"];
+  feat_dim = meta["FEAT_DIM"];
+  num_class = meta["NUM_CLASS"];
+  num_train = meta["NUM_TRAIN_SET"];
+  num_test = meta["NUM_TEST_SET"];
+  num_valid = meta["NUM_VALID_SET"];
+  SAM_CHECK(num_edge < (1ull << 32)) << "edge ids are 32 bit";
+
+  indptr = MapFile(dir + "indptr.bin", (num_node + 1) * 4, true);
+  indices = MapFile(dir + "indices.bin", num_edge * 4, true);
+  train_set = MapFile(dir + "train_set.bin", num_train * 4, true);
+  test_set = MapFile(dir + "test_set.bin", num_test * 4, false);
+  valid_set = MapFile(dir + "valid_set.bin", num_valid * 4, false);
+
+  // features: file, or an uninitialised buffer (engine.cc:138-155); SAMGRAPH_EMPTY_FEAT=k => 2^k rows
+  feat_rows = rc.option_empty_feat ? (1ull << rc.option_empty_feat) : num_node;
+  if (!rc.option_empty_feat) feat = ReadFileShared(dir + "feat.bin", num_node * feat_dim * 4);
+  if (!feat.ptr) {
+    feat.bytes = feat_rows * feat_dim * 4;
+    feat.ptr = SharedAnonymous(feat.bytes);
+  }
+  label = ReadFileShared(dir + "label.bin", num_node * 8);
+  if (!label.ptr) {
+    label.bytes = num_node * 8;
+    label.ptr = SharedAnonymous(label.bytes);
+  }
+  if (rc.sample_type == kWeightedKHopPrefix)
+    prob_prefix = MapFile(dir + "prob_prefix_table.bin", num_edge * 4, true);
+
+  if (rc.UseGPUCache()) {
+    const char *file = nullptr;
+    switch (rc.cache_policy) {
+      case kCacheByDegree: file = "cache_by_degree.bin"; break;
+      case kCacheByHeuristic: file = "cache_by_heuristic.bin"; break;
+      case kCacheByDegreeHop: file = "cache_by_degree_hop.bin"; break;
+      case kCacheByFakeOptimal: file = "cache_by_fake_optimal.bin"; break;
+      case kCacheByRandom: file = "cache_by_random.bin"; break;
+      case kCacheByPreSample: case kCacheByPreSampleStatic: break;
+      default: SAM_FATAL << "cache policy " << rc.cache_policy << " is not built";
+    }
+    if (file) {
+      ranking_file = MapFile(dir + file, num_node * 4, true);
+      ranking_nodes = static_cast<uint32_t *>(ranking_file.ptr);
+    } else {
+      // written by sampler 0's presample, read by every sampler and trainer (dist_engine.cc:115-127)
+      ranking_nodes = static_cast<uint32_t *>(SharedAnonymous(num_node * 4));
+    }
+  }
+  SAM_LOG(kInfo) << "dataset " << dir << ": " << num_node << " nodes, " << num_edge << " edges, dim " << feat_dim;
+}
+
+}  // namespace sam

@@ -1,0 +1,30 @@
+// eng_dataset.h -- on-disk dataset (reference engine.cc:73-264, constant.cc:23-50): raw
+// little-endian arrays mapped into host memory; everything the children need is MAP_SHARED so it
+// survives fork without duplication.
+#pragma once
+#include <string>
+
+#include "eng_config.h"
+
+namespace sam {
+
+struct HostArray {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  bool from_file = false;
+};
+
+struct Dataset {
+  size_t num_node = 0, num_edge = 0, feat_dim = 0, num_class = 0;
+  size_t num_train = 0, num_test = 0, num_valid = 0;
+  HostArray indptr, indices, feat, label, train_set, test_set, valid_set, prob_prefix, ranking_file;
+  uint32_t *ranking_nodes = nullptr;  // shared anonymous mapping for pre_sample, or the ranking file
+  size_t feat_rows = 0;               // num_node, or 2^SAMGRAPH_EMPTY_FEAT
+  void Load(const RunConfig &rc);
+};
+
+// MAP_SHARED|MAP_ANONYMOUS zero-filled host memory visible to forked children
+void *SharedAnonymous(size_t bytes);
+HostArray MapFile(const std::string &path, size_t expect_bytes, bool required);
+
+}  // namespace sam

@@ -1,0 +1,648 @@
+#include "eng_engine.h"
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstring>
+
+namespace sam {
+
+// ------------------------------------------------------------------------------------------------
+// DevicePool / GraphPool
+
+DevicePool::~DevicePool() {
+  for (auto &kv : free_) (void)hipFree(kv.second);
+}
+
+void *DevicePool::Alloc(size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  // round to 256 B below 1 MiB, to 1 MiB above: similar sizes recur every step
+  const size_t gran = bytes < (1u << 20) ? 256 : (1u << 20);
+  bytes = (bytes + gran - 1) / gran * gran;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = free_.lower_bound(bytes);
+    if (it != free_.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+      void *p = it->second;
+      live_[p] = it->first;
+      free_.erase(it);
+      return p;
+    }
+  }
+  void *p = nullptr;
+  SAM_HIP(hipMalloc(&p, bytes));
+  std::lock_guard<std::mutex> lk(mu_);
+  live_[p] = bytes;
+  return p;
+}
+
+void DevicePool::Free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = live_.find(p);
+  SAM_CHECK(it != live_.end()) << "DevicePool::Free of an unknown pointer";
+  free_.emplace(it->second, p);
+  live_.erase(it);
+}
+
+std::shared_ptr<GraphBatch> GraphPool::Get() {
+  while (true) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!q_.empty()) {
+        auto b = q_.front();
+        q_.pop();
+        return b;
+      }
+      if (stop_) return nullptr;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(1));
+  }
+}
+
+void GraphPool::Submit(std::shared_ptr<GraphBatch> b) {
+  std::lock_guard<std::mutex> lk(mu_);
+  SAM_CHECK(!stop_);
+  q_.push(std::move(b));
+}
+
+bool GraphPool::Full() {
+  std::lock_guard<std::mutex> lk(mu_);
+  return q_.size() >= max_size_;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+Engine &Engine::Get() {
+  static Engine e;
+  return e;
+}
+
+static void *DeviceVisible(void *host) {
+  void *dev = nullptr;
+  SAM_HIP(hipHostGetDevicePointer(&dev, host, 0));
+  return dev;
+}
+
+void Engine::Init() {
+  if (data_initialized_) return;
+  SAM_CHECK(RC().is_configured);
+  Timer t;
+  ds_.Load(RC());
+  Profiler::Get().LogInit(kLogInitL2LoadDataset, t.Passed());
+  num_step_ = RoundUpDiv(ds_.num_train, RC().batch_size);
+  Profiler::Get().Resize(RC().num_epoch, num_step_);
+  data_initialized_ = true;
+  if (RC().run_arch == kArch1) {
+    InitArch1();
+  } else {
+    SAM_CHECK_EQ(RC().run_arch, (int)kArch5);
+    // shared queue + sampler barrier, created BEFORE fork (dist_engine.cc:129-153)
+    Timer tq;
+    const bool have_data = RC().sample_type == kRandomWalk;
+    size_t slot = MaxMessageBytes(RC().batch_size, RC().fanout.data(), RC().fanout.size(), have_data);
+    size_t slots = RC().mq_budget_bytes / slot;
+    if (slots > kMaxSlots) slots = kMaxSlots;
+    if (slots < 2) slots = 2;
+    mq_ = new MemoryQueue(slot, slots);
+    void *bp = SharedAnonymous(sizeof(pthread_barrier_t));
+    sampler_barrier_ = static_cast<pthread_barrier_t *>(bp);
+    pthread_barrierattr_t attr;
+    pthread_barrierattr_init(&attr);
+    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(sampler_barrier_, &attr, (unsigned)RC().num_sample_worker);
+    Profiler::Get().LogInit(kLogInitL2DistQueue, tq.Passed());
+  }
+  Profiler::Get().LogInit(kLogInitL1Common, t.Passed());
+}
+
+void Engine::UploadTopology(int device) {
+  SAM_HIP(hipSetDevice(device));
+  device_ = device;
+  SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  SAM_HIP(hipMalloc(&d_indptr_, ds_.indptr.bytes));
+  SAM_HIP(hipMalloc(&d_indices_, ds_.indices.bytes ? ds_.indices.bytes : 4));
+  SAM_HIP(hipMemcpy(d_indptr_, ds_.indptr.ptr, ds_.indptr.bytes, hipMemcpyHostToDevice));
+  if (ds_.indices.bytes) SAM_HIP(hipMemcpy(d_indices_, ds_.indices.ptr, ds_.indices.bytes, hipMemcpyHostToDevice));
+  if (RC().sample_type == kWeightedKHopPrefix) {
+    SAM_HIP(hipMalloc(&d_prefix_, ds_.prob_prefix.bytes ? ds_.prob_prefix.bytes : 4));
+    SAM_HIP(hipMemcpy(d_prefix_, ds_.prob_prefix.ptr, ds_.prob_prefix.bytes, hipMemcpyHostToDevice));
+  }
+}
+
+void Engine::CreateSampler() {
+  fgnn_sampler_config c;
+  memset(&c, 0, sizeof(c));
+  c.indptr = d_indptr_;
+  c.indices = d_indices_;
+  c.prob_prefix = d_prefix_;
+  c.num_node = ds_.num_node;
+  c.sample_type = RC().sample_type;
+  c.num_layers = RC().fanout.size();
+  for (size_t i = 0; i < c.num_layers; ++i) c.fanout[i] = RC().fanout[i];
+  c.max_batch_size = RC().batch_size;
+  c.seed = RC().seed;
+  c.walk_len = RC().random_walk_length;
+  c.num_walks = RC().num_random_walk;
+  c.restart_prob = RC().random_walk_restart_prob;
+  int err = 0;
+  sampler_ = fgnn_sampler_create(&c, &err);
+  SAM_CHECK(sampler_) << "fgnn_sampler_create failed: " << err << " " << fgnn_last_error();
+}
+
+void Engine::ReleaseBatch(GraphBatch *b) {
+  if (!b) return;
+  for (void *p : b->pooled) dev_pool_.Free(p);
+  b->pooled.clear();
+  for (void *p : b->host_owned) free(p);
+  b->host_owned.clear();
+  if (b->fb) {
+    for (auto &s : slots_)
+      if (s.fb == b->fb) s.busy = false;
+    b->fb = nullptr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// arch1: one GPU samples and extracts (cuda_engine.cc:64-196, cuda_loops_arch1.cc:44-80)
+
+void Engine::InitArch1() {
+  SAM_CHECK(RC().sampler_ctx.IsGPU() && RC().trainer_ctx.IsGPU())
+      << "arch1 needs cuda contexts: the sampling path has no CPU fallback";
+  SAM_CHECK_EQ(RC().sampler_ctx.device_id, RC().trainer_ctx.device_id);
+  Timer t;
+  UploadTopology(RC().sampler_ctx.device_id);
+  SAM_HIP(hipMalloc(&d_feat_, ds_.feat.bytes));
+  SAM_HIP(hipMemcpy(d_feat_, ds_.feat.ptr, ds_.feat.bytes, hipMemcpyHostToDevice));
+  SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
+  SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
+  CreateSampler();
+  shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
+                               RC().batch_size, 0, 1, stream_));
+  pool_.reset(new GraphPool(RC().max_copying_jobs));
+  slots_.resize(RC().max_copying_jobs + 2);
+  for (auto &s : slots_) {
+    int err = 0;
+    s.fb = fgnn_batch_create(sampler_, ds_.feat_dim, FGNN_F32, FGNN_I64, 0, &err);
+    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    SAM_HIP(hipEventCreate(&s.e0));
+    SAM_HIP(hipEventCreate(&s.e1));
+    SAM_HIP(hipEventCreate(&s.e2));
+  }
+  Profiler::Get().LogInit(kLogInitL1Sampler, t.Passed());
+  initialized_ = true;
+}
+
+void Engine::SampleOnceArch1() {
+  if (pool_->Full()) {
+    std::this_thread::sleep_for(std::chrono::microseconds(1));
+    return;
+  }
+  Timer t0;
+  const uint32_t *d_batch = nullptr;
+  size_t bsize = 0;
+  if (!shuffler_->GetBatch(&d_batch, &bsize)) {
+    std::this_thread::sleep_for(std::chrono::microseconds(1));
+    return;
+  }
+  const uint64_t key = BatchKey(shuffler_->Epoch(), shuffler_->Step());
+  const double shuffle_time = t0.Passed();
+  Slot *s = nullptr;
+  for (size_t k = 0; k < slots_.size() && !s; ++k) {
+    Slot &c = slots_[(next_slot_ + k) % slots_.size()];
+    if (!c.busy) {
+      s = &c;
+      next_slot_ = (next_slot_ + k + 1) % slots_.size();
+    }
+  }
+  SAM_CHECK(s) << "no free batch buffer: the trainer holds more than max_copying_jobs batches";
+  SAM_HIP(hipEventRecord(s->e0, stream_));
+  SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s->fb, stream_));
+  SAM_HIP(hipEventRecord(s->e1, stream_));
+  SAM_FGNN(fgnn_batch_extract(s->fb, d_feat_, d_label_, stream_));
+  SAM_HIP(hipEventRecord(s->e2, stream_));
+  SAM_FGNN(fgnn_batch_finish(s->fb, stream_));
+  fgnn_batch_meta m;
+  SAM_FGNN(fgnn_batch_wait(s->fb, &m));
+  SAM_CHECK_EQ(m.overflow, 0u);
+  s->busy = true;
+
+  auto b = std::make_shared<GraphBatch>();
+  b->key = key;
+  b->num_layer = (int)m.num_layers;
+  for (uint32_t l = 0; l < m.num_layers; ++l) {
+    b->graphs[l].row = fgnn_batch_row(s->fb, l);
+    b->graphs[l].col = fgnn_batch_col(s->fb, l);
+    b->graphs[l].data = fgnn_batch_data(s->fb, l);
+    b->graphs[l].num_src = m.num_src[l];
+    b->graphs[l].num_dst = m.num_dst[l];
+    b->graphs[l].num_edge = m.num_edge[l];
+  }
+  b->feat = fgnn_batch_feat(s->fb);
+  b->feat_rows = m.num_input;
+  b->label = fgnn_batch_label(s->fb);
+  b->input_nodes = fgnn_batch_input_nodes(s->fb);
+  b->output_nodes = fgnn_batch_output_nodes(s->fb);
+  b->num_input = m.num_input;
+  b->num_output = m.num_output;
+  b->input_device = b->output_device = b->device = device_;
+  b->fb = s->fb;
+  pool_->Submit(b);
+
+  float ms_sample = 0, ms_extract = 0;
+  (void)hipEventElapsedTime(&ms_sample, s->e0, s->e1);
+  (void)hipEventElapsedTime(&ms_extract, s->e1, s->e2);
+  auto &P = Profiler::Get();
+  size_t edges = 0;
+  for (uint32_t l = 0; l < m.num_layers; ++l) edges += m.num_edge[l];
+  P.LogStep(key, kLogL1NumSample, (double)edges);
+  P.LogStep(key, kLogL1NumNode, (double)m.num_input);
+  P.LogStep(key, kLogL1SampleTime, shuffle_time + ms_sample * 1e-3);
+  P.LogStep(key, kLogL1CopyTime, ms_extract * 1e-3);
+  P.LogStep(key, kLogL2ShuffleTime, shuffle_time);
+  P.LogStep(key, kLogL2CoreSampleTime, ms_sample * 1e-3);
+  P.LogStep(key, kLogL2ExtractTime, ms_extract * 1e-3);
+  P.LogStep(key, kLogL1FeatureBytes, (double)m.num_input * ds_.feat_dim * 4);
+  P.LogStep(key, kLogL1LabelBytes, (double)m.num_output * 8);
+  P.LogEpochAdd(key, kLogEpochSampleTime, shuffle_time + ms_sample * 1e-3);
+  P.LogEpochAdd(key, kLogEpochCopyTime, ms_extract * 1e-3);
+  P.LogEpochAdd(key, kLogEpochSampleTotalTime, t0.Passed());
+}
+
+// ------------------------------------------------------------------------------------------------
+// arch5 sampler process (dist_engine.cc:231-364, dist_loops_arch5.cc:60-156)
+
+void Engine::SampleInit(int worker_id, Context ctx) {
+  if (initialized_) return;
+  SAM_CHECK(data_initialized_) << "samgraph_data_init must run before fork";
+  SAM_CHECK(ctx.IsGPU()) << "sampler context must be cuda:N (no CPU sampling path in this build)";
+  Timer t;
+  dist_type_ = DistType::Sample;
+  UploadTopology(ctx.device_id);
+  mq_->PinMemory();
+  CreateSampler();
+  shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
+                               RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_));
+  pool_.reset(new GraphPool(RC().max_copying_jobs));
+  slots_.resize(2);
+  for (auto &s : slots_) {
+    int err = 0;
+    s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
+    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    SAM_HIP(hipEventCreate(&s.e0));
+    SAM_HIP(hipEventCreate(&s.e1));
+    SAM_HIP(hipEventCreate(&s.e2));
+  }
+  if (RC().UseGPUCache()) {
+    Timer tp;
+    if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) {
+      if (worker_id == 0) PreSample();
+      int rc = pthread_barrier_wait(sampler_barrier_);
+      SAM_CHECK(rc == 0 || rc == PTHREAD_BARRIER_SERIAL_THREAD);
+    }
+    Profiler::Get().LogInit(kLogInitL2Presample, tp.Passed());
+    Timer tc;
+    BuildCacheTable();
+    Profiler::Get().LogInit(kLogInitL2BuildCache, tc.Passed());
+  }
+  Profiler::Get().LogInit(kLogInitL1Sampler, t.Passed());
+  initialized_ = true;
+}
+
+void Engine::PreSample() {
+  // frequency ranking over presample_epoch epochs of the sampling path (dist/pre_sampler.cc:75-162)
+  const int epochs = RC().presample_epoch > 0 ? RC().presample_epoch : 1;
+  Shuffler sh(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, epochs, RC().batch_size, 0, 1, stream_);
+  uint32_t *d_freq = nullptr;
+  SAM_HIP(hipMalloc(&d_freq, ds_.num_node * sizeof(uint32_t)));
+  SAM_HIP(hipMemsetAsync(d_freq, 0, ds_.num_node * sizeof(uint32_t), stream_));
+  fgnn_batch *fb = slots_[0].fb;
+  const uint32_t *d_batch;
+  size_t bsize;
+  const size_t cap = fgnn_sampler_max_nodes(sampler_);
+  while (sh.GetBatch(&d_batch, &bsize)) {
+    // a key space of its own: the presample draws must not replay the training epochs' draws
+    const uint64_t key = (1ull << 63) | (sh.Epoch() * sh.NumStep() + sh.Step());
+    SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, fb, stream_));
+    PresampleCount(d_freq, fgnn_batch_input_nodes(fb), &fgnn_batch_device_meta(fb)->num_input, cap, stream_);
+  }
+  PresampleRank(d_freq, ds_.num_node, ds_.ranking_nodes, stream_);
+  (void)hipFree(d_freq);
+}
+
+void Engine::BuildCacheTable() {
+  // direct-map table: table[ranking_nodes[i]] = i for i < num_cached (dist_engine.cc:193-229)
+  num_cached_ = (size_t)(ds_.num_node * RC().cache_percentage);
+  std::vector<uint32_t> table(ds_.num_node, FGNN_EMPTY_KEY);
+  for (size_t i = 0; i < num_cached_; ++i) table[ds_.ranking_nodes[i]] = (uint32_t)i;
+  SAM_HIP(hipMalloc(&d_cache_table_, ds_.num_node * sizeof(uint32_t)));
+  SAM_HIP(hipMemcpy(d_cache_table_, table.data(), ds_.num_node * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
+void Engine::PublishPending() {
+  if (pending_slot_ < 0) return;
+  Slot &s = slots_[pending_slot_];
+  fgnn_batch_meta m;
+  SAM_FGNN(fgnn_batch_wait(s.fb, &m));  // the pack kernel is ordered before the summary copy
+  SAM_CHECK_EQ(m.overflow, 0u) << "batch exceeded its buffers";
+  mq_->SimpleSend(s.mq_key);
+  s.pending = false;
+  pending_slot_ = -1;
+  float ms_sample = 0, ms_index = 0, ms_send = 0;
+  (void)hipEventElapsedTime(&ms_sample, s.e0, s.e1);
+  (void)hipEventElapsedTime(&ms_index, s.e1, s.e2);
+  auto &P = Profiler::Get();
+  size_t edges = 0;
+  for (uint32_t l = 0; l < m.num_layers; ++l) edges += m.num_edge[l];
+  const uint64_t key = s.key;
+  const double total = s.started.Passed();
+  ms_send = (float)(total * 1e3) - ms_sample - ms_index;
+  P.LogStep(key, kLogL1NumSample, (double)edges);
+  P.LogStep(key, kLogL1NumNode, (double)m.num_input);
+  P.LogStep(key, kLogL1SampleTime, ms_sample * 1e-3);
+  P.LogStep(key, kLogL2CoreSampleTime, ms_sample * 1e-3);
+  P.LogStep(key, kLogL3CacheGetIndexTime, ms_index * 1e-3);
+  P.LogStep(key, kLogL1SendTime, ms_send * 1e-3);
+  P.LogEpochAdd(key, kLogEpochSampleTime, ms_sample * 1e-3);
+  P.LogEpochAdd(key, kLogEpochSampleGetCacheMissIndexTime, ms_index * 1e-3);
+  P.LogEpochAdd(key, kLogEpochSampleSendTime, ms_send * 1e-3);
+  P.LogEpochAdd(key, kLogEpochSampleTotalTime, total);
+}
+
+void Engine::SampleOnceArch5() {
+  const uint32_t *d_batch = nullptr;
+  size_t bsize = 0;
+  if (!shuffler_->GetBatch(&d_batch, &bsize)) SAM_FATAL << "null task from DoShuffle!";
+  const uint64_t key = BatchKey(shuffler_->Epoch(), shuffler_->Step());
+  const int cur = (int)(next_slot_++ % slots_.size());
+  Slot &s = slots_[cur];
+  SAM_CHECK(!s.pending);
+  s.started = Timer();
+  s.key = key;
+  SAM_HIP(hipEventRecord(s.e0, stream_));
+  SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, stream_));
+  SAM_HIP(hipEventRecord(s.e1, stream_));
+  const bool use_cache = RC().UseGPUCache();
+  if (use_cache) SAM_FGNN(fgnn_batch_cache_index(s.fb, d_cache_table_, stream_));
+  SAM_HIP(hipEventRecord(s.e2, stream_));
+  // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
+  void *slot = mq_->GetPtr(&s.mq_key);
+  PackArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d_meta = fgnn_batch_device_meta(s.fb);
+  a.input_nodes = fgnn_batch_input_nodes(s.fb);
+  a.output_nodes = fgnn_batch_output_nodes(s.fb);
+  for (int k = 0; k < 4; ++k) a.cidx[k] = fgnn_batch_cache_index_ptr(s.fb, k);
+  for (size_t l = 0; l < RC().fanout.size(); ++l) {
+    a.row[l] = fgnn_batch_row(s.fb, (int)l);
+    a.col[l] = fgnn_batch_col(s.fb, (int)l);
+    a.data[l] = fgnn_batch_data(s.fb, (int)l);
+  }
+  a.ship_input = (!use_cache || RC().have_switcher) ? 1 : 0;
+  a.ship_cache_index = use_cache ? 1 : 0;
+  a.have_data = RC().sample_type == kRandomWalk ? 1 : 0;
+  a.slot = DeviceVisible(slot);
+  a.slot_bytes = mq_->SlotBytes();
+  SAM_FGNN(LaunchPack(a, stream_));
+  SAM_FGNN(fgnn_batch_finish(s.fb, stream_));
+  s.pending = true;
+  // publish the PREVIOUS batch now that this one is in flight (the reference's PIPELINE branch,
+  // dist_loops_arch5.cc:108-146); the last batch of an epoch is flushed immediately
+  const int prev = pending_slot_;
+  if (prev >= 0) PublishPending();
+  pending_slot_ = cur;
+  if (shuffler_->IsLastBatch()) PublishPending();
+}
+
+// ------------------------------------------------------------------------------------------------
+// arch5 trainer process (dist_engine.cc:366-482, dist_loops_arch5.cc:158-285, dist_loops.cc:713-929)
+
+void Engine::TrainInit(int worker_id, Context ctx, DistType type) {
+  (void)worker_id;
+  if (initialized_) return;
+  SAM_CHECK(data_initialized_) << "samgraph_data_init must run before fork";
+  SAM_CHECK(ctx.IsGPU()) << "trainer context must be cuda:N";
+  Timer t;
+  dist_type_ = type;
+  SAM_HIP(hipSetDevice(ctx.device_id));
+  device_ = ctx.device_id;
+  SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  mq_->PinMemory();
+  // the host feature table becomes GPU-readable: miss rows are fetched by the gather kernel itself
+  // (replaces the OpenMP ExtractMissData + H2D copy, cuda_cache_manager_host.cc:38-56)
+  SAM_HIP(hipHostRegister(ds_.feat.ptr, ds_.feat.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+  dev_host_feat_ = DeviceVisible(ds_.feat.ptr);
+  SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
+  SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
+  if (RC().UseGPUCache()) {
+    Timer tc;
+    BuildTrainerCache();
+    Profiler::Get().LogInit(kLogInitL2BuildCache, tc.Passed());
+  }
+  pool_.reset(new GraphPool(RC().max_copying_jobs));
+  Profiler::Get().LogInit(kLogInitL1Trainer, t.Passed());
+  initialized_ = true;
+}
+
+void Engine::BuildTrainerCache() {
+  // DistCacheManager (dist_cache_manager_host.cc:60-119): top cache_percentage*N rows of the ranking
+  num_cached_ = (size_t)(ds_.num_node * RC().cache_percentage);
+  const size_t row_bytes = ds_.feat_dim * 4;
+  SAM_HIP(hipMalloc(&d_cache_rows_, num_cached_ ? num_cached_ * row_bytes : 16));
+  if (num_cached_) {
+    uint32_t *d_rank = nullptr;
+    SAM_HIP(hipMalloc(&d_rank, num_cached_ * sizeof(uint32_t)));
+    SAM_HIP(hipMemcpy(d_rank, ds_.ranking_nodes, num_cached_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SAM_FGNN(fgnn_gather_rows(d_cache_rows_, dev_host_feat_, d_rank, nullptr, num_cached_, nullptr, num_cached_,
+                              ds_.feat_dim, FGNN_F32, stream_));
+    SAM_HIP(hipStreamSynchronize(stream_));
+    (void)hipFree(d_rank);
+  }
+  if (dist_type_ == DistType::Switch) BuildCacheTable();  // the switcher splits hits/misses itself
+}
+
+void Engine::TrainerOnce() {
+  while (pool_->Full()) std::this_thread::sleep_for(std::chrono::microseconds(1));
+  Timer t_recv;
+  size_t mq_key = 0;
+  const char *msg = static_cast<const char *>(mq_->Recv(&mq_key));
+  const double recv_time = t_recv.Passed();
+  Timer t_copy;
+  TransData hdr;
+  memcpy(&hdr, msg, sizeof(hdr));
+  SAM_CHECK(hdr.num_layer >= 0)
+      << "Size of batch topology exceeds memory queue capability. Raise SAMGRAPH_MQ_BYTES";  // task_queue.cc:162
+  SAM_CHECK_LE((size_t)hdr.num_layer, (size_t)FGNN_MAX_LAYERS);
+  const bool use_cache = RC().UseGPUCache();
+  const bool ship_input = !use_cache || RC().have_switcher;
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(msg + sizeof(TransData));
+  auto b = std::make_shared<GraphBatch>();
+  b->key = hdr.key;
+  b->num_layer = hdr.num_layer;
+  b->num_input = hdr.input_size;
+  b->num_output = hdr.output_size;
+  b->device = device_;
+
+  auto to_device = [&](const uint32_t *src, size_t n) -> uint32_t * {
+    uint32_t *d = static_cast<uint32_t *>(dev_pool_.Alloc(n * sizeof(uint32_t)));
+    b->pooled.push_back(d);
+    if (n) SAM_HIP(hipMemcpyAsync(d, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    return d;
+  };
+
+  uint32_t *d_input = nullptr;
+  if (ship_input) {
+    d_input = to_device(p, hdr.input_size);
+    p += hdr.input_size;
+    b->input_nodes = d_input;
+    b->input_device = device_;
+  }
+  uint32_t *d_output = to_device(p, hdr.output_size);
+  p += hdr.output_size;
+  b->output_nodes = d_output;
+  b->output_device = device_;
+
+  const size_t num_miss = hdr.num_miss, num_cache = hdr.input_size - hdr.num_miss;
+  uint32_t *d_cidx[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (use_cache) {
+    if (num_miss) {
+      d_cidx[0] = to_device(p, num_miss); p += num_miss;
+      d_cidx[1] = to_device(p, num_miss); p += num_miss;
+    }
+    if (num_cache) {
+      d_cidx[2] = to_device(p, num_cache); p += num_cache;
+      d_cidx[3] = to_device(p, num_cache); p += num_cache;
+    }
+  }
+  size_t graph_bytes = 0;
+  for (int l = 0; l < hdr.num_layer; ++l) {
+    uint64_t g[3];
+    memcpy(g, p, sizeof(g));  // GraphData header, possibly 4-byte aligned
+    p += sizeof(GraphData) / sizeof(uint32_t);
+    TrainGraphView &v = b->graphs[l];
+    v.num_src = g[0];
+    v.num_dst = g[1];
+    v.num_edge = g[2];
+    v.row = to_device(p, v.num_edge); p += v.num_edge;
+    v.col = to_device(p, v.num_edge); p += v.num_edge;
+    if (hdr.have_data) { v.data = to_device(p, v.num_edge); p += v.num_edge; }
+    graph_bytes += v.num_edge * (hdr.have_data ? 12 : 8);
+  }
+  SAM_CHECK_LE((size_t)((const char *)p - msg), mq_->SlotBytes());
+
+  // features (DoCacheFeatureCopy / DoSwitchCacheFeatureCopy / DoCPUFeatureExtract+DoFeatureCopy)
+  const size_t row_bytes = ds_.feat_dim * 4;
+  void *d_feat = dev_pool_.Alloc(hdr.input_size * row_bytes);
+  b->pooled.push_back(d_feat);
+  b->feat = d_feat;
+  b->feat_rows = hdr.input_size;
+  size_t miss_rows = num_miss;
+  if (!use_cache) {
+    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
+                              ds_.feat_dim, FGNN_F32, stream_));
+    miss_rows = hdr.input_size;
+  } else if (dist_type_ == DistType::Switch) {
+    // own (smaller) cache: split on this GPU with device-side counts
+    const size_t n = hdr.input_size;
+    uint32_t *idx[4];
+    for (auto &q : idx) { q = static_cast<uint32_t *>(dev_pool_.Alloc(n * sizeof(uint32_t))); b->pooled.push_back(q); }
+    const size_t ws_bytes = fgnn_scratch_bytes(n);
+    void *ws = dev_pool_.Alloc(ws_bytes + 16);
+    b->pooled.push_back(ws);
+    uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
+    SAM_FGNN(fgnn_get_miss_cache_index(d_cache_table_, d_input, n, nullptr, n, idx[0], idx[1], idx[2], idx[3], d_counts,
+                                       ws, ws_bytes, stream_));
+    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32, stream_));
+    SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
+                              stream_));
+  } else {
+    if (num_miss)   // CombineMissData with the host fetch fused in
+      SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss, ds_.feat_dim,
+                                FGNN_F32, stream_));
+    if (num_cache)  // CombineCacheData
+      SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, d_cidx[2], d_cidx[3], num_cache, nullptr, num_cache,
+                                ds_.feat_dim, FGNN_F32, stream_));
+  }
+  // labels (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) -- gathered on the GPU from the HBM copy
+  void *d_lab = dev_pool_.Alloc(hdr.output_size * 8);
+  b->pooled.push_back(d_lab);
+  b->label = d_lab;
+  SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
+                            stream_));
+  SAM_HIP(hipStreamSynchronize(stream_));
+  mq_->Release(mq_key);
+  pool_->Submit(b);
+
+  const double copy_time = t_copy.Passed();
+  auto &P = Profiler::Get();
+  P.LogStep(b->key, kLogL1RecvTime, recv_time);
+  P.LogStep(b->key, kLogL1CopyTime, recv_time + copy_time);
+  P.LogStep(b->key, kLogL2CacheCopyTime, copy_time);
+  P.LogStep(b->key, kLogL1FeatureBytes, (double)hdr.input_size * row_bytes);
+  P.LogStep(b->key, kLogL1MissBytes, (double)miss_rows * row_bytes);
+  P.LogStep(b->key, kLogL1LabelBytes, (double)hdr.output_size * 8);
+  P.LogStep(b->key, kLogL1GraphBytes, (double)graph_bytes);
+  P.LogEpochAdd(b->key, kLogEpochCopyTime, recv_time + copy_time);
+  P.LogEpochAdd(b->key, kLogEpochFeatureBytes, (double)hdr.input_size * row_bytes);
+  P.LogEpochAdd(b->key, kLogEpochMissBytes, (double)miss_rows * row_bytes);
+}
+
+void Engine::StartExtract(int count) {
+  SAM_CHECK(initialized_ && (dist_type_ == DistType::Extract || dist_type_ == DistType::Switch));
+  if (extract_thread_.joinable()) extract_thread_.join();
+  extract_thread_ = std::thread([this, count]() {
+    SAM_HIP(hipSetDevice(device_));
+    for (int i = 0; i < count && !shutdown_; ++i) TrainerOnce();
+  });
+}
+
+void Engine::RunSampleOnce() {
+  SAM_CHECK(initialized_);
+  if (RC().run_arch == kArch1) {
+    SampleOnceArch1();
+  } else if (dist_type_ == DistType::Sample) {
+    SampleOnceArch5();
+  } else {
+    TrainerOnce();  // trainer without --pipeline runs one copy iteration inline (dist_loops_arch5.cc:278-285)
+  }
+}
+
+uint64_t Engine::GetNextBatch() {
+  SAM_CHECK(initialized_ && pool_);
+  if (current_) {
+    ReleaseBatch(current_.get());
+    current_.reset();
+  }
+  auto b = pool_->Get();
+  SAM_CHECK(b) << "graph pool stopped";
+  current_ = b;
+  return b->key;
+}
+
+void Engine::Shutdown() {
+  shutdown_ = true;
+  if (pool_) pool_->Stop();
+  if (extract_thread_.joinable()) extract_thread_.join();
+  if (dist_type_ == DistType::Sample) PublishPending();
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (current_) {
+    ReleaseBatch(current_.get());
+    current_.reset();
+  }
+  for (auto &s : slots_) {
+    if (s.fb) fgnn_batch_destroy(s.fb);
+    if (s.e0) (void)hipEventDestroy(s.e0);
+    if (s.e1) (void)hipEventDestroy(s.e1);
+    if (s.e2) (void)hipEventDestroy(s.e2);
+  }
+  slots_.clear();
+  if (sampler_) {
+    fgnn_sampler_destroy(sampler_);
+    sampler_ = nullptr;
+  }
+  shuffler_.reset();
+  initialized_ = false;
+}
+
+}  // namespace sam

@@ -1,0 +1,168 @@
+// eng_engine.h -- the process-wide engine singleton behind the samgraph_* C ABI.
+// Reference: engine.{h,cc} (base), cuda/cuda_engine.cc + cuda/cuda_loops_arch1.cc (arch1),
+// dist/dist_engine.cc + dist/dist_loops.cc + dist/dist_loops_arch5.cc (arch5, FGNN),
+// graph_pool.cc, workspace_pool.cc.
+#pragma once
+#include <pthread.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "eng_config.h"
+#include "eng_dataset.h"
+#include "eng_profiler.h"
+#include "eng_queue.h"
+#include "eng_shuffler.h"
+
+namespace sam {
+
+// size-bucketed device allocator (WorkspacePool, workspace_pool.cc): batches come and go every
+// step, hipMalloc/hipFree must not be on that path
+class DevicePool {
+ public:
+  ~DevicePool();
+  void *Alloc(size_t bytes);
+  void Free(void *p);
+
+ private:
+  std::mutex mu_;
+  std::multimap<size_t, void *> free_;
+  std::map<void *, size_t> live_;
+};
+
+struct TrainGraphView {  // TrainGraph, common.h:186-193
+  const uint32_t *row = nullptr, *col = nullptr, *data = nullptr;
+  size_t num_src = 0, num_dst = 0, num_edge = 0;
+};
+
+struct GraphBatch {      // Task, common.h:205-222 (trainer-side view)
+  uint64_t key = 0;
+  int num_layer = 0;
+  TrainGraphView graphs[FGNN_MAX_LAYERS];
+  const void *feat = nullptr;
+  size_t feat_rows = 0;
+  const void *label = nullptr;
+  const uint32_t *input_nodes = nullptr;   // device (sampler ctx) or host; may be null
+  const uint32_t *output_nodes = nullptr;
+  size_t num_input = 0, num_output = 0;
+  int input_device = -1, output_device = -1, device = -1;  // -1 = host memory
+  // ownership
+  fgnn_batch *fb = nullptr;           // arch1: pooled sampler-side buffers
+  std::vector<void *> pooled;         // arch5 trainer: DevicePool allocations
+  std::vector<void *> host_owned;     // malloc'd host arrays
+};
+
+class GraphPool {        // graph_pool.cc:31-62
+ public:
+  explicit GraphPool(size_t max_size) : max_size_(max_size ? max_size : 1) {}
+  std::shared_ptr<GraphBatch> Get();
+  void Submit(std::shared_ptr<GraphBatch> b);
+  bool Full();
+  void Stop() { stop_ = true; }
+
+ private:
+  std::mutex mu_;
+  std::queue<std::shared_ptr<GraphBatch>> q_;
+  size_t max_size_;
+  std::atomic<bool> stop_{false};
+};
+
+enum class DistType { Default, Sample, Extract, Switch };
+
+class Engine {
+ public:
+  static Engine &Get();
+
+  void Init();  // samgraph_init (arch1) / samgraph_data_init (arch5)
+  void SampleInit(int worker_id, Context ctx);
+  void TrainInit(int worker_id, Context ctx, DistType type);
+  void Start() {}
+  void Shutdown();
+  void RunSampleOnce();
+  void StartExtract(int count);
+  uint64_t GetNextBatch();
+  std::shared_ptr<GraphBatch> Current() { return current_; }
+
+  bool Initialized() const { return initialized_; }
+  size_t NumEpoch() const { return RC().num_epoch; }
+  size_t NumStep() const { return num_step_; }
+  size_t NumLocalStep() const { return shuffler_ ? shuffler_->NumLocalStep() : 0; }
+  uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_step_ + step; }
+  Dataset &Data() { return ds_; }
+  void ForwardBarrier() { outer_counter_++; }
+
+ private:
+  // shared
+  void UploadTopology(int device);
+  void CreateSampler();
+  void ReleaseBatch(GraphBatch *b);
+  // arch1
+  void InitArch1();
+  void SampleOnceArch1();
+  // arch5 sampler
+  void PreSample();
+  void BuildCacheTable();
+  void SampleOnceArch5();
+  void PublishPending();
+  // arch5 trainer
+  void TrainerOnce();
+  void BuildTrainerCache();
+
+  Dataset ds_;
+  bool initialized_ = false, data_initialized_ = false;
+  size_t num_step_ = 0;
+  DistType dist_type_ = DistType::Default;
+  int device_ = -1;
+  hipStream_t stream_ = nullptr;
+
+  // device copies
+  uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
+  float *d_prefix_ = nullptr;
+  void *d_feat_ = nullptr;    // arch1: full table in HBM
+  void *d_label_ = nullptr;
+  uint32_t *d_cache_table_ = nullptr;  // direct-map table u32[num_node]
+  void *d_cache_rows_ = nullptr;       // trainer: cached feature rows
+  void *dev_host_feat_ = nullptr;      // device-visible address of the registered host feature table
+  size_t num_cached_ = 0;
+
+  fgnn_sampler *sampler_ = nullptr;
+  std::unique_ptr<Shuffler> shuffler_;
+  std::unique_ptr<GraphPool> pool_;
+  std::shared_ptr<GraphBatch> current_;
+  DevicePool dev_pool_;
+
+  // sampler-side batch buffers
+  struct Slot {
+    fgnn_batch *fb = nullptr;
+    bool busy = false;           // arch1: handed to the trainer
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    // arch5: message being written
+    bool pending = false;
+    size_t mq_key = 0;
+    uint64_t key = 0;
+    Timer started;
+  };
+  std::vector<Slot> slots_;
+  size_t next_slot_ = 0;
+  int pending_slot_ = -1;
+
+  // arch5 shared state (created before fork)
+  MemoryQueue *mq_ = nullptr;
+  pthread_barrier_t *sampler_barrier_ = nullptr;
+  std::thread extract_thread_;
+  std::atomic<bool> shutdown_{false};
+  std::atomic<size_t> outer_counter_{0};
+  void *dev_mq_base_ = nullptr;  // unused: slots are addressed through hipHostGetDevicePointer per message
+};
+
+// presample.hip
+void PresampleCount(uint32_t *d_freq, const uint32_t *d_nodes, const uint32_t *d_n, size_t cap, hipStream_t st);
+void PresampleRank(const uint32_t *d_freq, size_t num_node, uint32_t *h_rank, hipStream_t st);
+
+}  // namespace sam

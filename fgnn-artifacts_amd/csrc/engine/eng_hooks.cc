@@ -1,0 +1,95 @@
+// eng_hooks.cc -- include/fgnn_engine_hooks.h
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <vector>
+
+#include "eng_config.h"
+#include "eng_queue.h"
+#include "eng_shuffler.h"
+#include "fgnn_engine_hooks.h"
+
+using namespace sam;
+
+extern "C" void fgnn_host_shuffle_minstd0(uint32_t *data, size_t n, uint64_t seed) { ShuffleMinstd0(data, n, seed); }
+
+extern "C" void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_layers, int have_data,
+                                     size_t out[3]) {
+  out[0] = sizeof(TransData);
+  out[1] = sizeof(GraphData);
+  out[2] = MaxMessageBytes(batch_size, fanout, num_layers, have_data != 0);
+}
+
+static uint64_t Mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+extern "C" int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t messages, int producers,
+                                        int consumers) {
+  if (producers < 1 || consumers < 1 || slot_bytes < 64) return 2;
+  MemoryQueue mq(slot_bytes, slots);
+  // shared result area: seen[m] incremented by whoever receives message id m
+  auto *seen = static_cast<uint32_t *>(mmap(nullptr, (messages + 1) * sizeof(uint32_t), PROT_READ | PROT_WRITE,
+                                            MAP_SHARED | MAP_ANONYMOUS, -1, 0));
+  if (seen == MAP_FAILED) return 2;
+  std::vector<pid_t> kids;
+  for (int p = 0; p < producers; ++p) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      for (size_t m = (size_t)p; m < messages; m += (size_t)producers) {
+        size_t key;
+        auto *w = static_cast<uint64_t *>(mq.GetPtr(&key));
+        const size_t words = 2 + (Mix(m) % ((mq.SlotBytes() / 8) - 2));
+        w[0] = m;
+        w[1] = words;
+        for (size_t i = 2; i < words; ++i) w[i] = Mix(m * 1315423911ull + i);
+        mq.SimpleSend(key);
+      }
+      _exit(0);
+    }
+    kids.push_back(pid);
+  }
+  for (int c = 0; c < consumers; ++c) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      // consumer c takes ceil/floor share like the trainers do (train_graphsage.py:293-298)
+      size_t mine = messages / (size_t)consumers + ((size_t)c < messages % (size_t)consumers ? 1 : 0);
+      for (size_t k = 0; k < mine; ++k) {
+        size_t key;
+        auto *w = static_cast<const uint64_t *>(mq.Recv(&key));
+        const size_t m = w[0], words = w[1];
+        bool ok = m < messages && words >= 2 && words <= mq.SlotBytes() / 8;
+        for (size_t i = 2; ok && i < words; ++i) ok = w[i] == Mix(m * 1315423911ull + i);
+        if (ok) __sync_fetch_and_add(&seen[m], 1u);
+        else __sync_fetch_and_add(&seen[messages], 1u);
+        mq.Release(key);
+      }
+      _exit(0);
+    }
+    kids.push_back(pid);
+  }
+  int bad = 0;
+  for (pid_t pid : kids) {
+    int st = 0;
+    waitpid(pid, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  if (seen[messages] != 0) bad = 1;
+  for (size_t m = 0; m < messages; ++m)
+    if (seen[m] != 1) bad = 1;
+  munmap(seen, (messages + 1) * sizeof(uint32_t));
+  return bad;
+}
+
+extern "C" int fgnn_host_config_probe(const char **keys, const char **vals, size_t n, size_t out[4]) {
+  RunConfig rc;
+  rc.Parse(keys, vals, n);
+  out[0] = rc.fanout.size();
+  out[1] = rc.fanout[0];
+  out[2] = (size_t)rc.run_arch;
+  out[3] = rc.UseGPUCache() ? 1 : 0;
+  return 0;
+}

@@ -1,0 +1,191 @@
+// eng_operation.cc -- the samgraph_* C ABI (include/samgraph.h; reference operation.{h,cc},
+// torch/adapter.{h,cc}).
+#include <signal.h>
+#include <sys/wait.h>
+
+#include "eng_engine.h"
+#include "samgraph.h"
+
+using namespace sam;
+
+namespace {
+std::shared_ptr<GraphBatch> CurrentChecked(uint64_t key) {
+  auto b = Engine::Get().Current();
+  SAM_CHECK(b) << "no current batch: call samgraph_get_next_batch first";
+  SAM_CHECK_EQ(b->key, key);  // adapter.cc:52
+  return b;
+}
+}  // namespace
+
+extern "C" {
+
+void samgraph_config(const char **config_keys, const char **config_values, const size_t num_config_items) {
+  RC().Parse(config_keys, config_values, num_config_items);
+}
+
+void samgraph_init(void) {
+  SAM_CHECK(RC().is_configured);
+  SAM_CHECK_EQ(RC().run_arch, (int)kArch1) << "samgraph_init is the single-process entry (arch1) ";
+  Engine::Get().Init();
+}
+
+void samgraph_start(void) { Engine::Get().Start(); }
+void samgraph_shutdown(void) { Engine::Get().Shutdown(); }
+
+size_t samgraph_num_epoch(void) { return Engine::Get().NumEpoch(); }
+size_t samgraph_steps_per_epoch(void) { return Engine::Get().NumStep(); }
+size_t samgraph_num_class(void) { return Engine::Get().Data().num_class; }
+size_t samgraph_feat_dim(void) { return Engine::Get().Data().feat_dim; }
+
+uint64_t samgraph_get_next_batch(void) { return Engine::Get().GetNextBatch(); }
+void samgraph_sample_once(void) { Engine::Get().RunSampleOnce(); }
+
+size_t samgraph_get_graph_num_src(uint64_t key, int graph_id) { return CurrentChecked(key)->graphs[graph_id].num_src; }
+size_t samgraph_get_graph_num_dst(uint64_t key, int graph_id) { return CurrentChecked(key)->graphs[graph_id].num_dst; }
+size_t samgraph_get_graph_num_edge(uint64_t key, int graph_id) {
+  return CurrentChecked(key)->graphs[graph_id].num_edge;
+}
+
+void samgraph_log_step(uint64_t epoch, uint64_t step, int item, double val) {
+  SAM_CHECK_LT(item, kNumLogStepItems);
+  Profiler::Get().LogStep(Engine::Get().BatchKey(epoch, step), item, val);
+}
+void samgraph_log_step_add(uint64_t epoch, uint64_t step, int item, double val) {
+  SAM_CHECK_LT(item, kNumLogStepItems);
+  Profiler::Get().LogStepAdd(Engine::Get().BatchKey(epoch, step), item, val);
+}
+void samgraph_log_epoch_add(uint64_t epoch, int item, double val) {
+  SAM_CHECK_LT(item, kNumLogEpochItems);
+  Profiler::Get().LogEpochAdd(Engine::Get().BatchKey(epoch, 0), item, val);
+}
+double samgraph_get_log_init_value(int item) {
+  SAM_CHECK_LT(item, kNumLogInitItems);
+  return Profiler::Get().GetLogInitValue(item);
+}
+double samgraph_get_log_step_value(uint64_t epoch, uint64_t step, int item) {
+  SAM_CHECK_LT(item, kNumLogStepItems);
+  return Profiler::Get().GetLogStepValue(Engine::Get().BatchKey(epoch, step), item);
+}
+double samgraph_get_log_epoch_value(uint64_t epoch, int item) {
+  SAM_CHECK_LT(item, kNumLogEpochItems);
+  return Profiler::Get().GetLogEpochValue(epoch, item);
+}
+
+void samgraph_report_init(void) { Profiler::Get().ReportInit(); }
+void samgraph_report_step(uint64_t epoch, uint64_t step) { Profiler::Get().ReportStep(epoch, step); }
+void samgraph_report_step_average(uint64_t epoch, uint64_t step) { Profiler::Get().ReportStepAverage(epoch, step); }
+void samgraph_report_epoch(uint64_t epoch) { Profiler::Get().ReportEpoch(epoch); }
+void samgraph_report_epoch_average(uint64_t epoch) { Profiler::Get().ReportEpochAverage(epoch); }
+void samgraph_report_node_access(void) {}  // SAMGRAPH_LOG_NODE_ACCESS analysis is an offline study (profiler.cc:568-866)
+
+void samgraph_trace_step_begin(uint64_t key, int item, uint64_t ts) { Profiler::Get().TraceStep(key, item, ts, true); }
+void samgraph_trace_step_end(uint64_t key, int item, uint64_t ts) { Profiler::Get().TraceStep(key, item, ts, false); }
+void samgraph_trace_step_begin_now(uint64_t key, int item) {
+  Profiler::Get().TraceStep(key, item, Timer::NowMicro(), true);
+}
+void samgraph_trace_step_end_now(uint64_t key, int item) {
+  Profiler::Get().TraceStep(key, item, Timer::NowMicro(), false);
+}
+void samgraph_dump_trace(void) { Profiler::Get().DumpTrace(); }
+
+void samgraph_forward_barrier(void) { Engine::Get().ForwardBarrier(); }
+
+void samgraph_data_init(void) {
+  SAM_CHECK(RC().is_configured);
+  SAM_CHECK_EQ(RC().run_arch, (int)kArch5) << "samgraph_data_init is the multi-process entry (arch5) ";
+  Engine::Get().Init();
+}
+void samgraph_sample_init(int worker_id, const char *ctx) {
+  SAM_CHECK(RC().is_configured);
+  Engine::Get().SampleInit(worker_id, Context(std::string(ctx)));
+}
+void samgraph_train_init(int worker_id, const char *ctx) {
+  SAM_CHECK(RC().is_configured);
+  Engine::Get().TrainInit(worker_id, Context(std::string(ctx)), DistType::Extract);
+}
+void samgraph_extract_start(int count) { Engine::Get().StartExtract(count); }
+void samgraph_switch_init(int worker_id, const char *ctx, double cache_percentage) {
+  RC().cache_percentage = cache_percentage;  // operation.cc:363
+  SAM_CHECK(RC().is_configured);
+  Engine::Get().TrainInit(worker_id, Context(std::string(ctx)), DistType::Switch);
+}
+size_t samgraph_num_local_step(void) { return Engine::Get().NumLocalStep(); }
+
+int samgraph_wait_one_child(void) {  // operation.cc:374-385
+  int child_stat = 0;
+  pid_t pid = waitpid(-1, &child_stat, 0);
+  if (WEXITSTATUS(child_stat) != 0) {
+    SAM_LOG(kError) << "detect a terminated child " << pid << ", status is " << WEXITSTATUS(child_stat);
+    return 1;
+  } else if (WIFSIGNALED(child_stat) && (WTERMSIG(child_stat) == SIGABRT)) {
+    SAM_LOG(kError) << "detect an aborted child " << pid;
+    return 1;
+  }
+  return 0;
+}
+
+// ---- tensor getters (adapter.cc:48-192) ------------------------------------------------------------
+
+const void *samgraph_torch_get_graph_feat_ptr(uint64_t key, size_t *num_rows, size_t *dim, int *dtype, int *device) {
+  auto b = CurrentChecked(key);
+  *num_rows = b->feat_rows;
+  *dim = Engine::Get().Data().feat_dim;
+  *dtype = FGNN_F32;
+  *device = b->device;
+  return b->feat;
+}
+const void *samgraph_torch_get_graph_label_ptr(uint64_t key, size_t *num, int *dtype, int *device) {
+  auto b = CurrentChecked(key);
+  *num = b->num_output;
+  *dtype = FGNN_I64;
+  *device = b->device;
+  return b->label;
+}
+const uint32_t *samgraph_torch_get_graph_row_ptr(uint64_t key, int layer, size_t *num, int *device) {
+  auto b = CurrentChecked(key);
+  SAM_CHECK(layer >= 0 && layer < b->num_layer);
+  *num = b->graphs[layer].num_edge;
+  *device = b->device;
+  return b->graphs[layer].row;
+}
+const uint32_t *samgraph_torch_get_graph_col_ptr(uint64_t key, int layer, size_t *num, int *device) {
+  auto b = CurrentChecked(key);
+  SAM_CHECK(layer >= 0 && layer < b->num_layer);
+  *num = b->graphs[layer].num_edge;
+  *device = b->device;
+  return b->graphs[layer].col;
+}
+const uint32_t *samgraph_torch_get_graph_data_ptr(uint64_t key, int layer, size_t *num, int *device) {
+  auto b = CurrentChecked(key);
+  SAM_CHECK(layer >= 0 && layer < b->num_layer);
+  *num = b->graphs[layer].data ? b->graphs[layer].num_edge : 0;
+  *device = b->device;
+  return b->graphs[layer].data;
+}
+const uint32_t *samgraph_torch_get_graph_input_nodes_ptr(uint64_t key, size_t *num, int *device) {
+  auto b = CurrentChecked(key);
+  *num = b->input_nodes ? b->num_input : 0;
+  *device = b->input_device;
+  return b->input_nodes;
+}
+const uint32_t *samgraph_torch_get_graph_output_nodes_ptr(uint64_t key, size_t *num, int *device) {
+  auto b = CurrentChecked(key);
+  *num = b->num_output;
+  *device = b->output_device;
+  return b->output_nodes;
+}
+const void *samgraph_torch_get_dataset_feat_ptr(size_t *num_rows, size_t *dim, int *dtype) {
+  auto &d = Engine::Get().Data();
+  *num_rows = d.feat_rows;
+  *dim = d.feat_dim;
+  *dtype = FGNN_F32;
+  return d.feat.ptr;
+}
+const void *samgraph_torch_get_dataset_label_ptr(size_t *num, int *dtype) {
+  auto &d = Engine::Get().Data();
+  *num = d.num_node;
+  *dtype = FGNN_I64;
+  return d.label.ptr;
+}
+
+}  // extern "C"

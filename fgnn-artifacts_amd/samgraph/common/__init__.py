@@ -93,3 +93,83 @@ _enum(["kL0Event_Train_Step", "kL1Event_Sample", "kL2Event_Sample_Shuffle", "kL2
        "kL3Event_Copy_CacheCopy_CopyIndex", "kL3Event_Copy_CacheCopy_ExtractMiss", "kL3Event_Copy_CacheCopy_CopyMiss",
        "kL3Event_Copy_CacheCopy_CombineMiss", "kL3Event_Copy_CacheCopy_CombineCache", "kL1Event_Convert",
        "kL1Event_Train"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# ctypes binding of the samgraph_* C ABI (reference common/__init__.py:268-500; include/samgraph.h)
+
+def _get_ext_suffix():
+    import sysconfig
+    return sysconfig.get_config_var('EXT_SUFFIX') or sysconfig.get_config_var('SO') or '.so'
+
+
+def _get_extension_full_path(pkg_path, *args):
+    """<dir of pkg_path>/<args...>.so -- the reference appends the CPython EXT_SUFFIX
+    (common/__init__.py:31-36); this build's engine is a plain shared library, so `.so` is tried first."""
+    assert len(args) >= 1
+    dir_path = os.path.join(os.path.dirname(pkg_path), *args[:-1])
+    plain = os.path.join(dir_path, args[-1] + '.so')
+    if os.path.exists(plain):
+        return plain
+    return os.path.join(dir_path, args[-1] + _get_ext_suffix())
+
+
+_u64, _int, _dbl, _sz, _cstr = ctypes.c_uint64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_char_p
+
+# name -> (restype, argtypes); argtypes/restypes as the reference declares them (common/__init__.py:273-341)
+_SIGNATURES = {
+    'samgraph_config': (None, (ctypes.POINTER(_cstr), ctypes.POINTER(_cstr), _sz)),
+    'samgraph_init': (None, ()), 'samgraph_start': (None, ()), 'samgraph_shutdown': (None, ()),
+    'samgraph_num_epoch': (_sz, ()), 'samgraph_steps_per_epoch': (_sz, ()), 'samgraph_num_class': (_sz, ()),
+    'samgraph_feat_dim': (_sz, ()), 'samgraph_get_next_batch': (_u64, ()), 'samgraph_sample_once': (None, ()),
+    'samgraph_get_graph_num_src': (_sz, (_u64, _int)), 'samgraph_get_graph_num_dst': (_sz, (_u64, _int)),
+    'samgraph_get_graph_num_edge': (_sz, (_u64, _int)),
+    'samgraph_log_step': (None, (_u64, _u64, _int, _dbl)), 'samgraph_log_step_add': (None, (_u64, _u64, _int, _dbl)),
+    'samgraph_log_epoch_add': (None, (_u64, _int, _dbl)), 'samgraph_get_log_init_value': (_dbl, (_int,)),
+    'samgraph_get_log_step_value': (_dbl, (_u64, _u64, _int)), 'samgraph_get_log_epoch_value': (_dbl, (_u64, _int)),
+    'samgraph_report_init': (None, ()), 'samgraph_report_step': (None, (_u64, _u64)),
+    'samgraph_report_step_average': (None, (_u64, _u64)), 'samgraph_report_epoch': (None, (_u64,)),
+    'samgraph_report_epoch_average': (None, (_u64,)), 'samgraph_report_node_access': (None, ()),
+    'samgraph_trace_step_begin': (None, (_u64, _int, _u64)), 'samgraph_trace_step_end': (None, (_u64, _int, _u64)),
+    'samgraph_trace_step_begin_now': (None, (_u64, _int)), 'samgraph_trace_step_end_now': (None, (_u64, _int)),
+    'samgraph_dump_trace': (None, ()), 'samgraph_forward_barrier': (None, ()), 'samgraph_data_init': (None, ()),
+    'samgraph_sample_init': (None, (_int, _cstr)), 'samgraph_train_init': (None, (_int, _cstr)),
+    'samgraph_extract_start': (None, (_int,)), 'samgraph_switch_init': (None, (_int, _cstr, _dbl)),
+    'samgraph_num_local_step': (_sz, ()), 'samgraph_wait_one_child': (_int, ()),
+}
+
+
+class SamGraphBasics(object):
+    """Same method surface as the reference class (common/__init__.py:268-500)."""
+
+    def __init__(self, pkg_path, *args):
+        full_path = _get_extension_full_path(pkg_path, *args)
+        if not os.path.exists(full_path):
+            raise ImportError(full_path + " is missing: build it with `python __graft_entry__.py build` "
+                              "(the engine has no Python or CPU fallback)")
+        self.C_LIB_CTYPES = ctypes.CDLL(full_path, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, argt) in _SIGNATURES.items():
+            fn = getattr(self.C_LIB_CTYPES, name)
+            fn.restype = res
+            fn.argtypes = argt
+        # every samgraph_X becomes method X, except the ones with marshalling below
+        for name in _SIGNATURES:
+            short = name[len('samgraph_'):]
+            if not hasattr(self, short):
+                setattr(self, short, getattr(self.C_LIB_CTYPES, name))
+
+    def config(self, run_config: dict):
+        keys = [str.encode(str(k)) for k in run_config.keys()]
+        vals = [str.encode(' '.join(str(x) for x in v) if isinstance(v, list) else str(v))
+                for v in run_config.values()]
+        n = len(keys)
+        return self.C_LIB_CTYPES.samgraph_config((_cstr * n)(*keys), (_cstr * n)(*vals), n)
+
+    def sample_init(self, worker_id, ctx):
+        return self.C_LIB_CTYPES.samgraph_sample_init(worker_id, str.encode(ctx))
+
+    def train_init(self, worker_id, ctx):
+        return self.C_LIB_CTYPES.samgraph_train_init(worker_id, str.encode(ctx))
+
+    def switch_init(self, worker_id, ctx, cache_percentage):
+        return self.C_LIB_CTYPES.samgraph_switch_init(worker_id, str.encode(ctx), cache_percentage)

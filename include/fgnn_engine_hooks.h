@@ -1,0 +1,37 @@
+/*
+ * fgnn_engine_hooks.h -- host-only entry points of the engine library (c_lib.so) that let the CPU
+ * test-suite exercise the engine's host logic without a GPU.  They run exactly the code the
+ * samgraph_* path runs; nothing here is needed by an application.
+ */
+#ifndef FGNN_ENGINE_HOOKS_H
+#define FGNN_ENGINE_HOOKS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the shufflers' per-epoch Fisher-Yates (dist/dist_shuffler.cc:108-131), in place */
+void fgnn_host_shuffle_minstd0(uint32_t *data, size_t n, uint64_t seed);
+
+/* sizes the wire format was compiled with: out[0] = sizeof(TransData) (40), out[1] = sizeof(GraphData) (24),
+ * out[2] = worst-case message bytes for (batch_size, fanout[num_layers], have_data) (task_queue.cc:349-371) */
+void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_layers, int have_data, size_t out[3]);
+
+/* Multi-process self-test of the shared-memory hand-off ring (memory_queue.cc): forks `producers`
+ * writer processes and `consumers` reader processes over a ring of `slots` slots of `slot_bytes`,
+ * sends `messages` checksummed messages in total and verifies that every one arrives exactly once and
+ * intact.  Returns 0 on success. */
+int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t messages, int producers, int consumers);
+
+/* Parses a config through the same code as samgraph_config and returns 0; on an invalid config the
+ * process aborts like the reference.  Writes steps-per-epoch style derived values for inspection:
+ * out[0] = #layers, out[1] = fanout[0], out[2] = run_arch, out[3] = UseGPUCache. */
+int fgnn_host_config_probe(const char **keys, const char **vals, size_t n, size_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Drives the engine through the reference's Python API (import samgraph.torch as sam) exactly like
+example/samgraph/train_graphsage.py (arch1) and example/samgraph/multi_gpu/train_graphsage.py (arch5) do,
+and checks every batch bit-for-bit against the oracle.  Run as a subprocess by tests/test_engine_gpu.py
+(the engine is a process-wide singleton, like the reference's).
+
+usage: engine_runner.py <arch1|arch5> <sample_type> <workdir> [num_sampler] [num_trainer] [cache_pct]
+"""
+import multiprocessing as mp
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+SEED = 0x5A4D47
+NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, 2000
+BATCH, NUM_EPOCH = 256, 2
+
+
+def dataset(workdir, sample_type):
+    from fgnn_hip import synth
+    return synth.write_dataset(workdir, "synth", NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN, 100, 100, seed=17,
+                               with_prefix=(sample_type == "weighted_khop_prefix"))
+
+
+def base_config(path, arch, sample_type):
+    import samgraph.common as sc
+    cfg = dict(dataset_path=path, _arch=arch, _sample_type=sc.sample_types[sample_type], batch_size=BATCH,
+               num_epoch=NUM_EPOCH, _cache_policy=sc.kCacheByPreSample, cache_percentage=0.0, max_sampling_jobs=10,
+               max_copying_jobs=2, omp_thread_num=8, seed=SEED, presample_epoch=1, barriered_epoch=0)
+    if sample_type == "random_walk":
+        cfg.update(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4, num_neighbor=5, num_layer=3)
+    else:
+        fan = [5, 3] if sample_type != "weighted_khop_prefix" else [3, 4, 2]
+        cfg.update(num_fanout=len(fan), fanout=fan)
+    return cfg
+
+
+class OracleReplay:
+    """Replays what sampler `worker` of `num_sampler` does, batch by batch, with the oracle."""
+
+    def __init__(self, path, sample_type, worker=0, num_sampler=1, presample=False):
+        import oracle_py as oracle
+        self.o = oracle
+        self.indptr = np.fromfile(os.path.join(path, "indptr.bin"), dtype=np.uint32)
+        self.indices = np.fromfile(os.path.join(path, "indices.bin"), dtype=np.uint32)
+        self.feat = np.fromfile(os.path.join(path, "feat.bin"), dtype=np.float32).reshape(NUM_NODE, DIM)
+        self.label = np.fromfile(os.path.join(path, "label.bin"), dtype=np.int64)
+        self.train0 = np.fromfile(os.path.join(path, "train_set.bin"), dtype=np.uint32)
+        self.prefix = (np.fromfile(os.path.join(path, "prob_prefix_table.bin"), dtype=np.float32)
+                       if sample_type == "weighted_khop_prefix" else None)
+        self.st = dict(khop0=oracle.KHOP0, khop2=oracle.KHOP2, weighted_khop_prefix=oracle.WEIGHTED_KHOP_PREFIX,
+                       random_walk=oracle.RANDOM_WALK)[sample_type]
+        self.kw = {}
+        if sample_type == "random_walk":
+            self.fan = [5, 5, 5]
+            self.kw = dict(walk_len=3, num_walks=4, num_neighbor=5, restart_prob=0.5)
+        elif sample_type == "weighted_khop_prefix":
+            self.fan = [3, 4, 2]
+            self.kw = dict(prob_prefix=self.prefix)
+        else:
+            self.fan = [5, 3]
+        self.rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+        self.ht = oracle.HashTable(NUM_NODE, oracle.predict_num_nodes(BATCH, self.fan))
+        self.num_step = (NUM_TRAIN + BATCH - 1) // BATCH
+        self.part = oracle.dist_shuffler_partition(NUM_TRAIN, BATCH, worker, num_sampler)
+        self.rank = None
+        if presample and worker == 0:
+            self._presample()
+
+    def _sample(self, seeds, key):
+        return self.o.do_sample(self.indptr, self.indices, seeds, self.fan, self.st, self.rng, key, self.ht, **self.kw)
+
+    def _presample(self):
+        data = self.train0.copy()
+        freq = np.zeros(NUM_NODE, dtype=np.uint32)
+        data = self.o.shuffle_minstd0(data, 0)
+        for step in range(self.num_step):
+            seeds = data[step * BATCH:(step + 1) * BATCH]
+            t = self._sample(seeds, (1 << 63) | step)
+            np.add.at(freq, t["input_nodes"], 1)
+        self.rank = self.o.presample_rank(freq)
+
+    def epochs(self):
+        """yields (key, seeds, task) for this sampler's batches in order"""
+        data = self.train0.copy()
+        for epoch in range(NUM_EPOCH):
+            data = self.o.shuffle_minstd0(data, epoch)
+            first = self.part["dataset_offset"] // BATCH
+            for ls in range(self.part["num_local_step"]):
+                step = first + ls
+                seeds = data[step * BATCH:min(NUM_TRAIN, (step + 1) * BATCH)]
+                key = epoch * self.num_step + step
+                yield key, seeds, self._sample(seeds, key)
+
+
+def check_batch(sam, key, seeds, task, rep, what=""):
+    import torch  # noqa: F401
+    nl = len(task["graphs"])
+    blocks, feat, label = (sam.get_dgl_blocks_with_weights if rep.st == rep.o.RANDOM_WALK else sam.get_dgl_blocks)(
+        key, nl)
+
+    def u32(t):
+        return t.cpu().numpy().view(np.uint32)
+
+    for li in range(nl):
+        g = task["graphs"][li]
+        assert sam.get_graph_num_src(key, li) == g["num_src"], what
+        assert sam.get_graph_num_dst(key, li) == g["num_dst"], what
+        assert sam.get_graph_num_edge(key, li) == g["num_edge"], what
+        np.testing.assert_array_equal(u32(blocks[li].row), g["row"], err_msg=what)
+        np.testing.assert_array_equal(u32(blocks[li].col), g["col"], err_msg=what)
+        if g["data"] is not None:
+            np.testing.assert_array_equal(u32(blocks[li].edata["weights"]), g["data"], err_msg=what)
+    assert feat.cpu().numpy().tobytes() == rep.feat[task["input_nodes"]].tobytes(), what + " feat"
+    np.testing.assert_array_equal(label.cpu().numpy(), rep.label[seeds], err_msg=what)
+    np.testing.assert_array_equal(u32(sam.get_graph_output_nodes(key)), seeds, err_msg=what)
+    inp = sam.get_graph_input_nodes(key)
+    if inp.numel():
+        np.testing.assert_array_equal(u32(inp), task["input_nodes"], err_msg=what)
+
+
+def run_arch1(sample_type, workdir):
+    path = dataset(workdir, sample_type)
+    import samgraph.torch as sam
+    cfg = base_config(path, sam.kArch1, sample_type)
+    cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0")
+    sam.config(cfg)
+    sam.init()
+    assert sam.num_class() == NUM_CLASS and sam.feat_dim() == DIM and sam.num_epoch() == NUM_EPOCH
+    rep = OracleReplay(path, sample_type)
+    assert sam.steps_per_epoch() == rep.num_step
+    n = 0
+    for key, seeds, task in rep.epochs():
+        sam.sample_once()
+        got = sam.get_next_batch()
+        assert got == key, (got, key)
+        check_batch(sam, key, seeds, task, rep, "arch1 key %d" % key)
+        epoch, step = key // rep.num_step, key % rep.num_step
+        assert sam.get_log_step_value(epoch, step, sam.kLogL1NumSample) == task["total_edges"]
+        assert sam.get_log_step_value(epoch, step, sam.kLogL1NumNode) == len(task["input_nodes"])
+        n += 1
+    assert n == NUM_EPOCH * rep.num_step
+    sam.report_step_average(NUM_EPOCH - 1, rep.num_step - 1)
+    sam.shutdown()
+    print("arch1 %s ok: %d batches" % (sample_type, n))
+
+
+def _sampler_proc(worker, num_sampler, barrier, err):
+    try:
+        import samgraph.torch as sam
+        sam.sample_init(worker, "cuda:0")
+        barrier.wait()
+        num_step = sam.steps_per_epoch()
+        local = num_step - (num_step // num_sampler) * worker if worker == num_sampler - 1 else num_step // num_sampler
+        assert sam.num_local_step() == local
+        for _ in range(NUM_EPOCH):
+            for _ in range(local):
+                sam.sample_once()
+        sam.shutdown()
+    except BaseException:
+        traceback.print_exc()
+        err.value = 1
+        os._exit(1)
+
+
+def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample, pipeline, barrier, err):
+    try:
+        import samgraph.torch as sam
+        barrier.wait()  # samplers (and the presample) are done initialising
+        sam.train_init(worker, "cuda:0")
+        # expected batches of every sampler, by key
+        expected = {}
+        rank = None
+        for w in range(num_sampler):
+            rep = OracleReplay(path, sample_type, w, num_sampler, presample)
+            if w == 0:
+                rank = rep.rank
+            for key, seeds, task in rep.epochs():
+                expected[key] = (seeds, task, rep)
+        total = len(expected)
+        mine = total // num_trainer + (1 if worker < total % num_trainer else 0)
+        if pipeline:
+            sam.extract_start(mine)
+        seen = 0
+        for _ in range(mine):
+            if not pipeline:
+                sam.sample_once()
+            key = sam.get_next_batch()
+            seeds, task, rep = expected.pop(key)
+            check_batch(sam, key, seeds, task, rep, "arch5 key %d" % key)
+            seen += 1
+        if num_trainer == 1:
+            assert not expected
+        sam.shutdown()
+        print("trainer %d checked %d batches (presample rank head %s)" % (worker, seen,
+                                                                        None if rank is None else rank[:4]))
+    except BaseException:
+        traceback.print_exc()
+        err.value = 1
+        os._exit(1)
+
+
+def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipeline=True):
+    path = dataset(workdir, sample_type)
+    import samgraph.torch as sam
+    cfg = base_config(path, sam.kArch5, sample_type)
+    cfg.update(num_sample_worker=num_sampler, num_train_worker=num_trainer, cache_percentage=cache_pct)
+    sam.config(cfg)
+    sam.data_init()  # before fork, no GPU touched
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(num_sampler + num_trainer)
+    err = ctx.Value("i", 0)
+    procs = [ctx.Process(target=_sampler_proc, args=(w, num_sampler, barrier, err)) for w in range(num_sampler)]
+    procs += [ctx.Process(target=_trainer_proc,
+                          args=(w, num_trainer, num_sampler, path, sample_type, cache_pct > 0, pipeline, barrier, err))
+              for w in range(num_trainer)]
+    for p in procs:
+        p.start()
+    bad = 0
+    for p in procs:
+        p.join(timeout=300)
+        if p.is_alive():
+            p.terminate()
+            bad = 1
+        elif p.exitcode != 0:
+            bad = 1
+    if bad or err.value:
+        sys.exit(1)
+    print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
+
+
+if __name__ == "__main__":
+    mode, st, wd = sys.argv[1:4]
+    if mode == "arch1":
+        run_arch1(st, wd)
+    else:
+        run_arch5(st, wd, int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]),
+                  pipeline=(len(sys.argv) < 8 or sys.argv[7] == "pipeline"))

@@ -1,0 +1,36 @@
+"""End-to-end through the drop-in boundary on a real GPU: `import samgraph.torch as sam` -> samgraph_* C ABI ->
+HIP kernels, every batch compared bit-for-bit with the oracle (tests/engine_runner.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner.py")
+
+
+def _run(tmp_path, *args):
+    p = subprocess.run([sys.executable, RUNNER, args[0], args[1], str(tmp_path)] + [str(a) for a in args[2:]],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("sample_type", ["khop2", "khop0", "weighted_khop_prefix", "random_walk"])
+def test_arch1_single_gpu(tmp_path, sample_type):
+    """BASELINE config 2 in miniature: one GPU samples and extracts (cuda_loops_arch1.cc:44-80)."""
+    assert "ok" in _run(tmp_path, "arch1", sample_type)
+
+
+@pytest.mark.parametrize("sample_type,ns,nt,cache,mode", [
+    ("khop2", 1, 1, 0.25, "pipeline"),       # BASELINE config 3 in miniature: 1S + 1T, presample cache
+    ("khop2", 1, 1, 0.0, "inline"),          # no cache: input nodes shipped, all rows fetched from host memory
+    ("khop2", 2, 1, 0.25, "pipeline"),       # two samplers with disjoint step ranges, one trainer
+    ("weighted_khop_prefix", 1, 2, 0.3, "pipeline"),  # config 4 in miniature
+    ("random_walk", 2, 2, 0.2, "inline"),    # config 5 in miniature (edge data shipped)
+])
+def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
+    """FGNN: sampler processes -> shared pinned queue -> trainer processes, all on cuda:0
+    (dist_loops_arch5.cc; the reference's --single-gpu topology, common_config.py:186-191)."""
+    assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)

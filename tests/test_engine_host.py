@@ -1,0 +1,117 @@
+"""CPU-only tests of the engine library (samgraph/torch/c_lib.so): exported ABI, config parsing and its
+abort-on-error behaviour, the shuffler's exact permutation, the wire-format sizes, and the multi-process
+hand-off ring (the N>1 path of the sampler->trainer pipeline has no collective: it is this queue)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENG = os.path.join(ROOT, "fgnn-artifacts_amd", "samgraph", "torch", "c_lib.so")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not os.path.exists(ENG):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fgnn-artifacts_amd", "csrc")])
+    return C.CDLL(ENG)
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:fgnn|samgraph)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_engine_exports_reference_abi(eng):
+    names = _declared("samgraph.h")
+    # the 38 functions the reference defines (operation.cc) + the 9 tensor getters (adapter.h:29-42)
+    assert len([n for n in names if not n.startswith("samgraph_torch_")]) == 38
+    assert len([n for n in names if n.startswith("samgraph_torch_")]) == 9
+    missing = [n for n in names + _declared("fgnn_engine_hooks.h") if not hasattr(eng, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_abi():
+    import samgraph.common as sc
+    want = {n for n in _declared("samgraph.h") if not n.startswith("samgraph_torch_")}
+    assert set(sc._SIGNATURES) == want
+
+
+def _cfg(**over):
+    cfg = dict(dataset_path="/nonexistent", _arch=5, _sample_type=5, batch_size=8000, num_epoch=3, _cache_policy=2,
+               cache_percentage=0.2, max_sampling_jobs=10, max_copying_jobs=10, omp_thread_num=40,
+               num_sample_worker=2, num_train_worker=6, num_fanout=2, fanout="25 10", unknown_key="ignored")
+    cfg.update(over)
+    return cfg
+
+
+def _probe(eng, cfg):
+    keys = [str(k).encode() for k in cfg]
+    vals = [str(v).encode() for v in cfg.values()]
+    out = (C.c_size_t * 4)()
+    rc = eng.fgnn_host_config_probe((C.c_char_p * len(keys))(*keys), (C.c_char_p * len(vals))(*vals),
+                                    C.c_size_t(len(keys)), out)
+    return rc, list(out)
+
+
+def test_config_parse(eng):
+    rc, out = _probe(eng, _cfg())
+    assert rc == 0 and out == [2, 25, 5, 1]
+    rc, out = _probe(eng, _cfg(_arch=1, sampler_ctx="cuda:0", trainer_ctx="cuda:0"))
+    assert out == [2, 25, 1, 0]  # arch1 never uses the cache (run_config.h:84-86)
+    rw = _cfg(_sample_type=3, random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4, num_neighbor=5,
+              num_layer=3)
+    del rw["fanout"], rw["num_fanout"]
+    assert _probe(eng, rw)[1][:2] == [3, 5]
+
+
+@pytest.mark.parametrize("bad", [dict(drop="batch_size"), dict(_arch=6), dict(_sample_type=1), dict(drop="fanout"),
+                                 dict(_arch=1)])
+def test_config_errors_abort(bad):
+    """No return codes: a violated check prints file:line and abort()s (logging.h:32-45)."""
+    cfg = _cfg()
+    if "drop" in bad:
+        del cfg[bad.pop("drop")]
+    cfg.update(bad)
+    code = ("import ctypes as C\nL=C.CDLL(%r)\ncfg=%r\nk=[str(x).encode() for x in cfg]\n"
+            "v=[str(x).encode() for x in cfg.values()]\no=(C.c_size_t*4)()\n"
+            "L.fgnn_host_config_probe((C.c_char_p*len(k))(*k),(C.c_char_p*len(v))(*v),C.c_size_t(len(k)),o)\n"
+            % (ENG, cfg))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True)
+    assert p.returncode == -6, p.stderr  # SIGABRT
+    assert b"eng_config.cc:" in p.stderr
+
+
+def test_shuffle_matches_reference_permutation(eng, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "shuffle.npz"))
+    for key in g.files:
+        n = int(key[1:])
+        data = np.arange(n, dtype=np.uint32)
+        for epoch, want in enumerate(g[key]):
+            eng.fgnn_host_shuffle_minstd0(data.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_uint64(epoch))
+            np.testing.assert_array_equal(data, want)
+    data = np.arange(100003, dtype=np.uint32)
+    eng.fgnn_host_shuffle_minstd0(data.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), C.c_uint64(7))
+    np.testing.assert_array_equal(data, oracle.shuffle_minstd0(np.arange(100003, dtype=np.uint32), 7))
+
+
+def test_wire_sizes(eng):
+    out = (C.c_size_t * 3)()
+    fan = (C.c_size_t * 2)(25, 10)
+    eng.fgnn_host_wire_sizes(C.c_size_t(8000), fan, C.c_size_t(2), 0, out)
+    assert out[0] == 40 and out[1] == 24  # sizeof(TransData), sizeof(GraphData) on LP64 (task_queue.cc:68-88)
+    # 2 GraphData + 2*(80 000 + 2 200 000) edge words + 8000 output ids + 3 * 2 288 000 node words
+    assert out[2] >= 40 + 2 * 24 + 8 * (80000 + 2200000) + 4 * 8000 + 12 * 2288000
+    assert out[2] < 50 * 1024 * 1024  # fits the reference's hard-coded 50 MiB slot (task_queue.cc:32)
+
+
+@pytest.mark.parametrize("producers,consumers,slots", [(1, 1, 2), (2, 1, 3), (2, 3, 4), (1, 2, 170)])
+def test_queue_multiprocess(eng, producers, consumers, slots):
+    """world_size > 1 on CPU: forked writers and readers over the shared ring; every message exactly once."""
+    rc = eng.fgnn_host_queue_selftest(C.c_size_t(slots), C.c_size_t(4096), C.c_size_t(500), producers, consumers)
+    assert rc == 0
