@@ -195,7 +195,12 @@ def main():
     local_first = (steps_per_epoch // world) * rank
 
     sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
-    batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(2)]
+    NBUF = 3
+    batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
+    # two HIP streams: the sampling chain of batch i+1 (latency-bound) overlaps the feature gather of batch i
+    # (bandwidth-bound) -- the reference runs its sample and copy loops concurrently too (cuda_loops_arch3.cc)
+    s_sample, s_extract = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    sampled = [torch.cuda.Event() for _ in range(NBUF)]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -204,21 +209,25 @@ def main():
     def run_step(i, timed):
         step = (local_first + i) % steps_per_epoch
         seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
-        bt = batches[i % 2]
-        if i >= 2:
-            bt.wait()  # the buffers of step i-2 are about to be reused; its summary was already collected
-        sampler.sample(seeds, step, bt)
-        bt.cache_index(table)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            bt.extract(feat, None)
-            e1.record()
-            ev_pairs.append((e0, e1))
-        else:
-            bt.extract(feat, None)
-        bt.extract(None, label)
-        bt.finish()
+        bt = batches[i % NBUF]
+        if i >= NBUF:
+            bt.wait()  # its buffers are about to be reused; the summary was already collected
+        with torch.cuda.stream(s_sample):
+            sampler.sample(seeds, step, bt)
+            bt.cache_index(table)
+            sampled[i % NBUF].record(s_sample)
+        with torch.cuda.stream(s_extract):
+            s_extract.wait_event(sampled[i % NBUF])
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s_extract)
+                bt.extract(feat, None)
+                e1.record(s_extract)
+                ev_pairs.append((e0, e1))
+            else:
+                bt.extract(feat, None)
+            bt.extract(None, label)
+            bt.finish()
         return bt
 
     def barrier():
@@ -236,7 +245,7 @@ def main():
     for i in range(args.warmup, args.warmup + args.steps):
         bt = run_step(i, True)
         pending.append(bt)
-        if len(pending) == 2:  # collect the summary of step i-1 while step i runs
+        if len(pending) == NBUF:  # collect the oldest summary while newer steps run
             metas.append(pending.pop(0).wait())
     for bt in pending:
         metas.append(bt.wait())

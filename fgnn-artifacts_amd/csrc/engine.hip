@@ -11,7 +11,13 @@
 
 struct fgnn_sampler {
   fgnn_sampler_config cfg;
-  fgnn_hashtable *ht;
+  // two dedup tables used alternately: while batch k samples into one, the other is wiped on a side
+  // stream (the reference wipes its single 128 MiB table on the critical path, cuda_hashtable.cu:714-723)
+  fgnn_hashtable *ht[2];
+  hipStream_t reset_stream;
+  hipEvent_t used[2], wiped[2];
+  bool wipe_pending[2];
+  uint64_t batch_counter;
   size_t max_nodes;                       // PredictNumNodes(batch, fanout, L)
   size_t in_cap[FGNN_MAX_LAYERS];         // worst-case #seeds of layer l
   size_t edge_cap[FGNN_MAX_LAYERS];       // worst-case #edges of layer l
@@ -49,37 +55,6 @@ size_t dtype_size(int dtype) {
   }
 }
 
-__global__ void meta_begin_kernel(fgnn_batch_meta *m, uint64_t key, uint32_t num_layers, uint32_t num_output) {
-  m->key = key;
-  m->num_layers = num_layers;
-  m->num_output = num_output;
-  m->num_input = 0;
-  m->num_miss = 0;
-  m->num_cache = 0;
-  m->overflow = 0;
-}
-
-// after layer l: num_dst = #items before the fill (kept in d_num_items[1]), num_src = #items now
-__global__ void meta_layer_kernel(fgnn_batch_meta *m, int layer, const uint32_t *d_num_items, size_t edge_cap,
-                                  size_t node_cap) {
-  m->num_dst[layer] = d_num_items[1];
-  m->num_src[layer] = d_num_items[0];
-  m->num_input = d_num_items[0];
-  if (m->num_edge[layer] > edge_cap || d_num_items[0] > node_cap) m->overflow = 1;
-}
-
-__global__ __launch_bounds__(kBlock) void copy_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
-                                                          const uint32_t *d_n, size_t cap) {
-  const size_t n = resolve_count(0, d_n, cap);
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-}
-
-__global__ void meta_counts_kernel(fgnn_batch_meta *m, const uint32_t *d_counts) {
-  m->num_miss = d_counts[0];
-  m->num_cache = d_counts[1];
-}
-
 }  // namespace
 }  // namespace fgnn
 
@@ -109,7 +84,11 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
-  s->ht = nullptr;
+  s->ht[0] = s->ht[1] = nullptr;
+  s->reset_stream = nullptr;
+  s->used[0] = s->used[1] = s->wiped[0] = s->wiped[1] = nullptr;
+  s->wipe_pending[0] = s->wipe_pending[1] = false;
+  s->batch_counter = 0;
   s->tmp_dst = nullptr;
   s->ws = nullptr;
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
@@ -125,8 +104,19 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   s->max_nodes = count;
   if (s->max_edge_cap >= 0x7fffffffull || s->max_nodes >= 0x7fffffffull) { delete s; return fail(FGNN_EINVAL); }
   int err = FGNN_OK;
-  s->ht = fgnn_hashtable_create(s->max_nodes, &err);
-  if (!s->ht) { delete s; return fail(err); }
+  for (int k = 0; k < 2; ++k) {
+    s->ht[k] = fgnn_hashtable_create(s->max_nodes, &err);
+    if (!s->ht[k]) { fgnn_sampler_destroy(s); return fail(err); }
+    if (hipEventCreateWithFlags(&s->used[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->wiped[k], hipEventDisableTiming) != hipSuccess) {
+      fgnn_sampler_destroy(s);
+      return fail(FGNN_EHIP);
+    }
+  }
+  if (hipStreamCreateWithFlags(&s->reset_stream, hipStreamNonBlocking) != hipSuccess) {
+    fgnn_sampler_destroy(s);
+    return fail(FGNN_EHIP);
+  }
   s->ws_bytes = fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes);
   for (size_t l = 0; l < cfg->num_layers; ++l) {
     size_t need = 0;
@@ -145,7 +135,15 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
 
 extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   if (!s) return;
-  if (s->ht) fgnn_hashtable_destroy(s->ht);
+  if (s->reset_stream) {
+    (void)hipStreamSynchronize(s->reset_stream);
+    (void)hipStreamDestroy(s->reset_stream);
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (s->ht[k]) fgnn_hashtable_destroy(s->ht[k]);
+    if (s->used[k]) (void)hipEventDestroy(s->used[k]);
+    if (s->wiped[k]) (void)hipEventDestroy(s->wiped[k]);
+  }
   if (s->tmp_dst) (void)hipFree(s->tmp_dst);
   if (s->ws) (void)hipFree(s->ws);
   delete s;
@@ -227,23 +225,27 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
   const size_t L = s->cfg.num_layers;
+  const int slot = (int)(s->batch_counter++ & 1);
+  fgnn_hashtable *ht = s->ht[slot];
   out->num_output = num_seeds;
-  FGNN_HIP_CHECK(hipMemsetAsync(out->d_meta, 0, sizeof(fgnn_batch_meta), st));
-  hipLaunchKernelGGL(meta_begin_kernel, dim3(1), dim3(1), 0, st, out->d_meta, batch_key, (uint32_t)L,
-                     (uint32_t)num_seeds);
-  int rc = fgnn_hashtable_reset(s->ht, stream);
+  // this batch's table was wiped on the side stream after its previous use
+  if (s->wipe_pending[slot]) {
+    FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->wiped[slot], 0));
+    s->wipe_pending[slot] = false;
+  }
+  // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
+  int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
   if (rc != FGNN_OK) return rc;
-  if (num_seeds == 0) return launch_status(__func__);
-  FGNN_HIP_CHECK(hipMemcpyAsync(out->output_nodes, d_seeds, num_seeds * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-  rc = fgnn_hashtable_fill_unique(s->ht, d_seeds, num_seeds, stream);
+  // Reset state + FillWithUnique(seeds) + output_nodes copy + summary init: one launch
+  rc = fgnn_hashtable_start_batch(ht, d_seeds, num_seeds, out->output_nodes, out->d_meta, batch_key, (uint32_t)L,
+                                  stream);
   if (rc != FGNN_OK) return rc;
 
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
   size_t cur_n_host = num_seeds;
-  // tighter caps than the create-time worst case when this batch is smaller than max_batch_size
-  size_t in_cap = num_seeds;
-  for (long l = (long)L - 1; l >= 0; --l) {
+  size_t in_cap = num_seeds;          // tighter than the create-time worst case when the batch is short
+  for (long l = (long)L - 1; l >= 0 && num_seeds; --l) {
     const size_t fan = s->cfg.fanout[l];
     const size_t ecap = in_cap * fan;
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
@@ -266,34 +268,32 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
                              s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
                              stream);
     if (rc != FGNN_OK) return rc;
-    rc = fgnn_hashtable_fill_duplicates(s->ht, s->tmp_dst, 0, d_ne, ecap, out->row[l], s->ws, s->ws_bytes, stream);
+    // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
+    rc = hashtable_fill_duplicates_ex(ht, s->tmp_dst, 0, d_ne, ecap, out->row[l], s->ws, s->ws_bytes, stream,
+                                      LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
+                                                   &out->d_meta->num_input});
     if (rc != FGNN_OK) return rc;
     in_cap += ecap;
-    hipLaunchKernelGGL(meta_layer_kernel, dim3(1), dim3(1), 0, st, out->d_meta, (int)l,
-                       fgnn_hashtable_d_num_items(s->ht), ecap, in_cap);
-    cur = fgnn_hashtable_n2o(s->ht);
-    d_cur_n = fgnn_hashtable_d_num_items(s->ht);
+    cur = out->input_nodes;
+    d_cur_n = fgnn_hashtable_d_num_items(ht);
     cur_n_host = 0;
   }
-  // input_nodes = unique (cuda_loops.cc:258)
-  size_t blocks = div_up(in_cap, kBlock);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(copy_u32_kernel, dim3(blocks), dim3(kBlock), 0, st, out->input_nodes, fgnn_hashtable_n2o(s->ht),
-                     fgnn_hashtable_d_num_items(s->ht), in_cap);
+  // hand the table to the side stream for wiping; the next batch uses the other table meanwhile
+  FGNN_HIP_CHECK(hipEventRecord(s->used[slot], st));
+  FGNN_HIP_CHECK(hipStreamWaitEvent(s->reset_stream, s->used[slot], 0));
+  rc = fgnn_hashtable_reset(ht, s->reset_stream);
+  if (rc != FGNN_OK) return rc;
+  FGNN_HIP_CHECK(hipEventRecord(s->wiped[slot], s->reset_stream));
+  s->wipe_pending[slot] = true;
   return launch_status(__func__);
 }
 
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
   if (!b || !cache_table) return FGNN_EINVAL;
-  auto st = static_cast<hipStream_t>(stream);
-  // d_counts lives at the tail of the scratch block
-  uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(b->ws) + b->ws_bytes) - 2;
-  int rc = fgnn_get_miss_cache_index(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
-                                     b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], d_counts, b->ws,
-                                     b->ws_bytes - 2 * sizeof(uint32_t), stream);
-  if (rc != FGNN_OK) return rc;
-  hipLaunchKernelGGL(meta_counts_kernel, dim3(1), dim3(1), 0, st, b->d_meta, d_counts);
-  return launch_status(__func__);
+  // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
+  return fgnn_get_miss_cache_index(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
+                                   b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
+                                   b->ws_bytes, stream);
 }
 
 extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream) {

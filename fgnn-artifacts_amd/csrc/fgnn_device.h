@@ -142,4 +142,14 @@ int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *
 
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// where the dedup's last pass leaves the sizes of the layer it just closed (all device pointers, nullable)
+struct LayerSummary {
+  uint32_t *num_dst;    // #items in the table before the fill  (TrainGraph::num_dst)
+  uint32_t *num_src;    // #items after the fill                (TrainGraph::num_src)
+  uint32_t *num_total;  // same value again (the batch's running num_input)
+};
+int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                 const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
+                                 size_t ws_bytes, void *stream, LayerSummary summary);
+
 }  // namespace fgnn

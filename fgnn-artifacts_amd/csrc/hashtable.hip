@@ -25,7 +25,8 @@
 
 struct fgnn_hashtable {
   unsigned long long *table;  // capacity buckets
-  uint32_t *n2o;              // max_items
+  uint32_t *n2o;              // max_items; where new nodes are appended (owned, or a batch's input_nodes buffer)
+  uint32_t *n2o_owned;
   uint32_t *d_num_items;      // [2]: current, scratch for "old" value during a fill
   size_t capacity;            // power of two
   size_t max_items;
@@ -93,6 +94,37 @@ __global__ __launch_bounds__(kBlock) void ht_fill_unique_kernel(unsigned long lo
   }
 }
 
+// first fill of a batch on a freshly reset table: item i -> local id i; also copies the items (the
+// batch's output_nodes), initialises the batch summary and sets the item count -- one launch instead
+// of memset + fill + advance + copy
+__global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(unsigned long long *table, uint32_t shift,
+                                                                uint32_t mask, const uint32_t *__restrict__ items,
+                                                                size_t n, uint32_t *__restrict__ n2o,
+                                                                uint32_t *__restrict__ items_copy,
+                                                                uint32_t *d_num_items, fgnn_batch_meta *meta,
+                                                                uint64_t key, uint32_t num_layers) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) {
+    d_num_items[0] = (uint32_t)n;
+    d_num_items[1] = 0;
+    if (meta) {
+      fgnn_batch_meta m;
+      memset(&m, 0, sizeof(m));
+      m.key = key;
+      m.num_layers = num_layers;
+      m.num_output = (uint32_t)n;
+      m.num_input = (uint32_t)n;
+      *meta = m;
+    }
+  }
+  if (i < n) {
+    const uint32_t id = items[i];
+    (void)ht_insert_min(table, shift, mask, id, (uint32_t)i);
+    n2o[i] = id;
+    if (items_copy) items_copy[i] = id;
+  }
+}
+
 __global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_items[0] += add; }
 
 // pass 1: insert every item with value PENDING|i; remember its bucket
@@ -113,10 +145,12 @@ __global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *t
 __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long long *__restrict__ table,
                                                           size_t n_host, const size_t *d_n, size_t cap,
                                                           uint32_t *__restrict__ pos,
-                                                          uint32_t *__restrict__ block_sums) {
+                                                          uint32_t *__restrict__ block_sums,
+                                                          uint32_t *d_num_items) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t tile0 = (size_t)blockIdx.x * kTile;
+  if (blockIdx.x == 0 && threadIdx.x == 0) d_num_items[1] = d_num_items[0];  // count before this fill
   uint32_t cnt = 0;
 #pragma unroll
   for (int r = 0; r < kItemsPerThread; ++r) {
@@ -138,12 +172,18 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
                                                            const size_t *d_n, size_t cap,
                                                            const uint32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ block_offsets,
-                                                           const uint32_t *d_old_num_items,
-                                                           uint32_t *__restrict__ n2o, size_t max_items) {
+                                                           const uint32_t *d_num_items,
+                                                           uint32_t *__restrict__ n2o, size_t max_items,
+                                                           LayerSummary summary) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t tile0 = (size_t)blockIdx.x * kTile;
-  uint32_t running = *d_old_num_items + block_offsets[blockIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (summary.num_dst) *summary.num_dst = d_num_items[1];
+    if (summary.num_src) *summary.num_src = d_num_items[0];
+    if (summary.num_total) *summary.num_total = d_num_items[0];
+  }
+  uint32_t running = d_num_items[1] + block_offsets[blockIdx.x];
   // item order inside the tile is r-major: i = tile0 + r*kBlock + tid
   for (int r = 0; r < kItemsPerThread; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
@@ -222,23 +262,42 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err) {
   ht->shift = 32 - lg;
   ht->table = nullptr;
   ht->n2o = nullptr;
+  ht->n2o_owned = nullptr;
   ht->d_num_items = nullptr;
   if (hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc(&ht->n2o, max_items * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&ht->n2o_owned, max_items * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&ht->d_num_items, 2 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ht->table, 0xFF, cap * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ht->d_num_items, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
     fgnn_hashtable_destroy(ht);
     return fail(FGNN_EHIP);
   }
+  ht->n2o = ht->n2o_owned;
   if (h_err) *h_err = FGNN_OK;
   return ht;
+}
+
+extern "C" int fgnn_hashtable_set_n2o(fgnn_hashtable *ht, uint32_t *storage) {
+  if (!ht) return FGNN_EINVAL;
+  ht->n2o = storage ? storage : ht->n2o_owned;
+  return FGNN_OK;
+}
+
+extern "C" int fgnn_hashtable_start_batch(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                          uint32_t *items_copy, fgnn_batch_meta *d_meta, uint64_t key,
+                                          uint32_t num_layers, void *stream) {
+  if (!ht || (!items && num_items) || num_items > ht->max_items) return FGNN_EINVAL;
+  const uint32_t mask = (uint32_t)(ht->capacity - 1);
+  const size_t nb = num_items ? div_up(num_items, kBlock) : 1;
+  hipLaunchKernelGGL(ht_start_batch_kernel, dim3(nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream), ht->table,
+                     ht->shift, mask, items, num_items, ht->n2o, items_copy, ht->d_num_items, d_meta, key, num_layers);
+  return launch_status(__func__);
 }
 
 extern "C" void fgnn_hashtable_destroy(fgnn_hashtable *ht) {
   if (!ht) return;
   if (ht->table) (void)hipFree(ht->table);
-  if (ht->n2o) (void)hipFree(ht->n2o);
+  if (ht->n2o_owned) (void)hipFree(ht->n2o_owned);
   if (ht->d_num_items) (void)hipFree(ht->d_num_items);
   delete ht;
 }
@@ -273,6 +332,13 @@ extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *it
 extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                               const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped,
                                               void *ws, size_t ws_bytes, void *stream) {
+  return fgnn::hashtable_fill_duplicates_ex(ht, items, num_items, d_num_items, num_items_cap, mapped, ws, ws_bytes,
+                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr});
+}
+
+int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                                       const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
+                                       size_t ws_bytes, void *stream, LayerSummary summary) {
   if (!ht) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
@@ -287,13 +353,13 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
   const uint32_t mask = (uint32_t)(ht->capacity - 1);
   hipLaunchKernelGGL(ht_insert_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, ht->shift, mask, items, num_items,
                      d_num_items, cap, pos);
-  hipLaunchKernelGGL(ht_count_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos, sums);
-  // d_num_items[1] keeps the old count for pass 3; d_num_items[0] advances
-  FGNN_HIP_CHECK(hipMemcpyAsync(ht->d_num_items + 1, ht->d_num_items, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
+  hipLaunchKernelGGL(ht_count_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos, sums,
+                     ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s) != FGNN_OK)
     return FGNN_EHIP;
   hipLaunchKernelGGL(ht_assign_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, items, num_items, d_num_items, cap, pos,
-                     sums, ht->d_num_items + 1, ht->n2o, ht->max_items);
+                     sums, ht->d_num_items, ht->n2o, ht->max_items, summary);
   if (mapped)
     hipLaunchKernelGGL(ht_map_pos_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos,
                        mapped);

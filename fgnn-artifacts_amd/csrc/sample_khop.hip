@@ -148,21 +148,44 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
   }
   __syncthreads();
 
-  // ---- phase B: one lane per output edge --------------------------------------------------
+  // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   const size_t base = block_offsets[blockIdx.x];
-  for (uint32_t p = tid; p < total; p += S) {
-    const int k = owner_of_slot<S>(sh_lo, p);
-    const uint32_t j = p - sh_lo[k];
-    const uint32_t koff = sh_off[k];
-    const bool kbig = sh_len[k] > F;
-    const uint32_t pos = kbig ? sh_o[j * S + k] : j;
-    const uint32_t v = indices[koff + pos];
-    out_dst[base + p] = v;
-    out_src[base + p] = src_mode == FGNN_SRC_LOCAL ? (uint32_t)(first + k) : sh_rid[k];
-    if (KHOP2 && kbig) {
-      const uint32_t wv = indices[koff + sh_w[j * S + k]];
-      sh_o[j * S + k] = v;    // value that lands in the consumed tail slot len-1-j
-      sh_w[j * S + k] = wv;   // value that lands in position s_j
+  constexpr int UB = 4;
+  for (uint32_t p0 = tid; p0 < total; p0 += S * UB) {
+    uint32_t v[UB], wv[UB], slot[UB], srcv[UB];
+    bool live[UB], bigv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t p = p0 + u * S;
+      live[u] = p < total;
+      bigv[u] = false;
+      slot[u] = 0;
+      srcv[u] = 0;
+      v[u] = 0;
+      wv[u] = 0;
+      if (live[u]) {
+        const int k = owner_of_slot<S>(sh_lo, p);
+        const uint32_t j = p - sh_lo[k];
+        const uint32_t koff = sh_off[k];
+        bigv[u] = sh_len[k] > F;
+        slot[u] = j * S + k;
+        const uint32_t pos = bigv[u] ? sh_o[slot[u]] : j;
+        srcv[u] = src_mode == FGNN_SRC_LOCAL ? (uint32_t)(first + k) : sh_rid[k];
+        v[u] = indices[koff + pos];
+        if (KHOP2 && bigv[u]) wv[u] = indices[koff + sh_w[slot[u]]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (live[u]) {
+        const uint32_t p = p0 + u * S;
+        out_dst[base + p] = v[u];
+        out_src[base + p] = srcv[u];
+        if (KHOP2 && bigv[u]) {
+          sh_o[slot[u]] = v[u];   // value that lands in the consumed tail slot len-1-j
+          sh_w[slot[u]] = wv[u];  // value that lands in position s_j
+        }
+      }
     }
   }
 
@@ -202,8 +225,9 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   const uint32_t tag = ((KHOP2 ? FGNN_KHOP2 : FGNN_KHOP0) << 8) | (layer & 0xffu);
   const size_t words_per_seed = (KHOP2 ? 3u : 1u) * (size_t)F;
   // seeds per workgroup: as many as fit in ~120 KiB of LDS (160 KiB per CU on gfx950)
+  // small workgroups for small frontiers: the kernel is latency-bound, more resident waves hide more of it
   int S = 256;
-  while (S > 64 && words_per_seed * S * 4 > 120 * 1024) S >>= 1;
+  while (S > 64 && (words_per_seed * S * 4 > 120 * 1024 || cap / S < 2048)) S >>= 1;
   if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
   const size_t nb = div_up(cap, (size_t)S);
   if (ws_bytes < (nb + 1) * sizeof(uint32_t)) return FGNN_ENOSPC;

@@ -25,7 +25,8 @@ EXPORTS = [
     "fgnn_sample_random_walk",
     "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
-    "fgnn_hashtable_d_num_items", "fgnn_get_miss_cache_index", "fgnn_gather_rows",
+    "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
+    "fgnn_get_miss_cache_index", "fgnn_gather_rows",
 ]
 
 _lib = None

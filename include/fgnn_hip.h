@@ -115,6 +115,14 @@ int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t *items, si
 /* GPUMapEdges for arbitrary ids that are already in the table. */
 int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *stream);
+/* Redirects where the N2O list is written (storage for max_items ids; NULL = the table's own array): the
+ * batch driver points it at the batch's input_nodes buffer so no copy is needed at the end. */
+int fgnn_hashtable_set_n2o(fgnn_hashtable *ht, uint32_t *storage);
+/* First fill of a batch on a reset table in ONE launch: item i gets local id i, items are also copied to
+ * items_copy (may be NULL), *d_meta (may be NULL) is initialised with (key, num_layers, num_output). */
+struct fgnn_batch_meta_s;
+int fgnn_hashtable_start_batch(fgnn_hashtable *ht, const uint32_t *items, size_t num_items, uint32_t *items_copy,
+                               struct fgnn_batch_meta_s *d_meta, uint64_t key, uint32_t num_layers, void *stream);
 /* device pointers: N2O list (== `unique`, the next layer's input) and its length (uint32) */
 const uint32_t *fgnn_hashtable_n2o(const fgnn_hashtable *ht);
 const uint32_t *fgnn_hashtable_d_num_items(const fgnn_hashtable *ht);
@@ -168,7 +176,7 @@ typedef struct {
 
 /* Host-visible summary of one batch (Task / TrainGraph / MissCacheIndex sizes, common.h:186-222);
  * valid after fgnn_batch_wait. */
-typedef struct {
+typedef struct fgnn_batch_meta_s {
   uint64_t key;
   uint64_t num_edge[FGNN_MAX_LAYERS]; /* TrainGraph::num_edge */
   uint32_t num_src[FGNN_MAX_LAYERS];  /* TrainGraph::num_src = #unique after the layer */
