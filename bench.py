@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
     ap.add_argument("--cache-ratio", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="sample and extract on one stream")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
     args = ap.parse_args()
 
@@ -199,7 +200,9 @@ def main():
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
     # two HIP streams: the sampling chain of batch i+1 (latency-bound) overlaps the feature gather of batch i
     # (bandwidth-bound) -- the reference runs its sample and copy loops concurrently too (cuda_loops_arch3.cc)
-    s_sample, s_extract = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_sample, s_extract = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=0)
+    if args.no_overlap:
+        s_extract = s_sample
     sampled = [torch.cuda.Event() for _ in range(NBUF)]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup

@@ -14,11 +14,14 @@
 //    lane of a wave is busy for any feature width (D=100 -> 25 chunks, D=128 -> 32, D=256 -> 64) and
 //    several independent 16-byte loads are in flight per lane; a scalar path covers rows whose byte
 //    length is not a multiple of 16 (labels: dim 1 x 8 B).
+#include <cstdlib>
+
 #include "fgnn_device.h"
 
 namespace fgnn {
 namespace {
 
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void cache_count_kernel(const uint32_t *__restrict__ table,
                                                              const uint32_t *__restrict__ nodes, size_t n_host,
                                                              const uint32_t *d_n, size_t cap,
@@ -26,10 +29,10 @@ __global__ __launch_bounds__(kBlock) void cache_count_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ block_sums) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   uint32_t miss = 0;
 #pragma unroll
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t s = table[nodes[i]];
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(kBlock) void cache_count_kernel(const uint32_t *__r
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void cache_split_kernel(const uint32_t *__restrict__ nodes, size_t n_host,
                                                              const uint32_t *d_n, size_t cap,
                                                              const uint32_t *__restrict__ slot,
@@ -54,9 +58,9 @@ __global__ __launch_bounds__(kBlock) void cache_split_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ d_counts) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   uint32_t miss_before = block_offsets[blockIdx.x];
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t row0 = tile0 + (size_t)r * kBlock;
     const size_t i = row0 + threadIdx.x;
     uint32_t s = 0;
@@ -90,39 +94,70 @@ __global__ __launch_bounds__(kBlock) void cache_split_kernel(const uint32_t *__r
 
 struct alignas(16) chunk16 { uint32_t a, b, c, d; };
 
-// flat 16-byte-chunk gather; chunks_per_row = row_bytes / 16
-template <int UNROLL>
+// flat 16-byte-chunk gather; chunks_per_row = row_bytes / 16.  A workgroup walks tiles of
+// kBlock*UNROLL consecutive chunks (chunk c of the output = chunk c%cpr of row c/cpr).  The grid is capped
+// at a few workgroups per CU: enough loads in flight to saturate HBM while leaving wave slots for the
+// latency-bound sampling kernels of the next batch that run concurrently on another stream.
+// CPR > 0 fixes chunks-per-row at compile time (the index division becomes a multiply/shift).
+template <int UNROLL, int CPR, bool NT, bool NTS>
 __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restrict__ out,
                                                                const chunk16 *__restrict__ src,
                                                                const uint32_t *__restrict__ src_index,
                                                                const uint32_t *__restrict__ dst_index, size_t n_host,
-                                                               const uint32_t *d_n, size_t cap, uint32_t cpr) {
-  const size_t n = resolve_count(n_host, d_n, cap);
-  const size_t total = n * cpr;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; c + (UNROLL - 1) * stride < total; c += UNROLL * stride) {
+                                                               const uint32_t *d_n, size_t cap, uint32_t cpr_rt) {
+  const uint32_t cpr = CPR ? (uint32_t)CPR : cpr_rt;
+  const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);
+  const uint32_t total = n * cpr;  // host guarantees cap * cpr < 2^32
+  constexpr uint32_t tile = kBlock * UNROLL;
+  const uint32_t full = total / tile * tile;
+  uint32_t tile0 = blockIdx.x * tile;
+  for (; tile0 < full; tile0 += gridDim.x * tile) {
     chunk16 v[UNROLL];
     size_t dsts[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const size_t cc = c + u * stride;
-      const size_t row = cc / cpr;
-      const uint32_t col = (uint32_t)(cc - row * cpr);
+      const uint32_t cc = tile0 + u * kBlock + threadIdx.x;
+      const uint32_t row = cc / cpr;
+      const uint32_t col = cc - row * cpr;
       const size_t srow = src_index ? src_index[row] : row;
       const size_t drow = dst_index ? dst_index[row] : row;
-      v[u] = src[srow * cpr + col];
+      const chunk16 *sp = src + srow * cpr + col;
+      if (NT) {
+        v[u].a = __builtin_nontemporal_load(&sp->a);
+        v[u].b = __builtin_nontemporal_load(&sp->b);
+        v[u].c = __builtin_nontemporal_load(&sp->c);
+        v[u].d = __builtin_nontemporal_load(&sp->d);
+      } else {
+        v[u] = *sp;
+      }
       dsts[u] = drow * cpr + col;
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) out[dsts[u]] = v[u];
+    for (int u = 0; u < UNROLL; ++u) {
+      if (NTS) {
+        chunk16 *dp = out + dsts[u];
+        __builtin_nontemporal_store(v[u].a, &dp->a);
+        __builtin_nontemporal_store(v[u].b, &dp->b);
+        __builtin_nontemporal_store(v[u].c, &dp->c);
+        __builtin_nontemporal_store(v[u].d, &dp->d);
+      } else {
+        out[dsts[u]] = v[u];
+      }
+    }
   }
-  for (; c < total; c += stride) {
-    const size_t row = c / cpr;
-    const uint32_t col = (uint32_t)(c - row * cpr);
-    const size_t srow = src_index ? src_index[row] : row;
-    const size_t drow = dst_index ? dst_index[row] : row;
-    out[drow * cpr + col] = src[srow * cpr + col];
+  // ragged last tile (handled by the workgroup whose turn it is)
+  if (tile0 == full && full < total) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t cc = full + u * kBlock + threadIdx.x;
+      if (cc < total) {
+        const uint32_t row = cc / cpr;
+        const uint32_t col = cc - row * cpr;
+        const size_t srow = src_index ? src_index[row] : row;
+        const size_t drow = dst_index ? dst_index[row] : row;
+        out[drow * cpr + col] = src[srow * cpr + col];
+      }
+    }
   }
 }
 
@@ -173,17 +208,26 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
   }
   if (!table || !nodes || !miss_src || !miss_dst || !cache_src || !cache_dst || cap > 0xffffffffull)
     return FGNN_EINVAL;
-  const size_t nb = div_up(cap, kTile);
+  const int ipt = cap <= (4u << 20) ? 1 : kItemsPerThread;
+  const size_t nb = div_up(cap, (size_t)kBlock * ipt);
   // scratch: slot[cap] | block_sums[nb] | total_miss[1]
   if (ws_bytes < (cap + nb + 2) * sizeof(uint32_t)) return FGNN_ENOSPC;
   uint32_t *slot = static_cast<uint32_t *>(ws);
   uint32_t *sums = slot + cap;
   uint32_t *total = sums + nb;
-  hipLaunchKernelGGL(cache_count_kernel, dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes, d_num_nodes, cap, slot,
-                     sums);
+  if (ipt == 1)
+    hipLaunchKernelGGL((cache_count_kernel<1>), dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes, d_num_nodes, cap,
+                       slot, sums);
+  else
+    hipLaunchKernelGGL((cache_count_kernel<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes,
+                       d_num_nodes, cap, slot, sums);
   if (launch_scan_block_sums(sums, nb, nullptr, total, nullptr, nullptr, s) != FGNN_OK) return FGNN_EHIP;
-  hipLaunchKernelGGL(cache_split_kernel, dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes, d_num_nodes, cap, slot, sums,
-                     total, miss_src, miss_dst, cache_src, cache_dst, d_counts);
+  if (ipt == 1)
+    hipLaunchKernelGGL((cache_split_kernel<1>), dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes, d_num_nodes, cap, slot,
+                       sums, total, miss_src, miss_dst, cache_src, cache_dst, d_counts);
+  else
+    hipLaunchKernelGGL((cache_split_kernel<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes,
+                       d_num_nodes, cap, slot, sums, total, miss_src, miss_dst, cache_src, cache_dst, d_counts);
   return launch_status(__func__);
 }
 
@@ -201,11 +245,41 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
   if (vec) {
     const uint32_t cpr = (uint32_t)(row_bytes / 16);
     const size_t total = cap * cpr;
-    constexpr int U = 4;
-    size_t blocks = div_up(total, (size_t)kBlock * U);
-    if (blocks > 256 * 16) blocks = 256 * 16;  // 16 workgroups per CU, grid-stride the rest
-    hipLaunchKernelGGL((gather_rows16_kernel<U>), dim3(blocks), dim3(kBlock), 0, s, static_cast<chunk16 *>(out),
-                       static_cast<const chunk16 *>(src), src_index, dst_index, n, d_n, cap, cpr);
+    if (total >= 0xffffffffull) return FGNN_EINVAL;  // 32-bit chunk index (64 GiB of rows per call)
+    // tuning knobs (read per call: only used by profiles/ sweeps)
+    const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
+    const int unroll = e_u ? atoi(e_u) : 4;
+    const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4;
+    // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
+    // loads (profiles/r01_gather_sweep.csv)
+    const bool nt = e_nt ? atoi(e_nt) != 0 : true;
+    const char *e_nts = getenv("FGNN_GATHER_NTS");
+    const bool nts = e_nts ? atoi(e_nts) != 0 : false;
+#define FGNN_GATHER3(U, C, N)                                                                                    \
+  do {                                                                                                           \
+    size_t blocks = div_up(total, (size_t)kBlock * U);                                                           \
+    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;                                                      \
+    if (nts) hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, true>), dim3(blocks), dim3(kBlock), 0, s,          \
+                       static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
+                       d_n, cap, cpr);                                                                           \
+    else hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, false>), dim3(blocks), dim3(kBlock), 0, s,             \
+                       static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
+                       d_n, cap, cpr);                                                                           \
+  } while (0)
+#define FGNN_GATHER2(U, C) do { if (nt) FGNN_GATHER3(U, C, true); else FGNN_GATHER3(U, C, false); } while (0)
+#define FGNN_GATHER(U)                                  \
+  do {                                                  \
+    if (cpr == 32) FGNN_GATHER2(U, 32);                 \
+    else if (cpr == 64) FGNN_GATHER2(U, 64);            \
+    else if (cpr == 25) FGNN_GATHER2(U, 25);            \
+    else FGNN_GATHER2(U, 0);                            \
+  } while (0)
+    if (unroll == 8) FGNN_GATHER(8);
+    else if (unroll == 2) FGNN_GATHER(2);
+    else FGNN_GATHER(4);
+#undef FGNN_GATHER
+#undef FGNN_GATHER2
+#undef FGNN_GATHER3
   } else {
     const size_t total = cap * dim;
     size_t blocks = div_up(total, kBlock);

@@ -22,5 +22,5 @@ extern "C" int fgnn_device_count(void) {
 
 // Largest layout any call needs: one uint32 per item + one per workgroup + slack.
 extern "C" size_t fgnn_scratch_bytes(size_t n_cap) {
-  return (n_cap + fgnn::div_up(n_cap, 64) + 64) * sizeof(uint32_t);
+  return (n_cap + fgnn::div_up(n_cap, 64) + 64) * sizeof(uint32_t);  // items + one sum per >=64-item workgroup
 }

@@ -128,20 +128,22 @@ __global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(unsigned long lo
 __global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_items[0] += add; }
 
 // pass 1: insert every item with value PENDING|i; remember its bucket
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *table, uint32_t shift, uint32_t mask,
                                                            const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
                                                            uint32_t *__restrict__ pos) {
   const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
 #pragma unroll
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) pos[i] = ht_insert_min(table, shift, mask, items[i], kPending | (uint32_t)i);
   }
 }
 
 // pass 2: owner(i) <=> bucket value == PENDING|i ; per-workgroup owner counts; flag kept in pos bit 31
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long long *__restrict__ table,
                                                           size_t n_host, const size_t *d_n, size_t cap,
                                                           uint32_t *__restrict__ pos,
@@ -149,11 +151,11 @@ __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long lo
                                                           uint32_t *d_num_items) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   if (blockIdx.x == 0 && threadIdx.x == 0) d_num_items[1] = d_num_items[0];  // count before this fill
   uint32_t cnt = 0;
 #pragma unroll
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t b = pos[i];
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long lo
 }
 
 // pass 3: owners take local id = old_num_items + rank (rank in item order) and append to N2O
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *table,
                                                            const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
                                                            LayerSummary summary) {
   __shared__ uint32_t sh[kWavesPerBlock];
   const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (summary.num_dst) *summary.num_dst = d_num_items[1];
     if (summary.num_src) *summary.num_src = d_num_items[0];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
   }
   uint32_t running = d_num_items[1] + block_offsets[blockIdx.x];
   // item order inside the tile is r-major: i = tile0 + r*kBlock + tid
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     uint32_t b = 0;
     bool owner = false;
@@ -208,14 +211,15 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
 }
 
 // pass 4: mapped[i] = local id of items[i] (bucket known)
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long long *__restrict__ table,
                                                             size_t n_host, const size_t *d_n, size_t cap,
                                                             const uint32_t *__restrict__ pos,
                                                             uint32_t *__restrict__ mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
 #pragma unroll
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t b = pos[i] & ~kPending;
@@ -225,15 +229,16 @@ __global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long 
 }
 
 // GPUMapEdges for ids without a remembered bucket
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(const unsigned long long *__restrict__ table,
                                                               uint32_t shift, uint32_t mask,
                                                               const uint32_t *__restrict__ items, size_t n_host,
                                                               const size_t *d_n, size_t cap,
                                                               uint32_t *__restrict__ mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t tile0 = (size_t)blockIdx.x * kTile;
+  const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
 #pragma unroll
-  for (int r = 0; r < kItemsPerThread; ++r) {
+  for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       uint32_t b;
@@ -344,25 +349,29 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (cap == 0) return FGNN_OK;
   if (!items || cap >= 0x80000000ull) return FGNN_EINVAL;
   auto s = static_cast<hipStream_t>(stream);
-  const size_t nb = div_up(cap, kTile);
+  // latency-bound at mini-batch sizes: one item per lane (8x more waves in flight) unless the input is huge
+  const int ipt = cap <= (4u << 20) ? 1 : kItemsPerThread;
+  const size_t nb = div_up(cap, (size_t)kBlock * ipt);
   // scratch layout: pos[cap] | block_sums[nb + 1]
   const size_t need = (cap + nb + 2) * sizeof(uint32_t);
   if (ws_bytes < need) return FGNN_ENOSPC;
   uint32_t *pos = static_cast<uint32_t *>(ws);
   uint32_t *sums = pos + cap;
   const uint32_t mask = (uint32_t)(ht->capacity - 1);
-  hipLaunchKernelGGL(ht_insert_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, ht->shift, mask, items, num_items,
-                     d_num_items, cap, pos);
+#define FGNN_HT(KERNEL, ...)                                                                  \
+  do {                                                                                        \
+    if (ipt == 1) hipLaunchKernelGGL((KERNEL<1>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
+  } while (0)
+  FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos);
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
-  hipLaunchKernelGGL(ht_count_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos, sums,
-                     ht->d_num_items);
+  FGNN_HT(ht_count_kernel, ht->table, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s) != FGNN_OK)
     return FGNN_EHIP;
-  hipLaunchKernelGGL(ht_assign_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, items, num_items, d_num_items, cap, pos,
-                     sums, ht->d_num_items, ht->n2o, ht->max_items, summary);
-  if (mapped)
-    hipLaunchKernelGGL(ht_map_pos_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap, pos,
-                       mapped);
+  FGNN_HT(ht_assign_kernel, ht->table, items, num_items, d_num_items, cap, pos, sums, ht->d_num_items, ht->n2o,
+          ht->max_items, summary);
+  if (mapped) FGNN_HT(ht_map_pos_kernel, ht->table, num_items, d_num_items, cap, pos, mapped);
+#undef FGNN_HT
   return launch_status(__func__);
 }
 
@@ -373,7 +382,8 @@ extern "C" int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *item
   if (cap == 0) return FGNN_OK;
   if (!items || !mapped) return FGNN_EINVAL;
   const uint32_t mask = (uint32_t)(ht->capacity - 1);
-  hipLaunchKernelGGL(ht_map_probe_kernel, dim3(div_up(cap, kTile)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     ht->table, ht->shift, mask, items, num_items, d_num_items, cap, mapped);
+  hipLaunchKernelGGL((ht_map_probe_kernel<1>), dim3(div_up(cap, kBlock)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), ht->table, ht->shift, mask, items, num_items, d_num_items, cap,
+                     mapped);
   return launch_status(__func__);
 }

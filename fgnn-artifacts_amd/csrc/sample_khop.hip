@@ -150,7 +150,7 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   const size_t base = block_offsets[blockIdx.x];
-  constexpr int UB = 4;
+  constexpr int UB = 8;
   for (uint32_t p0 = tid; p0 < total; p0 += S * UB) {
     uint32_t v[UB], wv[UB], slot[UB], srcv[UB];
     bool live[UB], bigv[UB];
