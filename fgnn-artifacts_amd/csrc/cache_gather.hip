@@ -221,7 +221,9 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
   else
     hipLaunchKernelGGL((cache_count_kernel<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes,
                        d_num_nodes, cap, slot, sums);
-  if (launch_scan_block_sums(sums, nb, nullptr, total, nullptr, nullptr, s) != FGNN_OK) return FGNN_EHIP;
+  if (launch_scan_block_sums(sums, nb, nullptr, total, nullptr, nullptr, s, d_num_nodes, (uint32_t)(kBlock * ipt)) !=
+      FGNN_OK)
+    return FGNN_EHIP;
   if (ipt == 1)
     hipLaunchKernelGGL((cache_split_kernel<1>), dim3(nb), dim3(kBlock), 0, s, nodes, num_nodes, d_num_nodes, cap, slot,
                        sums, total, miss_src, miss_dst, cache_src, cache_dst, d_counts);

@@ -117,7 +117,9 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     fgnn_sampler_destroy(s);
     return fail(FGNN_EHIP);
   }
-  s->ws_bytes = fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes);
+  // dedup scratch (pos + sums) plus the fused sampler's own block offsets behind it
+  s->ws_bytes = 2 * fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes) +
+                (s->max_edge_cap / 16 + 64) * sizeof(uint32_t);
   for (size_t l = 0; l < cfg->num_layers; ++l) {
     size_t need = 0;
     if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX) need = fgnn_weighted_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
@@ -259,19 +261,18 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
                                    s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], s->tmp_dst, out->data[l],
                                    d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
                                    stream);
-    else if (s->cfg.sample_type == FGNN_KHOP2)
-      rc = fgnn_sample_khop2(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
-                             s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
-                             stream);
     else
-      rc = fgnn_sample_khop0(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
-                             s->tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
-                             stream);
+      // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
+      rc = sample_khop_fused(s->cfg.sample_type == FGNN_KHOP2, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n,
+                             in_cap, fan, out->col[l], s->tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, s->ws,
+                             s->ws_bytes, stream);
     if (rc != FGNN_OK) return rc;
+    const bool inserted = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
     rc = hashtable_fill_duplicates_ex(ht, s->tmp_dst, 0, d_ne, ecap, out->row[l], s->ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
-                                                   &out->d_meta->num_input});
+                                                   &out->d_meta->num_input},
+                                      inserted);
     if (rc != FGNN_OK) return rc;
     in_cap += ecap;
     cur = out->input_nodes;

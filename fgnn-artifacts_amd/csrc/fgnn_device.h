@@ -6,6 +6,17 @@
 
 #include "fgnn_hip.h"
 
+// OrderedHashTable state (hashtable.hip); the samplers insert into it directly (fused path)
+struct fgnn_hashtable {
+  unsigned long long *table;  // capacity buckets of {key:hi32, value:lo32}
+  uint32_t *n2o;              // max_items; where new nodes are appended (owned, or a batch's input_nodes buffer)
+  uint32_t *n2o_owned;
+  uint32_t *d_num_items;      // [2]: current count, count before the running fill
+  size_t capacity;            // power of two
+  size_t max_items;
+  uint32_t shift;             // 32 - log2(capacity)
+};
+
 namespace fgnn {
 
 constexpr int kWave = 64;
@@ -65,6 +76,38 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t batch_key
                                                uint32_t item, uint32_t j) {
   return pick_word(philox_block(seed, batch_key, tag, item, j >> 2), j);
 }
+
+// ---- dedup hash table probes (see hashtable.hip for the design) -----------------------------------
+constexpr unsigned long long kEmpty64 = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kPending = 0x80000000u;
+constexpr uint32_t kNoBucket = 0x7FFFFFFFu;  // capacity <= 2^31, so never a real bucket index
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t shift, uint32_t mask) {
+  return ((id * 0x9E3779B1u) >> shift) & mask;
+}
+
+// Inserts (id, value) keeping the minimum value per key.  Returns the bucket index.
+__device__ __forceinline__ uint32_t ht_insert_min(unsigned long long *table, uint32_t shift, uint32_t mask,
+                                                  uint32_t id, uint32_t value) {
+  const unsigned long long mine = ((unsigned long long)id << 32) | value;
+  uint32_t h = hash_slot(id, shift, mask);
+  // load factor <= 0.5 by construction; the bound only keeps a violated contract (more distinct
+  // keys than max_items) from hanging the GPU
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    unsigned long long cur = table[h];
+    if (cur == kEmpty64) {
+      cur = atomicCAS(&table[h], kEmpty64, mine);
+      if (cur == kEmpty64) return h;
+    }
+    if ((uint32_t)(cur >> 32) == id) {
+      if ((uint32_t)cur > value) atomicMin(&table[h], mine);
+      return h;
+    }
+    h = (h + 1) & mask;
+  }
+  return kNoBucket;
+}
+
 
 // ---- wave64 / block primitives ----------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
@@ -137,8 +180,12 @@ __device__ __forceinline__ size_t resolve_count64(size_t n_host, const size_t *d
 // Exclusive scan of `n` block sums by ONE workgroup of 1024 threads, in place (defined in
 // scan.hip).  total -> *total64 and *total32 (either may be null).  If accum != null the kernel also
 // does *accum_out = *accum + total (used to advance the hash table's item count on the device).
+// d_items32 / d_items64 (optional): device count of the items the sums were computed from, items_per_sum
+// of them per entry -- lets the scan skip the capacity padding.
 int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *total32,
-                           const uint32_t *accum, uint32_t *accum_out, hipStream_t stream);
+                           const uint32_t *accum, uint32_t *accum_out, hipStream_t stream,
+                           const uint32_t *d_items32 = nullptr, uint32_t items_per_sum = 0,
+                           const size_t *d_items64 = nullptr);
 
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
@@ -150,6 +197,13 @@ struct LayerSummary {
 };
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
-                                 size_t ws_bytes, void *stream, LayerSummary summary);
+                                 size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted);
+// k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
+// with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
+// to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).
+int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                      const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                      size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
+                      void *ws, size_t ws_bytes, void *stream);
 
 }  // namespace fgnn

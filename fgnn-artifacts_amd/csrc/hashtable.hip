@@ -23,48 +23,9 @@
 //  * owner ranks come from wave ballots + a one-workgroup scan of per-workgroup counts.
 #include "fgnn_device.h"
 
-struct fgnn_hashtable {
-  unsigned long long *table;  // capacity buckets
-  uint32_t *n2o;              // max_items; where new nodes are appended (owned, or a batch's input_nodes buffer)
-  uint32_t *n2o_owned;
-  uint32_t *d_num_items;      // [2]: current, scratch for "old" value during a fill
-  size_t capacity;            // power of two
-  size_t max_items;
-  uint32_t shift;             // 32 - log2(capacity)
-};
 
 namespace fgnn {
 namespace {
-
-constexpr unsigned long long kEmpty64 = 0xFFFFFFFFFFFFFFFFull;
-constexpr uint32_t kPending = 0x80000000u;
-constexpr uint32_t kNoBucket = 0x7FFFFFFFu;  // capacity <= 2^31, so never a real bucket index
-
-__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t shift, uint32_t mask) {
-  return ((id * 0x9E3779B1u) >> shift) & mask;
-}
-
-// Inserts (id, value) keeping the minimum value per key.  Returns the bucket index.
-__device__ __forceinline__ uint32_t ht_insert_min(unsigned long long *table, uint32_t shift, uint32_t mask,
-                                                  uint32_t id, uint32_t value) {
-  const unsigned long long mine = ((unsigned long long)id << 32) | value;
-  uint32_t h = hash_slot(id, shift, mask);
-  // load factor <= 0.5 by construction; the bound only keeps a violated contract (more distinct
-  // keys than max_items) from hanging the GPU
-  for (uint32_t probes = 0; probes <= mask; ++probes) {
-    unsigned long long cur = table[h];
-    if (cur == kEmpty64) {
-      cur = atomicCAS(&table[h], kEmpty64, mine);
-      if (cur == kEmpty64) return h;
-    }
-    if ((uint32_t)(cur >> 32) == id) {
-      if ((uint32_t)cur > value) atomicMin(&table[h], mine);
-      return h;
-    }
-    h = (h + 1) & mask;
-  }
-  return kNoBucket;
-}
 
 __device__ __forceinline__ uint32_t ht_find(const unsigned long long *table, uint32_t shift, uint32_t mask,
                                             uint32_t id, uint32_t *bucket) {
@@ -338,12 +299,12 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
                                               const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped,
                                               void *ws, size_t ws_bytes, void *stream) {
   return fgnn::hashtable_fill_duplicates_ex(ht, items, num_items, d_num_items, num_items_cap, mapped, ws, ws_bytes,
-                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr});
+                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false);
 }
 
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
-                                       size_t ws_bytes, void *stream, LayerSummary summary) {
+                                       size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted) {
   if (!ht) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
@@ -363,10 +324,12 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (ipt == 1) hipLaunchKernelGGL((KERNEL<1>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
   } while (0)
-  FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos);
+  // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
+  if (!already_inserted) FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos);
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
   FGNN_HT(ht_count_kernel, ht->table, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
-  if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s) != FGNN_OK)
+  if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s, nullptr,
+                             (uint32_t)(kBlock * ipt), d_num_items) != FGNN_OK)
     return FGNN_EHIP;
   FGNN_HT(ht_assign_kernel, ht->table, items, num_items, d_num_items, cap, pos, sums, ht->d_num_items, ht->n2o,
           ht->max_items, summary);

@@ -59,14 +59,20 @@ __device__ __forceinline__ int owner_of_slot(const uint32_t *lo, uint32_t p) {
 // KHOP2 == false : reservoir sampling (khop0.cu:41-90), CSR untouched
 // KHOP2 == true  : partial Fisher-Yates in place (khop2.cu:41-89)
 // S seeds per workgroup, S threads.  Dynamic LDS: KHOP2 ? 3*F*S words : F*S words.
-template <int S, bool KHOP2>
+struct FuseArgs {               // dedup insert fused into phase B (engine path)
+  unsigned long long *table;    // null = not fused
+  uint32_t shift, mask;
+  uint32_t *pos;                // bucket of every emitted edge
+};
+
+template <int S, bool KHOP2, int FMAX>
 __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restrict__ indptr, uint32_t *indices,
                                                         const uint32_t *__restrict__ input, size_t num_input,
                                                         const uint32_t *d_num_input, size_t cap, uint32_t F,
                                                         const uint32_t *__restrict__ block_offsets,
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
-                                                        uint32_t tag) {
+                                                        uint32_t tag, FuseArgs fuse) {
   constexpr int NW = S / kWave;
   extern __shared__ uint32_t dyn[];
   __shared__ uint32_t sh_scan[NW > 0 ? NW : 1];
@@ -106,21 +112,47 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
       // s_i == p, else p itself (a consumed tail position len-1-i is never touched again).
       //   o_j = content(sel_j)      -> emitted origin
       //   w_j = content(len-1-j)    -> origin that moves into position sel_j
-      u32x4 blk{0, 0, 0, 0};
-      for (uint32_t j = 0; j < F; ++j) {
-        if ((j & 3u) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 2);
-        const uint32_t sel = pick_word(blk, j) % (len - j);
-        const uint32_t t = len - 1 - j;
-        uint32_t o = sel, w = t;
-        for (uint32_t q = 0; q < j; ++q) {
-          const uint32_t sq = sh_s[q * S + tid];
-          const uint32_t wq = sh_w[q * S + tid];
-          if (sq == sel) o = wq;
-          if (sq == t) w = wq;
+      if (FMAX > 0) {
+        // fanout <= FMAX: the swap log lives in registers (fully unrolled, static indices); the LDS
+        // copies below are write-only here -- no LDS round trip inside the O(F^2) recurrence
+        uint32_t rs[FMAX > 0 ? FMAX : 1], rw[FMAX > 0 ? FMAX : 1];
+        u32x4 blk{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+          if ((uint32_t)j < F) {
+            if ((j & 3) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, (uint32_t)j >> 2);
+            const uint32_t sel = pick_word(blk, (uint32_t)j) % (len - (uint32_t)j);
+            const uint32_t t = len - 1 - (uint32_t)j;
+            uint32_t o = sel, w = t;
+#pragma unroll
+            for (int q = 0; q < j; ++q) {
+              o = rs[q] == sel ? rw[q] : o;
+              w = rs[q] == t ? rw[q] : w;
+            }
+            rs[j] = sel;
+            rw[j] = w;
+            sh_s[j * S + tid] = sel;
+            sh_w[j * S + tid] = w;
+            sh_o[j * S + tid] = o;
+          }
         }
-        sh_s[j * S + tid] = sel;
-        sh_w[j * S + tid] = w;
-        sh_o[j * S + tid] = o;
+      } else {
+        u32x4 blk{0, 0, 0, 0};
+        for (uint32_t j = 0; j < F; ++j) {
+          if ((j & 3u) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 2);
+          const uint32_t sel = pick_word(blk, j) % (len - j);
+          const uint32_t t = len - 1 - j;
+          uint32_t o = sel, w = t;
+          for (uint32_t q = 0; q < j; ++q) {
+            const uint32_t sq = sh_s[q * S + tid];
+            const uint32_t wq = sh_w[q * S + tid];
+            if (sq == sel) o = wq;
+            if (sq == t) w = wq;
+          }
+          sh_s[j * S + tid] = sel;
+          sh_w[j * S + tid] = w;
+          sh_o[j * S + tid] = o;
+        }
       }
     }
   } else {
@@ -181,6 +213,9 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
         const uint32_t p = p0 + u * S;
         out_dst[base + p] = v[u];
         out_src[base + p] = srcv[u];
+        // FillWithDuplicates pass 1 right here: the neighbour id is in a register, the edge index is known
+        if (fuse.table)
+          fuse.pos[base + p] = ht_insert_min(fuse.table, fuse.shift, fuse.mask, v[u], kPending | (uint32_t)(base + p));
         if (KHOP2 && bigv[u]) {
           sh_o[slot[u]] = v[u];   // value that lands in the consumed tail slot len-1-j
           sh_w[slot[u]] = wv[u];  // value that lands in position s_j
@@ -213,7 +248,7 @@ template <bool KHOP2>
 int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
-                size_t ws_bytes, hipStream_t stream) {
+                size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
   if (cap == 0) {
@@ -230,35 +265,69 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   while (S > 64 && (words_per_seed * S * 4 > 120 * 1024 || cap / S < 2048)) S >>= 1;
   if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
   const size_t nb = div_up(cap, (size_t)S);
-  if (ws_bytes < (nb + 1) * sizeof(uint32_t)) return FGNN_ENOSPC;
+  FuseArgs fuse{nullptr, 0, 0, nullptr};
   uint32_t *sums = static_cast<uint32_t *>(ws);
+  if (fuse_ht) {
+    // ws = pos[cap*F] (consumed by the dedup passes) | dedup sums | ... ; this kernel's offsets go at the very end
+    if (ws_bytes < (cap * fanout + nb + 8) * sizeof(uint32_t) + fgnn_scratch_bytes(cap * fanout)) return FGNN_ENOSPC;
+    fuse.table = fuse_ht->table;
+    fuse.shift = fuse_ht->shift;
+    fuse.mask = (uint32_t)(fuse_ht->capacity - 1);
+    fuse.pos = static_cast<uint32_t *>(ws);
+    sums = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes) - (nb + 4);
+  } else if (ws_bytes < (nb + 1) * sizeof(uint32_t)) {
+    return FGNN_ENOSPC;
+  }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
 
+#define FGNN_LAUNCH_KHOP2(SS, FM)                                                                              \
+  do {                                                                                                         \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, KHOP2, FM>),   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((khop_sample_kernel<SS, KHOP2, FM>), dim3(nb), dim3(SS), lds, stream, indptr, indices,  \
+                       input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
+                       batch_key, tag, fuse);                                                                  \
+  } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \
     hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,     \
                        d_num_input, cap, F, sums);                                                             \
-    if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream) != FGNN_OK)             \
+    if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream, d_num_input, SS) !=     \
+        FGNN_OK)                                                                                               \
       return FGNN_EHIP;                                                                                        \
-    static bool attr_done_##SS = false;                                                                        \
-    if (!attr_done_##SS) {                                                                                     \
-      FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, KHOP2>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
-      attr_done_##SS = true;                                                                                   \
-    }                                                                                                          \
-    hipLaunchKernelGGL((khop_sample_kernel<SS, KHOP2>), dim3(nb), dim3(SS), lds, stream, indptr, indices,      \
-                       input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag);                                                                        \
+    if (!KHOP2) FGNN_LAUNCH_KHOP2(SS, 0);                                                                      \
+    else if (F <= 8) FGNN_LAUNCH_KHOP2(SS, 8);                                                                 \
+    else if (F <= 16) FGNN_LAUNCH_KHOP2(SS, 16);                                                               \
+    else if (F <= 32) FGNN_LAUNCH_KHOP2(SS, 32);                                                               \
+    else FGNN_LAUNCH_KHOP2(SS, 0);                                                                             \
   } while (0)
 
   if (S == 256) FGNN_LAUNCH_KHOP(256);
   else if (S == 128) FGNN_LAUNCH_KHOP(128);
   else FGNN_LAUNCH_KHOP(64);
 #undef FGNN_LAUNCH_KHOP
+#undef FGNN_LAUNCH_KHOP2
   return launch_status(__func__);
 }
 
 }  // namespace
+
+int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                      const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                      size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
+                      void *ws, size_t ws_bytes, void *stream) {
+  if (!ht) return FGNN_EINVAL;
+  auto st = static_cast<hipStream_t>(stream);
+  return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht)
+               : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
+                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht);
+}
+
 }  // namespace fgnn
 
 extern "C" int fgnn_sample_khop0(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,

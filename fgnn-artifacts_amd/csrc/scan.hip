@@ -9,8 +9,15 @@ constexpr int kScanBlock = 1024;
 
 __global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(uint32_t *sums, size_t n, size_t *total64,
                                                                     uint32_t *total32, const uint32_t *accum,
-                                                                    uint32_t *accum_out) {
+                                                                    uint32_t *accum_out, const uint32_t *d_items32,
+                                                                    const size_t *d_items64, uint32_t items_per_sum) {
   __shared__ uint32_t sh[kScanBlock / kWave];
+  // grids are sized by capacity; only the first ceil(items / items_per_sum) sums can be non-zero
+  if (d_items32 || d_items64) {
+    const size_t items = d_items32 ? (size_t)*d_items32 : *d_items64;
+    const size_t live = (items + items_per_sum - 1) / items_per_sum;
+    if (live < n) n = live;
+  }
   uint32_t carry = 0;
   for (size_t base = 0; base < n; base += kScanBlock) {
     const size_t i = base + threadIdx.x;
@@ -28,9 +35,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(uint32_t *s
 }
 
 int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *total32, const uint32_t *accum,
-                           uint32_t *accum_out, hipStream_t stream) {
+                           uint32_t *accum_out, hipStream_t stream, const uint32_t *d_items32, uint32_t items_per_sum,
+                           const size_t *d_items64) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream, sums, n, total64, total32, accum,
-                     accum_out);
+                     accum_out, d_items32, d_items64, items_per_sum ? items_per_sum : 1u);
   return launch_status(__func__);
 }
 
