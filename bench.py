@@ -196,18 +196,19 @@ def main():
     local_first = (steps_per_epoch // world) * rank
 
     sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
-    NBUF = 3
+    NBUF = 4
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
-    # two HIP streams: the sampling chain of batch i+1 (latency-bound) overlaps the feature gather of batch i
-    # (bandwidth-bound) -- the reference runs its sample and copy loops concurrently too (cuda_loops_arch3.cc)
-    s_sample, s_extract = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=0)
+    # Two HIP streams, whole batches alternate between them: the chain of batch i+1 (latency-bound sampling /
+    # dedup kernels) overlaps the tail of batch i (bandwidth-bound feature gather).  khop2's in-place CSR swaps
+    # keep their batch order through an event inside fgnn_sampler_sample, so results do not change.
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     if args.no_overlap:
-        s_extract = s_sample
-    sampled = [torch.cuda.Event() for _ in range(NBUF)]
+        streams[1] = streams[0]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     ev_pairs = []
+    host_enqueue = [0.0]
 
     def run_step(i, timed):
         step = (local_first + i) % steps_per_epoch
@@ -215,22 +216,23 @@ def main():
         bt = batches[i % NBUF]
         if i >= NBUF:
             bt.wait()  # its buffers are about to be reused; the summary was already collected
-        with torch.cuda.stream(s_sample):
+        t_h = time.perf_counter()
+        st = streams[i % 2]
+        with torch.cuda.stream(st):
             sampler.sample(seeds, step, bt)
             bt.cache_index(table)
-            sampled[i % NBUF].record(s_sample)
-        with torch.cuda.stream(s_extract):
-            s_extract.wait_event(sampled[i % NBUF])
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(s_extract)
+                e0.record(st)
                 bt.extract(feat, None)
-                e1.record(s_extract)
+                e1.record(st)
                 ev_pairs.append((e0, e1))
             else:
                 bt.extract(feat, None)
             bt.extract(None, label)
             bt.finish()
+        if timed:
+            host_enqueue[0] += time.perf_counter() - t_h
         return bt
 
     def barrier():
@@ -297,6 +299,7 @@ def main():
             "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
             if world == 1 else None,
             "overflow": bool(overflow), "setup_s": t_setup,
+            "host_enqueue_ms_per_step": host_enqueue[0] / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)

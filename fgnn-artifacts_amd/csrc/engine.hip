@@ -22,9 +22,13 @@ struct fgnn_sampler {
   size_t in_cap[FGNN_MAX_LAYERS];         // worst-case #seeds of layer l
   size_t edge_cap[FGNN_MAX_LAYERS];       // worst-case #edges of layer l
   size_t max_edge_cap;
-  uint32_t *tmp_dst;                      // [max_edge_cap] sampled neighbours (global ids)
-  void *ws;                               // kernel scratch
+  // Two batches may be in flight (on two streams): each slot has its own table, scratch and temporaries.
+  uint32_t *tmp_dst[2];                   // [max_edge_cap] sampled neighbours (global ids)
+  void *ws[2];                            // kernel scratch
   size_t ws_bytes;
+  hipEvent_t slot_done[2];                // last use of a slot's scratch by sample()
+  hipEvent_t csr_done;                    // khop2 mutates the CSR: samplers of consecutive batches are ordered
+  bool slot_used[2], csr_used;
 };
 
 struct fgnn_batch {
@@ -85,12 +89,14 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
   s->ht[0] = s->ht[1] = nullptr;
+  s->tmp_dst[0] = s->tmp_dst[1] = nullptr;
+  s->ws[0] = s->ws[1] = nullptr;
+  s->slot_done[0] = s->slot_done[1] = s->csr_done = nullptr;
+  s->slot_used[0] = s->slot_used[1] = s->csr_used = false;
   s->reset_stream = nullptr;
   s->used[0] = s->used[1] = s->wiped[0] = s->wiped[1] = nullptr;
   s->wipe_pending[0] = s->wipe_pending[1] = false;
   s->batch_counter = 0;
-  s->tmp_dst = nullptr;
-  s->ws = nullptr;
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -126,8 +132,15 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
-  if (hipMalloc(&s->tmp_dst, s->max_edge_cap * sizeof(uint32_t)) != hipSuccess ||
-      hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) {
+  for (int k = 0; k < 2; ++k) {
+    if (hipMalloc(&s->tmp_dst[k], s->max_edge_cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&s->ws[k], s->ws_bytes) != hipSuccess ||
+        hipEventCreateWithFlags(&s->slot_done[k], hipEventDisableTiming) != hipSuccess) {
+      fgnn_sampler_destroy(s);
+      return fail(FGNN_EHIP);
+    }
+  }
+  if (hipEventCreateWithFlags(&s->csr_done, hipEventDisableTiming) != hipSuccess) {
     fgnn_sampler_destroy(s);
     return fail(FGNN_EHIP);
   }
@@ -146,8 +159,12 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
     if (s->used[k]) (void)hipEventDestroy(s->used[k]);
     if (s->wiped[k]) (void)hipEventDestroy(s->wiped[k]);
   }
-  if (s->tmp_dst) (void)hipFree(s->tmp_dst);
-  if (s->ws) (void)hipFree(s->ws);
+  for (int k = 0; k < 2; ++k) {
+    if (s->tmp_dst[k]) (void)hipFree(s->tmp_dst[k]);
+    if (s->ws[k]) (void)hipFree(s->ws[k]);
+    if (s->slot_done[k]) (void)hipEventDestroy(s->slot_done[k]);
+  }
+  if (s->csr_done) (void)hipEventDestroy(s->csr_done);
   delete s;
 }
 
@@ -230,6 +247,13 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
   const int slot = (int)(s->batch_counter++ & 1);
   fgnn_hashtable *ht = s->ht[slot];
   out->num_output = num_seeds;
+  uint32_t *tmp_dst = s->tmp_dst[slot];
+  void *ws = s->ws[slot];
+  // the slot's scratch was last used two batches ago, possibly on another stream
+  if (s->slot_used[slot]) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot_done[slot], 0));
+  // khop2 swaps CSR entries in place: its kernels must run in batch order even when batches overlap
+  const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
+  if (mutates && s->csr_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->csr_done, 0));
   // this batch's table was wiped on the side stream after its previous use
   if (s->wipe_pending[slot]) {
     FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->wiped[slot], 0));
@@ -253,23 +277,27 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
     if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX)
       rc = fgnn_sample_weighted_khop_prefix(s->cfg.indptr, s->cfg.indices, s->cfg.prob_prefix, cur, cur_n_host,
-                                            d_cur_n, in_cap, fan, out->col[l], s->tmp_dst, d_ne, FGNN_SRC_LOCAL,
-                                            s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes, stream);
+                                            d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
+                                            s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream);
     else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
       // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
       rc = fgnn_sample_random_walk(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
-                                   s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], s->tmp_dst, out->data[l],
-                                   d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, s->ws, s->ws_bytes,
+                                   s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
+                                   d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
                                    stream);
     else
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       rc = sample_khop_fused(s->cfg.sample_type == FGNN_KHOP2, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n,
-                             in_cap, fan, out->col[l], s->tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, s->ws,
+                             in_cap, fan, out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws,
                              s->ws_bytes, stream);
     if (rc != FGNN_OK) return rc;
+    if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
+      FGNN_HIP_CHECK(hipEventRecord(s->csr_done, st));
+      s->csr_used = true;
+    }
     const bool inserted = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
-    rc = hashtable_fill_duplicates_ex(ht, s->tmp_dst, 0, d_ne, ecap, out->row[l], s->ws, s->ws_bytes, stream,
+    rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
                                       inserted);
@@ -279,6 +307,8 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     d_cur_n = fgnn_hashtable_d_num_items(ht);
     cur_n_host = 0;
   }
+  FGNN_HIP_CHECK(hipEventRecord(s->slot_done[slot], st));
+  s->slot_used[slot] = true;
   // hand the table to the side stream for wiping; the next batch uses the other table meanwhile
   FGNN_HIP_CHECK(hipEventRecord(s->used[slot], st));
   FGNN_HIP_CHECK(hipStreamWaitEvent(s->reset_stream, s->used[slot], 0));
