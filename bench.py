@@ -87,6 +87,35 @@ def gen_features_on_gpu(num_node, dim, device):
     return feat
 
 
+def reduce_over_ranks(elapsed, edges, rows, device=None):
+    """Contract: time = MAX over ranks, work = SUM over ranks (no other collective touches the data path)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return elapsed, edges, rows
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    e = torch.tensor([edges, rows], dtype=torch.float64, device=device)
+    dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    return float(t[0]), float(e[0]), float(e[1])
+
+
+def local_step_range(steps_per_epoch, rank, world):
+    """First step and count of this rank's contiguous step range (DistShuffler, dist/dist_shuffler.cc:59-79)."""
+    first = (steps_per_epoch // world) * rank
+    count = steps_per_epoch - first if rank == world - 1 else steps_per_epoch // world
+    return first, count
+
+
+def pmc_traffic_ratio():
+    """HBM bytes / algorithmic bytes of the feature gather, from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_over_algorithmic"]
+    except Exception:
+        return None
+
+
 def algorithmic_bytes(metas, feat_dim, batch_size):
     """per batch, 4-byte ids.  Returns dict of per-stage algorithmic bytes (sums)."""
     sample = dedup = split = gather = 0
@@ -103,9 +132,11 @@ def algorithmic_bytes(metas, feat_dim, batch_size):
     return dict(sample=sample, dedup_remap=dedup, cache_split=split, gather=gather)
 
 
-def cpu_baseline(w, indptr, indices, feat, train, steps_budget_s=20.0):
-    """The reference's CPU sampling path restated in oracle/ (CPUSampleKHop2 + CPUHashTable2 + CPUExtract,
-    cpu/cpu_loops.cc:55-227), timed on this host on a bounded number of batches of the same workload."""
+def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
+    """The reference's CPU sampling path (CPUSampleKHop2 + CPUHashTable2 + CPUExtract driven as DoCPUSample /
+    DoFeatureExtract, cpu/cpu_loops.cc:55-227) restated in oracle/ and timed on this host on a bounded number of
+    batches of the same workload: once multi-threaded like the reference runs it (OpenMP, static schedules,
+    per-thread mt19937) and once with the single-thread variant that is pinned bit-exactly to the reference."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as oracle
     oracle.build()
@@ -117,32 +148,40 @@ def cpu_baseline(w, indptr, indices, feat, train, steps_budget_s=20.0):
     copy_s = time.time() - t0
     num_node = h_indptr.shape[0] - 1
     fan, bs = w["fanout"], w["batch_size"]
-    ht = oracle.HashTable(num_node, oracle.predict_num_nodes(bs, fan))
-    rng = oracle.make_rng(oracle.RNG_MT_CPU_TWIN)
+    cap = oracle.predict_num_nodes(bs, fan)
     h_train = train.cpu().numpy().view(np.uint32)
-    edges = rows = 0
-    t_sample = t_extract = 0.0
-    nb = 0
-    mask = np.uint32((1 << mock_bits) - 1)
-    while t_sample + t_extract < steps_budget_s and (nb + 1) * bs <= len(h_train):
-        seeds = h_train[nb * bs:(nb + 1) * bs]
-        t1 = time.time()
-        task = oracle.do_sample(h_indptr, h_indices, seeds, fan, oracle.KHOP2, rng, nb, ht)
-        t2 = time.time()
-        oracle.extract(h_feat, task["input_nodes"] & mask)
-        t3 = time.time()
-        t_sample += t2 - t1
-        t_extract += t3 - t2
-        edges += task["total_edges"]
-        rows += len(task["input_nodes"])
-        nb += 1
+    mask = (1 << mock_bits) - 1
+    out = np.empty((cap, h_feat.shape[1]), dtype=np.float32)
+    threads = int(os.environ.get("FGNN_CPU_BASELINE_THREADS", max(1, (os.cpu_count() or 2) // 2)))
+    res = {}
+    for label, T in (("omp", threads), ("single", 1)):
+        ctx = oracle.OmpBaseline(num_node, cap, T)
+        edges = rows = nb = 0
+        t_total = 0.0
+        warm = 2  # untimed: OpenMP thread-pool start-up and first touch of the tables
+        k = 0
+        while t_total < budget_s and (k + 1) * bs <= len(h_train):
+            seeds = np.ascontiguousarray(h_train[k * bs:(k + 1) * bs])
+            t1 = time.time()
+            e, n_in = ctx.sample_batch(h_indptr, h_indices, seeds, fan, h_feat, mask, out)
+            dt = time.time() - t1
+            k += 1
+            if k <= warm:
+                continue
+            t_total += dt
+            edges += e
+            rows += n_in
+            nb += 1
+        res[label] = dict(threads=T, batches=nb, seconds=t_total, edges_per_s=edges / t_total, rows_per_s=rows / t_total)
+    best = res["omp"] if res["omp"]["edges_per_s"] >= res["single"]["edges_per_s"] else res["single"]
     return {
-        "value": edges / (t_sample + t_extract), "unit": "sampled-edges/s", "cores": 1, "kind": "port",
-        "sample": f"{nb} batches of {bs} seeds, fanout {fan}, same graph; sample+dedup+remap {t_sample:.2f}s, "
-                  f"extract {t_extract:.2f}s (feature table masked to 2^{mock_bits} rows like SAMGRAPH_EMPTY_FEAT); "
-                  f"host copy of CSR/features {copy_s:.1f}s not counted; single-thread oracle "
-                  f"(CPUSampleKHop2 + CPUHashTable2 + CPUExtract restatement, mt19937 twin mode)",
-        "sample_only_edges_per_s": edges / t_sample, "extract_rows_per_s": rows / max(t_extract, 1e-9),
+        "value": best["edges_per_s"], "unit": "sampled-edges/s", "cores": best["threads"], "kind": "port",
+        "sample": f"{best['batches']} batches of {bs} seeds, fanout {fan}, same graph, whole path (sample + dedup + remap "
+                  f"+ feature gather) in {best['seconds']:.1f}s with {best['threads']} OpenMP threads; single thread: "
+                  f"{res['single']['edges_per_s']:.3e} edges/s; feature table masked to 2^{mock_bits} rows like "
+                  f"SAMGRAPH_EMPTY_FEAT; host copy of CSR/features {copy_s:.1f}s not counted; oracle restatement of "
+                  f"CPUSampleKHop2 + CPUHashTable2 + CPUExtract",
+        "rows_per_s": best["rows_per_s"], "single_thread_edges_per_s": res["single"]["edges_per_s"],
         "host_cpus": os.cpu_count(),
     }
 
@@ -193,7 +232,7 @@ def main():
     train = train[torch.randperm(train.numel(), generator=g, device=dev)]
     bs = w["batch_size"]
     steps_per_epoch = (train.numel() + bs - 1) // bs
-    local_first = (steps_per_epoch // world) * rank
+    local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
     sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
     NBUF = 4
@@ -270,13 +309,9 @@ def main():
     gather_avg_ms = float(np.mean(gather_ms))
     achieved = gather_feat_bytes / len(metas) / (gather_avg_ms * 1e-3) / 1e9
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        e = torch.tensor([edges, rows], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.SUM)
-        elapsed, edges, rows = float(t[0]), float(e[0]), float(e[1])
+    elapsed, edges, rows = reduce_over_ranks(elapsed, edges, rows, dev)
 
+    ratio = pmc_traffic_ratio()
     if rank == 0:
         out = {
             "metric": "sampled-edges/sec (GraphSAGE fanout 25/10, batch 8000, full hot path: sample + dedup + remap + "
@@ -290,7 +325,11 @@ def main():
                                    f"1 process per GPU, full replica per GPU, disjoint step ranges",
                        "global_batch": bs * world, "parallelism": f"dp{world} (independent samplers)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (gather_feat_bytes / len(metas) * ratio) if ratio else None,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "separate passes; per-launch bytes = measured ratio x this run's "
+                                           "algorithmic bytes)",
                          "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
                          "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas)},
             "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps / world,

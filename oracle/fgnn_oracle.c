@@ -616,3 +616,171 @@ void fgnn_oracle_dist_shuffler_partition(size_t num_data, size_t batch_size, int
   }
   *last_batch_size = last;
 }
+
+/* ------------------------------------------------------------------ OpenMP CPU baseline -----
+ * The reference's CPU sampling path as it actually runs with omp_thread_num > 1
+ * (cpu/cpu_sampling_khop2.cc:29-76 with a thread_local default-seeded mt19937 per thread,
+ * cpu/cpu_random.cc:26-30; cpu/cpu_hashtable2.cc:53-194 Populate/MapNodes/MapEdges with static
+ * schedules; cpu/cpu_extraction.cc:31-49).  Used ONLY as the timed cpu_baseline of bench.py: with
+ * more than one thread its output depends on the thread count exactly like the reference's does
+ * (every thread replays the same mt19937 stream; CAS winners are arbitrary), so it is checked for
+ * invariants, not bit-exactness. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { uint32_t key, index, local, version; } omp_bucket;
+
+struct fgnn_omp_ctx {
+  omp_bucket *o2n;     /* [num_node], direct-indexed like CPUHashTable2 */
+  uint32_t *n2o;
+  size_t num_node, capacity, num_items;
+  uint32_t version;
+  int threads;
+  fgnn_mt19937 *mt;    /* one generator per thread, all default-seeded (thread_local in the reference) */
+};
+
+fgnn_omp_ctx *fgnn_omp_create(size_t num_node, size_t capacity, int threads) {
+  fgnn_omp_ctx *c = (fgnn_omp_ctx *)calloc(1, sizeof(*c));
+  c->o2n = (omp_bucket *)malloc(sizeof(omp_bucket) * num_node);
+  c->n2o = (uint32_t *)malloc(sizeof(uint32_t) * capacity);
+  c->num_node = num_node;
+  c->capacity = capacity;
+  c->threads = threads > 0 ? threads : 1;
+  c->mt = (fgnn_mt19937 *)malloc(sizeof(fgnn_mt19937) * (size_t)c->threads);
+  for (int t = 0; t < c->threads; ++t) fgnn_mt19937_seed(&c->mt[t], 5489u);
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+  for (size_t i = 0; i < num_node; ++i) c->o2n[i].key = FGNN_EMPTY_KEY;
+  return c;
+}
+
+void fgnn_omp_destroy(fgnn_omp_ctx *c) {
+  if (!c) return;
+  free(c->o2n); free(c->n2o); free(c->mt); free(c);
+}
+
+static void omp_reset(fgnn_omp_ctx *c) {
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+  for (size_t i = 0; i < c->num_items; ++i) c->o2n[c->n2o[i]].key = FGNN_EMPTY_KEY;
+  c->num_items = 0;
+  c->version = 0;
+}
+
+static void omp_populate(fgnn_omp_ctx *c, const uint32_t *input, size_t n) {
+  const int T = c->threads;
+  size_t *cnt = (size_t *)calloc((size_t)T * 8 + 8, sizeof(size_t));
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t id = input[i];
+    if (__sync_val_compare_and_swap(&c->o2n[id].key, FGNN_EMPTY_KEY, id) == FGNN_EMPTY_KEY) {
+      c->o2n[id].index = (uint32_t)i;
+      c->o2n[id].version = c->version;
+    }
+  }
+#pragma omp parallel num_threads(T)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    size_t local = 0;
+#pragma omp for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+      const omp_bucket *b = &c->o2n[input[i]];
+      if (b->index == i && b->version == c->version) ++local;
+    }
+    cnt[(size_t)t * 8] = local;
+  }
+  size_t prefix = 0;
+  for (int t = 0; t < T; ++t) { const size_t v = cnt[(size_t)t * 8]; cnt[(size_t)t * 8] = prefix; prefix += v; }
+  const size_t start = c->num_items;
+#pragma omp parallel num_threads(T)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    size_t off = cnt[(size_t)t * 8];
+#pragma omp for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+      omp_bucket *b = &c->o2n[input[i]];
+      if (b->index == i && b->version == c->version) {
+        const uint32_t id = (uint32_t)(start + off++);
+        b->local = id;
+        c->n2o[id] = input[i];
+      }
+    }
+  }
+  c->num_items += prefix;
+  c->version++;
+  free(cnt);
+}
+
+/* DoCPUSample + DoFeatureExtract for one batch (cpu/cpu_loops.cc:55-227) with khop2.
+ * Returns the number of sampled edges; *num_input_nodes gets |input_nodes|.  feat_out (may be NULL)
+ * receives the gathered rows, indexed through `feat_row_mask` like CPUMockExtract. */
+size_t fgnn_omp_sample_batch(fgnn_omp_ctx *c, const uint32_t *indptr, uint32_t *indices, const uint32_t *seeds,
+                             size_t num_seeds, const size_t *fanout, size_t num_layers, const float *feat,
+                             size_t feat_dim, uint32_t feat_row_mask, float *feat_out, size_t *num_input_nodes) {
+  const int T = c->threads;
+  omp_reset(c);
+  omp_populate(c, seeds, num_seeds);
+  uint32_t *cur = (uint32_t *)malloc(sizeof(uint32_t) * (num_seeds ? num_seeds : 1));
+  memcpy(cur, seeds, sizeof(uint32_t) * num_seeds);
+  size_t num_input = num_seeds, total = 0;
+  for (long l = (long)num_layers - 1; l >= 0; --l) {
+    const size_t F = fanout[l];
+    uint32_t *src = (uint32_t *)malloc(sizeof(uint32_t) * (num_input * F + 1));
+    uint32_t *dst = (uint32_t *)malloc(sizeof(uint32_t) * (num_input * F + 1));
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+      fgnn_mt19937 *g = &c->mt[omp_get_thread_num()];
+#else
+      fgnn_mt19937 *g = &c->mt[0];
+#endif
+#pragma omp for schedule(static)
+      for (size_t i = 0; i < num_input; ++i) {
+        const uint32_t rid = cur[i], off = indptr[rid], len = indptr[rid + 1] - off;
+        uint32_t *s = src + i * F, *d = dst + i * F;
+        if (len <= F) {
+          size_t j = 0;
+          for (; j < len; ++j) { s[j] = rid; d[j] = indices[off + j]; }
+          for (; j < F; ++j) { s[j] = FGNN_EMPTY_KEY; d[j] = FGNN_EMPTY_KEY; }
+        } else {
+          for (size_t j = 0; j < F; ++j) {
+            const uint32_t k = fgnn_mt19937_uniform_int(g, 0, (uint32_t)(len - j - 1));
+            const uint32_t v = indices[off + k];
+            s[j] = rid; d[j] = v;
+            indices[off + k] = indices[off + len - j - 1];
+            indices[off + len - j - 1] = v;
+          }
+        }
+      }
+    }
+    const size_t num_out = compact_padded(src, dst, num_input * F);  /* single-thread remove_if, khop2.cc:66-75 */
+    omp_populate(c, dst, num_out);
+    const size_t num_unique = c->num_items;
+    uint32_t *unique = (uint32_t *)malloc(sizeof(uint32_t) * (num_unique + 1));
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (size_t i = 0; i < num_unique; ++i) unique[i] = c->n2o[i];
+    uint32_t *ns = (uint32_t *)malloc(sizeof(uint32_t) * (num_out + 1));
+    uint32_t *nd = (uint32_t *)malloc(sizeof(uint32_t) * (num_out + 1));
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (size_t i = 0; i < num_out; ++i) { ns[i] = c->o2n[src[i]].local; nd[i] = c->o2n[dst[i]].local; }
+    total += num_out;
+    free(src); free(dst); free(ns); free(nd); free(cur);
+    cur = unique;
+    num_input = num_unique;
+  }
+  if (feat && feat_out) {
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (size_t i = 0; i < num_input; ++i)
+      memcpy(feat_out + i * feat_dim, feat + (size_t)(cur[i] & feat_row_mask) * feat_dim, feat_dim * sizeof(float));
+  }
+  *num_input_nodes = num_input;
+  free(cur);
+  return total;
+}

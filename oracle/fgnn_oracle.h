@@ -213,6 +213,16 @@ void fgnn_oracle_dist_shuffler_partition(size_t num_data, size_t batch_size, int
 
 size_t fgnn_dtype_bytes(int dtype);
 
+/* ---------------------------------------------------------------- OpenMP CPU baseline -------
+ * The reference's multi-threaded CPU path (khop2 + CPUHashTable2 + CPUExtract, cpu/cpu_loops.cc:55-227),
+ * for bench.py's cpu_baseline timing only; see fgnn_oracle.c. */
+typedef struct fgnn_omp_ctx fgnn_omp_ctx;
+fgnn_omp_ctx *fgnn_omp_create(size_t num_node, size_t capacity, int threads);
+void fgnn_omp_destroy(fgnn_omp_ctx *c);
+size_t fgnn_omp_sample_batch(fgnn_omp_ctx *c, const uint32_t *indptr, uint32_t *indices, const uint32_t *seeds,
+                             size_t num_seeds, const size_t *fanout, size_t num_layers, const float *feat,
+                             size_t feat_dim, uint32_t feat_row_mask, float *feat_out, size_t *num_input_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,3 +285,33 @@ def dist_shuffler_partition(num_data, batch_size, sampler_id, num_sampler):
                                               C.c_int(num_sampler), *[C.byref(x) for x in v])
     return dict(dataset_offset=v[0].value, num_local_step=v[1].value, local_data_size=v[2].value,
                 last_batch_size=v[3].value, epoch_step=v[4].value)
+
+
+class OmpBaseline:
+    """The reference's OpenMP CPU path (see fgnn_oracle.c, 'OpenMP CPU baseline'); timing only."""
+
+    def __init__(self, num_node, capacity, threads):
+        L = lib()
+        L.fgnn_omp_create.restype = C.c_void_p
+        L.fgnn_omp_create.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+        L.fgnn_omp_sample_batch.restype = C.c_size_t
+        self.h = C.c_void_p(L.fgnn_omp_create(num_node, capacity, threads))
+        self.threads = threads
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fgnn_omp_destroy(self.h)
+            self.h = None
+
+    def sample_batch(self, indptr, indices, seeds, fanout, feat=None, feat_row_mask=0xFFFFFFFF, feat_out=None):
+        fo = (C.c_size_t * len(fanout))(*fanout)
+        n_in = C.c_size_t(0)
+        P = C.POINTER(C.c_uint32)
+        fp = feat.ctypes.data_as(C.c_void_p) if feat is not None else None
+        fo_p = feat_out.ctypes.data_as(C.c_void_p) if feat_out is not None else None
+        dim = feat.shape[1] if feat is not None else 0
+        edges = lib().fgnn_omp_sample_batch(self.h, indptr.ctypes.data_as(P), indices.ctypes.data_as(P),
+                                            seeds.ctypes.data_as(P), C.c_size_t(len(seeds)), fo,
+                                            C.c_size_t(len(fanout)), fp, C.c_size_t(dim), C.c_uint32(feat_row_mask),
+                                            fo_p, C.byref(n_in))
+        return edges, n_in.value
