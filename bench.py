@@ -202,7 +202,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
     ap.add_argument("--cache-ratio", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="sample and extract on one stream")
+    ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
+    ap.add_argument("--host-threads", type=int, default=2, help="host threads = HIP streams = batches in flight")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
     args = ap.parse_args()
 
@@ -243,74 +244,79 @@ def main():
     local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
     sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
-    NBUF = 4
+    NT = 1 if args.no_overlap else args.host_threads
+    NBUF = 2 * NT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
-    # Two HIP streams, whole batches alternate between them: the chain of batch i+1 (latency-bound sampling /
-    # dedup kernels) overlaps the tail of batch i (bandwidth-bound feature gather).  khop2's in-place CSR swaps
-    # keep their batch order through an event inside fgnn_sampler_sample, so results do not change.
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    if args.no_overlap:
-        streams[1] = streams[0]
+    for bt in batches:
+        bt.enable_timing(True)  # HIP events around the feature gather, on the stream it is launched on
+    # NT host threads, each with its own HIP stream, take batches round-robin (batch i -> thread i % NT): whole
+    # batches overlap -- the latency-bound sampling/dedup chain of one with the bandwidth-bound gather of another.
+    # fgnn_sampler_run_batch is thread-safe and keeps khop2's in-place CSR swaps in batch order (sequence numbers),
+    # so the results are the same as a serial run.  (The reference also overlaps its sample and copy loops.)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NT)]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    ev_pairs = []
-    host_enqueue = [0.0]
+    import threading
+    metas, gather_ms, host_busy = [], [], [0.0] * NT
+    lock = threading.Lock()
 
-    def run_step(i, timed):
+    def seeds_of(i):
         step = (local_first + i) % steps_per_epoch
-        seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
-        bt = batches[i % NBUF]
-        if i >= NBUF:
-            bt.wait()  # its buffers are about to be reused; the summary was already collected
-        t_h = time.perf_counter()
-        st = streams[i % 2]
-        with torch.cuda.stream(st):
-            sampler.sample(seeds, step, bt)
-            bt.cache_index(table)
+        return step, train[step * bs:min(train.numel(), (step + 1) * bs)]
+
+    def worker(t, first, last, timed):
+        torch.cuda.set_device(dev)
+        mine, gm = [], []
+        for i in range(first + ((t - first) % NT), last, NT):
+            bt = batches[i % NBUF]
+            if i - first >= NBUF:           # buffer reuse: collect the summary of the batch that used it
+                m = bt.wait()
+                if timed:
+                    mine.append(m)
+                    gm.append(bt.gather_ms())
+            step, seeds = seeds_of(i)
+            t_h = time.perf_counter()
+            sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[t])
+            host_busy[t] += time.perf_counter() - t_h
+        for i in range(max(first, last - NBUF) + ((t - max(first, last - NBUF)) % NT), last, NT):
+            m = batches[i % NBUF].wait()
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(st)
-                bt.extract(feat, None)
-                e1.record(st)
-                ev_pairs.append((e0, e1))
-            else:
-                bt.extract(feat, None)
-            bt.extract(None, label)
-            bt.finish()
-        if timed:
-            host_enqueue[0] += time.perf_counter() - t_h
-        return bt
+                mine.append(m)
+                gm.append(batches[i % NBUF].gather_ms())
+        with lock:
+            metas.extend(mine)
+            gather_ms.extend(gm)
+
+    def run_region(first, last, timed):
+        ths = [threading.Thread(target=worker, args=(t, first, last, timed)) for t in range(NT)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for i in range(args.warmup):
-        run_step(i, False)
+    run_region(0, args.warmup, False)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    metas = []
+    host_busy = [0.0] * NT
     t0 = time.perf_counter()
-    pending = []
-    for i in range(args.warmup, args.warmup + args.steps):
-        bt = run_step(i, True)
-        pending.append(bt)
-        if len(pending) == NBUF:  # collect the oldest summary while newer steps run
-            metas.append(pending.pop(0).wait())
-    for bt in pending:
-        metas.append(bt.wait())
+    run_region(args.warmup, args.warmup + args.steps, True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    assert len(metas) == args.steps, (len(metas), args.steps)
 
     # metas hold ctypes structs that alias nothing (copied by value in wait())
     edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
     rows = sum(int(m.num_input) for m in metas)
     overflow = any(m.overflow for m in metas)
-    gather_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    gather_ms = [g for g in gather_ms if g >= 0]
     ab = algorithmic_bytes(metas, w["feat_dim"], bs)
     # dominant kernel = feature gather: U*(4 + 8*D) bytes per launch (index read + row read + row write)
     gather_feat_bytes = sum(int(m.num_input) * (4 + 8 * w["feat_dim"]) for m in metas)
@@ -346,7 +352,7 @@ def main():
             "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
             if world == 1 else None,
             "overflow": bool(overflow), "setup_s": t_setup,
-            "host_enqueue_ms_per_step": host_enqueue[0] / args.steps * 1e3,
+            "host_threads": NT, "host_enqueue_ms_per_step": sum(host_busy) / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)

@@ -4,31 +4,44 @@
 //
 // Everything a batch needs is enqueued on one stream with device-resident sizes; the host gets one
 // pinned fgnn_batch_meta per batch.  Bit-identical to oracle fgnn_oracle_do_sample.
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "fgnn_device.h"
 
+constexpr int kSlots = 4;  // batches that may be in flight at once (each on its own stream if the caller wishes)
+
 struct fgnn_sampler {
   fgnn_sampler_config cfg;
-  // two dedup tables used alternately: while batch k samples into one, the other is wiped on a side
-  // stream (the reference wipes its single 128 MiB table on the critical path, cuda_hashtable.cu:714-723)
-  fgnn_hashtable *ht[2];
-  hipStream_t reset_stream;
-  hipEvent_t used[2], wiped[2];
-  bool wipe_pending[2];
-  uint64_t batch_counter;
   size_t max_nodes;                       // PredictNumNodes(batch, fanout, L)
   size_t in_cap[FGNN_MAX_LAYERS];         // worst-case #seeds of layer l
   size_t edge_cap[FGNN_MAX_LAYERS];       // worst-case #edges of layer l
   size_t max_edge_cap;
-  // Two batches may be in flight (on two streams): each slot has its own table, scratch and temporaries.
-  uint32_t *tmp_dst[2];                   // [max_edge_cap] sampled neighbours (global ids)
-  void *ws[2];                            // kernel scratch
   size_t ws_bytes;
-  hipEvent_t slot_done[2];                // last use of a slot's scratch by sample()
-  hipEvent_t csr_done;                    // khop2 mutates the CSR: samplers of consecutive batches are ordered
-  bool slot_used[2], csr_used;
+  // Per in-flight batch ("slot" = sequence number % kSlots): its own dedup table, scratch and temporaries.
+  // A table is wiped on the slot's side stream after use, off the critical path (the reference wipes its
+  // single 128 MiB table at the start of every batch, cuda_hashtable.cu:714-723).
+  struct Slot {
+    fgnn_hashtable *ht = nullptr;
+    uint32_t *tmp_dst = nullptr;          // [max_edge_cap] sampled neighbours (global ids)
+    void *ws = nullptr;                   // kernel scratch
+    hipStream_t reset_stream = nullptr;
+    hipEvent_t used = nullptr, wiped = nullptr, done = nullptr, csr = nullptr;
+    bool wipe_pending = false, was_used = false;
+  } slot[kSlots];
+  // host-side sequencing (calls may come from several threads, one per stream): call `seq` may start once
+  // call seq - kSlots has returned; for khop2 (which swaps CSR entries in place) the sampler kernels of call
+  // seq are enqueued only after call seq - 1 has enqueued its last sampler kernel, so the CSR is mutated in
+  // batch order no matter how the batches overlap.
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next_seq = 0;                  // for the unordered entry point
+  uint64_t returned = 0;                  // calls [0, returned) have returned
+  uint64_t csr_passed = 0;                // calls [0, csr_passed) have enqueued their last sampler kernel
+  bool done_flag[kSlots] = {false, false, false, false};
+  bool csr_flag[kSlots] = {false, false, false, false};
 };
 
 struct fgnn_batch {
@@ -44,6 +57,8 @@ struct fgnn_batch {
   void *ws;                               // scratch for the cache split
   size_t ws_bytes;
   hipEvent_t done;
+  hipEvent_t t0, t1;                      // optional: bracket the feature gather (fgnn_batch_enable_timing)
+  bool timing, timed;
 };
 
 namespace fgnn {
@@ -88,15 +103,6 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
-  s->ht[0] = s->ht[1] = nullptr;
-  s->tmp_dst[0] = s->tmp_dst[1] = nullptr;
-  s->ws[0] = s->ws[1] = nullptr;
-  s->slot_done[0] = s->slot_done[1] = s->csr_done = nullptr;
-  s->slot_used[0] = s->slot_used[1] = s->csr_used = false;
-  s->reset_stream = nullptr;
-  s->used[0] = s->used[1] = s->wiped[0] = s->wiped[1] = nullptr;
-  s->wipe_pending[0] = s->wipe_pending[1] = false;
-  s->batch_counter = 0;
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -109,20 +115,6 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   }
   s->max_nodes = count;
   if (s->max_edge_cap >= 0x7fffffffull || s->max_nodes >= 0x7fffffffull) { delete s; return fail(FGNN_EINVAL); }
-  int err = FGNN_OK;
-  for (int k = 0; k < 2; ++k) {
-    s->ht[k] = fgnn_hashtable_create(s->max_nodes, &err);
-    if (!s->ht[k]) { fgnn_sampler_destroy(s); return fail(err); }
-    if (hipEventCreateWithFlags(&s->used[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->wiped[k], hipEventDisableTiming) != hipSuccess) {
-      fgnn_sampler_destroy(s);
-      return fail(FGNN_EHIP);
-    }
-  }
-  if (hipStreamCreateWithFlags(&s->reset_stream, hipStreamNonBlocking) != hipSuccess) {
-    fgnn_sampler_destroy(s);
-    return fail(FGNN_EHIP);
-  }
   // dedup scratch (pos + sums) plus the fused sampler's own block offsets behind it
   s->ws_bytes = 2 * fgnn_scratch_bytes(s->max_edge_cap > s->max_nodes ? s->max_edge_cap : s->max_nodes) +
                 (s->max_edge_cap / 16 + 64) * sizeof(uint32_t);
@@ -132,17 +124,19 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
-  for (int k = 0; k < 2; ++k) {
-    if (hipMalloc(&s->tmp_dst[k], s->max_edge_cap * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&s->ws[k], s->ws_bytes) != hipSuccess ||
-        hipEventCreateWithFlags(&s->slot_done[k], hipEventDisableTiming) != hipSuccess) {
+  for (auto &sl : s->slot) {
+    int err = FGNN_OK;
+    sl.ht = fgnn_hashtable_create(s->max_nodes, &err);
+    bool ok = sl.ht != nullptr;
+    ok = ok && hipMalloc(&sl.tmp_dst, s->max_edge_cap * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&sl.reset_stream, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t *e : {&sl.used, &sl.wiped, &sl.done, &sl.csr})
+      ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
       fgnn_sampler_destroy(s);
-      return fail(FGNN_EHIP);
+      return fail(err != FGNN_OK ? err : FGNN_EHIP);
     }
-  }
-  if (hipEventCreateWithFlags(&s->csr_done, hipEventDisableTiming) != hipSuccess) {
-    fgnn_sampler_destroy(s);
-    return fail(FGNN_EHIP);
   }
   if (h_err) *h_err = FGNN_OK;
   return s;
@@ -150,21 +144,17 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
 
 extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   if (!s) return;
-  if (s->reset_stream) {
-    (void)hipStreamSynchronize(s->reset_stream);
-    (void)hipStreamDestroy(s->reset_stream);
+  for (auto &sl : s->slot) {
+    if (sl.reset_stream) {
+      (void)hipStreamSynchronize(sl.reset_stream);
+      (void)hipStreamDestroy(sl.reset_stream);
+    }
+    if (sl.ht) fgnn_hashtable_destroy(sl.ht);
+    if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
+    if (sl.ws) (void)hipFree(sl.ws);
+    for (hipEvent_t e : {sl.used, sl.wiped, sl.done, sl.csr})
+      if (e) (void)hipEventDestroy(e);
   }
-  for (int k = 0; k < 2; ++k) {
-    if (s->ht[k]) fgnn_hashtable_destroy(s->ht[k]);
-    if (s->used[k]) (void)hipEventDestroy(s->used[k]);
-    if (s->wiped[k]) (void)hipEventDestroy(s->wiped[k]);
-  }
-  for (int k = 0; k < 2; ++k) {
-    if (s->tmp_dst[k]) (void)hipFree(s->tmp_dst[k]);
-    if (s->ws[k]) (void)hipFree(s->ws[k]);
-    if (s->slot_done[k]) (void)hipEventDestroy(s->slot_done[k]);
-  }
-  if (s->csr_done) (void)hipEventDestroy(s->csr_done);
   delete s;
 }
 
@@ -190,6 +180,8 @@ extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
   if (b->h_meta) (void)hipHostFree(b->h_meta);
   if (b->ws) (void)hipFree(b->ws);
   if (b->done) (void)hipEventDestroy(b->done);
+  if (b->t0) (void)hipEventDestroy(b->t0);
+  if (b->t1) (void)hipEventDestroy(b->t1);
   delete b;
 }
 
@@ -238,26 +230,71 @@ extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim,
   return b;
 }
 
-extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
-                                   fgnn_batch *out, void *stream) {
+namespace {
+
+// marks the hand-over points of call `seq` even on an early error return, so later calls never wait forever
+struct SeqGuard {
+  fgnn_sampler *s;
+  uint64_t seq;
+  bool csr_marked = false;
+  void mark_csr() {
+    if (csr_marked) return;
+    csr_marked = true;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->csr_flag[seq % kSlots] = true;
+    while (s->csr_flag[s->csr_passed % kSlots]) {
+      s->csr_flag[s->csr_passed % kSlots] = false;
+      ++s->csr_passed;
+    }
+    s->cv.notify_all();
+  }
+  ~SeqGuard() {
+    mark_csr();
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->done_flag[seq % kSlots] = true;
+    while (s->done_flag[s->returned % kSlots]) {
+      s->done_flag[s->returned % kSlots] = false;
+      ++s->returned;
+    }
+    s->cv.notify_all();
+  }
+};
+
+}  // namespace
+
+extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                           uint64_t batch_key, fgnn_batch *out, void *stream) {
   if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
     return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
   const size_t L = s->cfg.num_layers;
-  const int slot = (int)(s->batch_counter++ & 1);
-  fgnn_hashtable *ht = s->ht[slot];
-  out->num_output = num_seeds;
-  uint32_t *tmp_dst = s->tmp_dst[slot];
-  void *ws = s->ws[slot];
-  // the slot's scratch was last used two batches ago, possibly on another stream
-  if (s->slot_used[slot]) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot_done[slot], 0));
-  // khop2 swaps CSR entries in place: its kernels must run in batch order even when batches overlap
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
-  if (mutates && s->csr_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->csr_done, 0));
-  // this batch's table was wiped on the side stream after its previous use
-  if (s->wipe_pending[slot]) {
-    FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->wiped[slot], 0));
-    s->wipe_pending[slot] = false;
+  {
+    // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return seq < s->returned + kSlots; });
+    if (seq < s->returned) return FGNN_EINVAL;  // sequence numbers must be used once, in a window of kSlots
+  }
+  SeqGuard guard{s, seq};
+  fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+  fgnn_hashtable *ht = sl.ht;
+  uint32_t *tmp_dst = sl.tmp_dst;
+  void *ws = sl.ws;
+  out->num_output = num_seeds;
+  // the slot's scratch was last used kSlots batches ago, possibly on another stream
+  if (sl.was_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+  // its table was wiped on the side stream after that use
+  if (sl.wipe_pending) {
+    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.wiped, 0));
+    sl.wipe_pending = false;
+  }
+  if (mutates && seq > 0) {
+    // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [&] { return s->csr_passed >= seq; });
+    }
+    FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
   int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
@@ -287,13 +324,12 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
                                    stream);
     else
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
-      rc = sample_khop_fused(s->cfg.sample_type == FGNN_KHOP2, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n,
-                             in_cap, fan, out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws,
-                             s->ws_bytes, stream);
+      rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
+                             tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream);
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
-      FGNN_HIP_CHECK(hipEventRecord(s->csr_done, st));
-      s->csr_used = true;
+      FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+      guard.mark_csr();
     }
     const bool inserted = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
@@ -307,16 +343,39 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     d_cur_n = fgnn_hashtable_d_num_items(ht);
     cur_n_host = 0;
   }
-  FGNN_HIP_CHECK(hipEventRecord(s->slot_done[slot], st));
-  s->slot_used[slot] = true;
-  // hand the table to the side stream for wiping; the next batch uses the other table meanwhile
-  FGNN_HIP_CHECK(hipEventRecord(s->used[slot], st));
-  FGNN_HIP_CHECK(hipStreamWaitEvent(s->reset_stream, s->used[slot], 0));
-  rc = fgnn_hashtable_reset(ht, s->reset_stream);
+  if (mutates && num_seeds == 0) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+  FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
+  sl.was_used = true;
+  // hand the table to the side stream for wiping; later batches use the other tables meanwhile
+  FGNN_HIP_CHECK(hipEventRecord(sl.used, st));
+  FGNN_HIP_CHECK(hipStreamWaitEvent(sl.reset_stream, sl.used, 0));
+  rc = fgnn_hashtable_reset(ht, sl.reset_stream);
   if (rc != FGNN_OK) return rc;
-  FGNN_HIP_CHECK(hipEventRecord(s->wiped[slot], s->reset_stream));
-  s->wipe_pending[slot] = true;
+  FGNN_HIP_CHECK(hipEventRecord(sl.wiped, sl.reset_stream));
+  sl.wipe_pending = true;
   return launch_status(__func__);
+}
+
+extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                                   fgnn_batch *out, void *stream) {
+  if (!s) return FGNN_EINVAL;
+  uint64_t seq;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    seq = s->next_seq++;
+  }
+  return fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
+}
+
+// whole batch in one call: sample -> [cache index] -> extract -> summary copy (saves host round trips per step)
+extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                      uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
+                                      const void *feat, const void *label, void *stream) {
+  int rc = fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
+  if (rc == FGNN_OK && cache_table) rc = fgnn_batch_cache_index(out, cache_table, stream);
+  if (rc == FGNN_OK && (feat || label)) rc = fgnn_batch_extract(out, feat, label, stream);
+  if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
+  return rc;
 }
 
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
@@ -327,12 +386,36 @@ extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table
                                    b->ws_bytes, stream);
 }
 
+extern "C" int fgnn_batch_enable_timing(fgnn_batch *b, int on) {
+  if (!b) return FGNN_EINVAL;
+  if (on && !b->t0) {
+    FGNN_HIP_CHECK(hipEventCreate(&b->t0));
+    FGNN_HIP_CHECK(hipEventCreate(&b->t1));
+  }
+  b->timing = on != 0;
+  b->timed = false;
+  return FGNN_OK;
+}
+
+extern "C" float fgnn_batch_gather_ms(fgnn_batch *b) {
+  float ms = -1.0f;
+  if (b && b->timed && hipEventElapsedTime(&ms, b->t0, b->t1) != hipSuccess) ms = -1.0f;
+  return ms;
+}
+
 extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream) {
   if (!b || !b->feat_dim) return FGNN_EINVAL;
   int rc = FGNN_OK;
-  if (feat)
+  auto st = static_cast<hipStream_t>(stream);
+  if (feat) {
+    if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
     rc = fgnn_gather_rows(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
                           b->feat_dim, b->feat_dtype, stream);
+    if (b->timing) {
+      FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
+      b->timed = true;
+    }
+  }
   if (rc == FGNN_OK && label && b->num_output)
     rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
                           b->label_dtype, stream);

@@ -264,7 +264,8 @@ KHOP0, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2 = 0, 3, 4, 5
 
 EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
-    "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_batch_cache_index", "fgnn_batch_extract",
+    "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_sampler_sample_ordered",
+    "fgnn_sampler_run_batch", "fgnn_batch_enable_timing", "fgnn_batch_gather_ms", "fgnn_batch_cache_index", "fgnn_batch_extract",
     "fgnn_batch_extract_cached", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta",
@@ -350,10 +351,25 @@ class Sampler:
     def new_batch(self, feat_dim=0, feat_dtype=F32, label_dtype=I64, feat_rows_cap=0):
         return Batch(self, feat_dim, feat_dtype, label_dtype, feat_rows_cap)
 
-    def sample(self, seeds, batch_key, batch):
+    def sample(self, seeds, batch_key, batch, seq=None):
+        """seq=None: internal call counter (single-threaded use); else the explicit batch order (thread-safe)."""
         _need_gpu(seeds)
-        _check(load().fgnn_sampler_sample(self.h, _ptr(seeds), C.c_size_t(seeds.numel()), C.c_uint64(batch_key),
-                                          batch.h, _stream()), "fgnn_sampler_sample")
+        if seq is None:
+            _check(load().fgnn_sampler_sample(self.h, _ptr(seeds), C.c_size_t(seeds.numel()), C.c_uint64(batch_key),
+                                              batch.h, _stream()), "fgnn_sampler_sample")
+        else:
+            _check(load().fgnn_sampler_sample_ordered(self.h, C.c_uint64(seq), _ptr(seeds), C.c_size_t(seeds.numel()),
+                                                      C.c_uint64(batch_key), batch.h, _stream()),
+                   "fgnn_sampler_sample_ordered")
+
+    def run_batch(self, seq, seeds, batch_key, batch, cache_table=None, feat=None, label=None, stream=None):
+        """sample + cache index + extract + finish in ONE C call on `stream` (a torch stream; default current).
+        Safe to call from several Python threads (ctypes releases the GIL)."""
+        _need_gpu(seeds)
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        _check(load().fgnn_sampler_run_batch(self.h, C.c_uint64(seq), _ptr(seeds), C.c_size_t(seeds.numel()),
+                                             C.c_uint64(batch_key), batch.h, _ptr(cache_table), _ptr(feat),
+                                             _ptr(label), st), "fgnn_sampler_run_batch")
 
 
 class Batch:
@@ -385,6 +401,13 @@ class Batch:
 
     def finish(self):
         _check(load().fgnn_batch_finish(self.h, _stream()), "fgnn_batch_finish")
+
+    def enable_timing(self, on=True):
+        _check(load().fgnn_batch_enable_timing(self.h, C.c_int(1 if on else 0)), "fgnn_batch_enable_timing")
+
+    def gather_ms(self):
+        load().fgnn_batch_gather_ms.restype = C.c_float
+        return float(load().fgnn_batch_gather_ms(self.h))
 
     def wait(self):
         m = BatchMeta()

@@ -204,6 +204,16 @@ void fgnn_batch_destroy(fgnn_batch *b);
  * the seed, data = random-walk visit count.  input_nodes = final unique list. */
 int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
                         fgnn_batch *out, void *stream);
+/* Thread-safe, explicitly ordered variant for overlapping batches: `seq` = 0,1,2,... is the batch's position
+ * in the run; calls may come from several host threads (one per stream) in any timing, the library makes
+ * khop2's in-place CSR swaps happen in `seq` order and keeps at most 4 batches in flight.  fgnn_sampler_sample
+ * is this with an internal counter (do not mix the two on one sampler). */
+int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                uint64_t batch_key, fgnn_batch *out, void *stream);
+/* sample_ordered + cache_index (if cache_table) + extract (if feat/label) + finish in one call. */
+int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                           uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table, const void *feat,
+                           const void *label, void *stream);
 /* DoGetCacheMissIndex on input_nodes against a direct-map table u32[num_node]. */
 int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream);
 /* DoGPUFeatureExtract: feat_out[i,:] = feat[input_nodes[i],:], label_out[i] = label[output_nodes[i]].
@@ -214,6 +224,10 @@ int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void 
  * full_feat is device-accessible (HBM, or pinned / registered host memory read over the host link). */
 int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void *full_feat, const void *label,
                               void *stream);
+/* Optional HIP-event bracket around the feature gather launched by fgnn_batch_extract (on its stream);
+ * fgnn_batch_gather_ms returns the elapsed time of the last bracketed launch after fgnn_batch_wait, or -1. */
+int fgnn_batch_enable_timing(fgnn_batch *b, int on);
+float fgnn_batch_gather_ms(fgnn_batch *b);
 /* async copy of the summary to pinned host memory + event */
 int fgnn_batch_finish(fgnn_batch *b, void *stream);
 /* blocks until the batch's event; copies the summary to *h_meta (may be NULL) */
