@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
     ap.add_argument("--host-threads", type=int, default=2, help="host threads = HIP streams = batches in flight")
+    ap.add_argument("--sample-type", default="khop2", choices=["khop2", "khop0"],
+                    help="khop2 = the reference's default for GraphSAGE (multi_gpu/train_graphsage.py:75)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
     args = ap.parse_args()
 
@@ -243,7 +245,8 @@ def main():
     steps_per_epoch = (train.numel() + bs - 1) // bs
     local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
-    sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=lib.KHOP2, seed=args.seed)
+    sampler = lib.Sampler(indptr, indices, w["fanout"], bs,
+                          sample_type=lib.KHOP2 if args.sample_type == "khop2" else lib.KHOP0, seed=args.seed)
     NT = 1 if args.no_overlap else args.host_threads
     NBUF = 2 * NT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
@@ -334,7 +337,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic power-law CSR, N={w['num_node']}, "
-                                   f"E={num_edge}, feat f32[N,{w['feat_dim']}] resident in HBM, khop2 fanout "
+                                   f"E={num_edge}, feat f32[N,{w['feat_dim']}] resident in HBM, {args.sample_type} fanout "
                                    f"{w['fanout']}, batch {bs}, cache table ratio {args.cache_ratio}, "
                                    f"1 process per GPU, full replica per GPU, disjoint step ranges",
                        "global_batch": bs * world, "parallelism": f"dp{world} (independent samplers)"},

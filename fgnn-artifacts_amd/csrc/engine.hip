@@ -21,15 +21,15 @@ struct fgnn_sampler {
   size_t max_edge_cap;
   size_t ws_bytes;
   // Per in-flight batch ("slot" = sequence number % kSlots): its own dedup table, scratch and temporaries.
-  // A table is wiped on the slot's side stream after use, off the critical path (the reference wipes its
-  // single 128 MiB table at the start of every batch, cuda_hashtable.cu:714-723).
+  // A table is wiped right after its last use in the batch (end of the sampling chain) instead of at the start
+  // of the next batch (cuda_hashtable.cu:714-723): the 64 MiB memset is bandwidth work that overlaps the
+  // latency-bound kernels of the batches running on the other streams.
   struct Slot {
     fgnn_hashtable *ht = nullptr;
     uint32_t *tmp_dst = nullptr;          // [max_edge_cap] sampled neighbours (global ids)
     void *ws = nullptr;                   // kernel scratch
-    hipStream_t reset_stream = nullptr;
-    hipEvent_t used = nullptr, wiped = nullptr, done = nullptr, csr = nullptr;
-    bool wipe_pending = false, was_used = false;
+    hipEvent_t done = nullptr, csr = nullptr;
+    bool was_used = false;
   } slot[kSlots];
   // host-side sequencing (calls may come from several threads, one per stream): call `seq` may start once
   // call seq - kSlots has returned; for khop2 (which swaps CSR entries in place) the sampler kernels of call
@@ -130,8 +130,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     bool ok = sl.ht != nullptr;
     ok = ok && hipMalloc(&sl.tmp_dst, s->max_edge_cap * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&sl.reset_stream, hipStreamNonBlocking) == hipSuccess;
-    for (hipEvent_t *e : {&sl.used, &sl.wiped, &sl.done, &sl.csr})
+    for (hipEvent_t *e : {&sl.done, &sl.csr})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       fgnn_sampler_destroy(s);
@@ -145,14 +144,10 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
 extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   if (!s) return;
   for (auto &sl : s->slot) {
-    if (sl.reset_stream) {
-      (void)hipStreamSynchronize(sl.reset_stream);
-      (void)hipStreamDestroy(sl.reset_stream);
-    }
     if (sl.ht) fgnn_hashtable_destroy(sl.ht);
     if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
     if (sl.ws) (void)hipFree(sl.ws);
-    for (hipEvent_t e : {sl.used, sl.wiped, sl.done, sl.csr})
+    for (hipEvent_t e : {sl.done, sl.csr})
       if (e) (void)hipEventDestroy(e);
   }
   delete s;
@@ -283,11 +278,6 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   out->num_output = num_seeds;
   // the slot's scratch was last used kSlots batches ago, possibly on another stream
   if (sl.was_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
-  // its table was wiped on the side stream after that use
-  if (sl.wipe_pending) {
-    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.wiped, 0));
-    sl.wipe_pending = false;
-  }
   if (mutates && seq > 0) {
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
     {
@@ -344,15 +334,11 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     cur_n_host = 0;
   }
   if (mutates && num_seeds == 0) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+  // wipe the table for the slot's next batch (Reset, cuda_hashtable.cu:714-723), then mark the slot reusable
+  rc = fgnn_hashtable_reset(ht, stream);
+  if (rc != FGNN_OK) return rc;
   FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
   sl.was_used = true;
-  // hand the table to the side stream for wiping; later batches use the other tables meanwhile
-  FGNN_HIP_CHECK(hipEventRecord(sl.used, st));
-  FGNN_HIP_CHECK(hipStreamWaitEvent(sl.reset_stream, sl.used, 0));
-  rc = fgnn_hashtable_reset(ht, sl.reset_stream);
-  if (rc != FGNN_OK) return rc;
-  FGNN_HIP_CHECK(hipEventRecord(sl.wiped, sl.reset_stream));
-  sl.wipe_pending = true;
   return launch_status(__func__);
 }
 
