@@ -109,6 +109,42 @@ __device__ __forceinline__ uint32_t ht_insert_min(unsigned long long *table, uin
 }
 
 
+// UB independent inserts with their memory operations overlapped: all probe loads are issued first, then all
+// CAS, and only keys that collide with a different key fall back to the sequential probe loop.  A lane that
+// inserts its UB edges one after the other pays UB dependent (load + CAS) round trips to the memory-side
+// atomic unit; here it pays about one.
+template <int UB>
+__device__ __forceinline__ void ht_insert_min_batch(unsigned long long *table, uint32_t shift, uint32_t mask,
+                                                    const uint32_t (&key)[UB], const uint32_t (&val)[UB],
+                                                    const bool (&live)[UB], uint32_t (&bucket)[UB]) {
+  uint32_t h[UB];
+  unsigned long long cur[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    h[u] = hash_slot(key[u], shift, mask);
+    cur[u] = live[u] ? table[h[u]] : 0ull;
+  }
+  unsigned long long old[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    old[u] = cur[u];
+    if (live[u] && cur[u] == kEmpty64)
+      old[u] = atomicCAS(&table[h[u]], kEmpty64, ((unsigned long long)key[u] << 32) | val[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    if (!live[u]) continue;
+    if (cur[u] == kEmpty64 && old[u] == kEmpty64) {  // our CAS installed the key
+      bucket[u] = h[u];
+    } else if ((uint32_t)(old[u] >> 32) == key[u]) {  // key already there: keep the minimum value
+      if ((uint32_t)old[u] > val[u]) atomicMin(&table[h[u]], ((unsigned long long)key[u] << 32) | val[u]);
+      bucket[u] = h[u];
+    } else {  // slot taken by another key: ordinary probing from here
+      bucket[u] = ht_insert_min(table, shift, mask, key[u], val[u]);
+    }
+  }
+}
+
 // ---- wave64 / block primitives ----------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }

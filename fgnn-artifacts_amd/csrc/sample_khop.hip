@@ -16,6 +16,8 @@
 //    short rows are contiguous; every lane has independent loads in flight.  Phase C (khop2) applies
 //    the row mutation with the values phase B already fetched;
 //  * sizes may live on the device (d_num_input) so layers chain without a host round trip.
+#include <cstdlib>
+
 #include "fgnn_device.h"
 
 namespace fgnn {
@@ -59,23 +61,28 @@ __device__ __forceinline__ int owner_of_slot(const uint32_t *lo, uint32_t p) {
 // KHOP2 == false : reservoir sampling (khop0.cu:41-90), CSR untouched
 // KHOP2 == true  : partial Fisher-Yates in place (khop2.cu:41-89)
 // S seeds per workgroup, S threads.  Dynamic LDS: KHOP2 ? 3*F*S words : F*S words.
+constexpr uint32_t kWriteBack = 0x80000000u;  // flag on a logged swap position: this step's value survives in the row
+
 struct FuseArgs {               // dedup insert fused into phase B (engine path)
   unsigned long long *table;    // null = not fused
   uint32_t shift, mask;
   uint32_t *pos;                // bucket of every emitted edge
 };
 
-template <int S, bool KHOP2, int FMAX>
-__global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restrict__ indptr, uint32_t *indices,
+// S seeds per workgroup handled by T >= S threads: the per-seed phases (0, A, C) use the first S threads, the
+// per-edge phase B uses all T, so a small frontier still gives every CU several waves to overlap latencies.
+template <int S, int T, bool KHOP2, int FMAX>
+__global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restrict__ indptr, uint32_t *indices,
                                                         const uint32_t *__restrict__ input, size_t num_input,
                                                         const uint32_t *d_num_input, size_t cap, uint32_t F,
                                                         const uint32_t *__restrict__ block_offsets,
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
-                                                        uint32_t tag, FuseArgs fuse) {
-  constexpr int NW = S / kWave;
+                                                        uint32_t tag, FuseArgs fuse, uint32_t ablate) {
+  constexpr int NW = T / kWave;
+  static_assert(T >= S && T % kWave == 0, "threads per workgroup");
   extern __shared__ uint32_t dyn[];
-  __shared__ uint32_t sh_scan[NW > 0 ? NW : 1];
+  __shared__ uint32_t sh_scan[NW];
   __shared__ uint32_t sh_off[S], sh_len[S], sh_rid[S], sh_lo[S + 1];
 
   uint32_t *sh_o = dyn;                         // [F][S] khop2: origin position, then fetched value
@@ -88,8 +95,9 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
   if (first >= n) return;  // whole workgroup exits together
   const size_t i = first + tid;
 
+  const bool seed_lane = tid < S;
   uint32_t rid = 0, off = 0, len = 0;
-  if (i < n) {
+  if (seed_lane && i < n) {
     rid = input[i];
     off = indptr[rid];
     len = indptr[rid + 1] - off;
@@ -97,16 +105,20 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
   const uint32_t c = len < F ? len : F;
   uint32_t total;
   const uint32_t lo = block_exclusive_scan<NW>(c, sh_scan, &total);
-  sh_off[tid] = off;
-  sh_len[tid] = len;
-  sh_rid[tid] = rid;
-  sh_lo[tid] = lo;
+  if (seed_lane) {
+    sh_off[tid] = off;
+    sh_len[tid] = len;
+    sh_rid[tid] = rid;
+    sh_lo[tid] = lo;
+  }
   if (tid == 0) sh_lo[S] = total;
-  const bool big = len > F;
+  const bool big = seed_lane && len > F;
 
   // ---- phase A: which CSR positions does a long row emit? ---------------------------------
   if (KHOP2) {
-    if (big) {
+    if (big && (ablate & 1u)) {  // profiling only: skip the swap simulation
+      for (uint32_t j = 0; j < F; ++j) { sh_s[j * S + tid] = j; sh_w[j * S + tid] = j; sh_o[j * S + tid] = j; }
+    } else if (big) {
       // Simulate `for j: sel = draw % (len-j); emit A[sel]; swap(A[sel], A[len-1-j])` on POSITIONS.
       // Content of a position p at step j = origin written by the last earlier step i with
       // s_i == p, else p itself (a consumed tail position len-1-i is never touched again).
@@ -131,9 +143,19 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
             }
             rs[j] = sel;
             rw[j] = w;
-            sh_s[j * S + tid] = sel;
             sh_w[j * S + tid] = w;
             sh_o[j * S + tid] = o;
+          }
+        }
+        // write-back flag (bit 31 of the logged position; row offsets stay below 2^31 by the host check):
+        // position s_j receives a value iff it is not a consumed tail slot and no later step writes it again
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+          if ((uint32_t)j < F) {
+            bool wb = rs[j] < len - F;
+#pragma unroll
+            for (int q = j + 1; q < FMAX; ++q) wb = wb && !((uint32_t)q < F && rs[q] == rs[j]);
+            sh_s[j * S + tid] = rs[j] | (wb ? kWriteBack : 0u);
           }
         }
       } else {
@@ -153,11 +175,18 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
           sh_w[j * S + tid] = w;
           sh_o[j * S + tid] = o;
         }
+        for (uint32_t j = 0; j < F; ++j) {
+          const uint32_t sj = sh_s[j * S + tid];
+          bool wb = sj < len - F;
+          for (uint32_t q = j + 1; q < F && wb; ++q) wb = (sh_s[q * S + tid] & ~kWriteBack) != sj;
+          if (wb) sh_s[j * S + tid] = sj | kWriteBack;
+        }
       }
     }
   } else {
     // reservoir: slot k ends up with A[max{j >= F : draw_j % (j+1) == k}], or A[k] if none.
-    for (uint32_t q = 0; q < F; ++q) sh_o[q * S + tid] = q;
+    if (seed_lane)
+      for (uint32_t q = 0; q < F; ++q) sh_o[q * S + tid] = q;
     __syncthreads();
     // wave-parallel over each long row of this workgroup (rows can be millions long)
     for (int k = wave_id(); k < S; k += NW) {
@@ -182,13 +211,13 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   const size_t base = block_offsets[blockIdx.x];
-  constexpr int UB = 8;
-  for (uint32_t p0 = tid; p0 < total; p0 += S * UB) {
+  constexpr int UB = 4;
+  for (uint32_t p0 = tid; p0 < total; p0 += T * UB) {
     uint32_t v[UB], wv[UB], slot[UB], srcv[UB];
     bool live[UB], bigv[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const uint32_t p = p0 + u * S;
+      const uint32_t p = p0 + u * T;
       live[u] = p < total;
       bigv[u] = false;
       slot[u] = 0;
@@ -203,19 +232,27 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
         slot[u] = j * S + k;
         const uint32_t pos = bigv[u] ? sh_o[slot[u]] : j;
         srcv[u] = src_mode == FGNN_SRC_LOCAL ? (uint32_t)(first + k) : sh_rid[k];
-        v[u] = indices[koff + pos];
-        if (KHOP2 && bigv[u]) wv[u] = indices[koff + sh_w[slot[u]]];
+        if (!(ablate & 8u)) {
+          v[u] = indices[koff + pos];
+          if (KHOP2 && bigv[u]) wv[u] = indices[koff + sh_w[slot[u]]];
+        }
       }
+    }
+    // FillWithDuplicates pass 1 right here: the neighbour ids are in registers, the edge indices are known
+    uint32_t bucket[UB];
+    if (fuse.table && !(ablate & 2u)) {
+      uint32_t ival[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) ival[u] = kPending | (uint32_t)(base + p0 + u * T);
+      ht_insert_min_batch<UB>(fuse.table, fuse.shift, fuse.mask, v, ival, live, bucket);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       if (live[u]) {
-        const uint32_t p = p0 + u * S;
+        const uint32_t p = p0 + u * T;
         out_dst[base + p] = v[u];
         out_src[base + p] = srcv[u];
-        // FillWithDuplicates pass 1 right here: the neighbour id is in a register, the edge index is known
-        if (fuse.table)
-          fuse.pos[base + p] = ht_insert_min(fuse.table, fuse.shift, fuse.mask, v[u], kPending | (uint32_t)(base + p));
+        if (fuse.table) fuse.pos[base + p] = (ablate & 2u) ? kNoBucket : bucket[u];
         if (KHOP2 && bigv[u]) {
           sh_o[slot[u]] = v[u];   // value that lands in the consumed tail slot len-1-j
           sh_w[slot[u]] = wv[u];  // value that lands in position s_j
@@ -224,21 +261,14 @@ __global__ __launch_bounds__(S) void khop_sample_kernel(const uint32_t *__restri
     }
   }
 
-  // ---- phase C (khop2): apply the swaps to the CSR row ---------------------------------------
-  if (KHOP2) {
+  // ---- phase C (khop2): apply the swaps to the CSR row, one lane per long row -------------------
+  if (KHOP2 && !(ablate & 4u)) {
     __syncthreads();  // every read of the old row contents above has been consumed
-    for (uint32_t p = tid; p < total; p += S) {
-      const int k = owner_of_slot<S>(sh_lo, p);
-      const uint32_t klen = sh_len[k];
-      if (klen <= F) continue;
-      const uint32_t j = p - sh_lo[k];
-      const uint32_t koff = sh_off[k];
-      indices[koff + klen - 1 - j] = sh_o[j * S + k];
-      const uint32_t s = sh_s[j * S + k];
-      if (s < klen - F) {  // positions >= len-F are consumed tail slots, written above
-        bool last = true;
-        for (uint32_t q = j + 1; q < F; ++q) last = last && (sh_s[q * S + k] != s);
-        if (last) indices[koff + s] = sh_w[j * S + k];
+    if (big) {
+      for (uint32_t j = 0; j < F; ++j) {
+        indices[off + len - 1 - j] = sh_o[j * S + tid];  // the emitted value moves to the consumed tail slot
+        const uint32_t sj = sh_s[j * S + tid];
+        if (sj & kWriteBack) indices[off + (sj & ~kWriteBack)] = sh_w[j * S + tid];
       }
     }
   }
@@ -265,6 +295,8 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   while (S > 64 && (words_per_seed * S * 4 > 120 * 1024 || cap / S < 2048)) S >>= 1;
   if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
   const size_t nb = div_up(cap, (size_t)S);
+  const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
+  const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
   FuseArgs fuse{nullptr, 0, 0, nullptr};
   uint32_t *sums = static_cast<uint32_t *>(ws);
   if (fuse_ht) {
@@ -284,13 +316,13 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   do {                                                                                                         \
     static bool attr_done = false;                                                                             \
     if (!attr_done) {                                                                                          \
-      FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, KHOP2, FM>),   \
+      FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&khop_sample_kernel<SS, 256, KHOP2, FM>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
       attr_done = true;                                                                                        \
     }                                                                                                          \
-    hipLaunchKernelGGL((khop_sample_kernel<SS, KHOP2, FM>), dim3(nb), dim3(SS), lds, stream, indptr, indices,  \
+    hipLaunchKernelGGL((khop_sample_kernel<SS, 256, KHOP2, FM>), dim3(nb), dim3(256), lds, stream, indptr, indices, \
                        input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag, fuse);                                                                  \
+                       batch_key, tag, fuse, ablate);                                                          \
   } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \
