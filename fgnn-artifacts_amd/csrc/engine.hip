@@ -30,6 +30,7 @@ struct fgnn_sampler {
     void *ws = nullptr;                   // kernel scratch
     hipEvent_t done = nullptr, csr = nullptr;
     bool was_used = false;
+    fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
   } slot[kSlots];
   // host-side sequencing (calls may come from several threads, one per stream): call `seq` may start once
   // call seq - kSlots has returned; for khop2 (which swaps CSR entries in place) the sampler kernels of call
@@ -132,6 +133,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
     for (hipEvent_t *e : {&sl.done, &sl.csr})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && sl.scan_sample.create(s->max_nodes / 64 + 2) == FGNN_OK;
     if (!ok) {
       fgnn_sampler_destroy(s);
       return fail(err != FGNN_OK ? err : FGNN_EHIP);
@@ -145,6 +147,7 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   if (!s) return;
   for (auto &sl : s->slot) {
     if (sl.ht) fgnn_hashtable_destroy(sl.ht);
+    sl.scan_sample.destroy();
     if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
     if (sl.ws) (void)hipFree(sl.ws);
     for (hipEvent_t e : {sl.done, sl.csr})
@@ -315,7 +318,8 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     else
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
-                             tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream);
+                             tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
+                             &sl.scan_sample);
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
       FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));

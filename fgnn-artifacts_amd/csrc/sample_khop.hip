@@ -78,7 +78,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ block_offsets,
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
-                                                        uint32_t tag, FuseArgs fuse, uint32_t ablate) {
+                                                        uint32_t tag, FuseArgs fuse, uint32_t ablate, ScanWs scan,
+                                                        size_t *d_num_out) {
   constexpr int NW = T / kWave;
   static_assert(T >= S && T % kWave == 0, "threads per workgroup");
   extern __shared__ uint32_t dyn[];
@@ -91,8 +92,13 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
 
   const int tid = threadIdx.x;
   const size_t n = resolve_count(num_input, d_num_input, cap);
-  const size_t first = (size_t)blockIdx.x * S;
-  if (first >= n) return;  // whole workgroup exits together
+  // single-pass mode (scan.desc != null): the workgroup's position in the seed list is an ordered ticket and the
+  // output offset comes from a look-back over the earlier workgroups' edge counts -- no count kernel, no scan kernel
+  const bool single_pass = scan.desc != nullptr;
+  __shared__ uint32_t sh_tile;
+  const uint32_t tile = single_pass ? scan_take_tile(scan, &sh_tile) : blockIdx.x;
+  const size_t first = (size_t)tile * S;
+  if (!single_pass && first >= n) return;  // whole workgroup exits together
   const size_t i = first + tid;
 
   const bool seed_lane = tid < S;
@@ -210,7 +216,13 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   __syncthreads();
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
-  const size_t base = block_offsets[blockIdx.x];
+  size_t base;
+  if (single_pass) {
+    base = scan_lookback(scan, tile, total, &sh_tile);
+    if (tile == gridDim.x - 1 && tid == 0 && d_num_out) *d_num_out = base + total;
+  } else {
+    base = block_offsets[tile];
+  }
   constexpr int UB = 4;
   for (uint32_t p0 = tid; p0 < total; p0 += T * UB) {
     uint32_t v[UB], wv[UB], slot[UB], srcv[UB];
@@ -278,7 +290,8 @@ template <bool KHOP2>
 int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
-                size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr) {
+                size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr,
+                ScanWsHost *scan_host = nullptr) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
   if (cap == 0) {
@@ -311,6 +324,8 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     return FGNN_ENOSPC;
   }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
+  ScanWs scan{nullptr, nullptr, nullptr, 0, 0};
+  bool want_scan = scan_host && nb <= scan_host->ws.max_tiles;
 
 #define FGNN_LAUNCH_KHOP2(SS, FM)                                                                              \
   do {                                                                                                         \
@@ -320,17 +335,32 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
       attr_done = true;                                                                                        \
     }                                                                                                          \
+    if (want_scan) {                                                                                           \
+      /* single-pass only when every workgroup of the grid is resident at once (no ticket needed, no        */ \
+      /* possible wait on an undispatched workgroup); 3/4 of the occupancy query as margin                  */ \
+      static size_t occ_lds = ~size_t(0);                                                                      \
+      static int per_cu = 0;                                                                                   \
+      if (occ_lds != lds) {                                                                                    \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, khop_sample_kernel<SS, 256, KHOP2, FM>, 256, \
+                                                         lds) != hipSuccess)                                   \
+          per_cu = 0;                                                                                          \
+        occ_lds = lds;                                                                                         \
+      }                                                                                                        \
+      if (nb <= (size_t)per_cu * 256 * 3 / 4) scan = scan_host->next(true);                                    \
+    }                                                                                                          \
+    if (!scan.desc) {                                                                                          \
+      hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,   \
+                         d_num_input, cap, F, sums);                                                           \
+      if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream, d_num_input, SS) !=   \
+          FGNN_OK)                                                                                             \
+        return FGNN_EHIP;                                                                                      \
+    }                                                                                                          \
     hipLaunchKernelGGL((khop_sample_kernel<SS, 256, KHOP2, FM>), dim3(nb), dim3(256), lds, stream, indptr, indices, \
                        input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag, fuse, ablate);                                                          \
+                       batch_key, tag, fuse, ablate, scan, d_num_out);                                         \
   } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \
-    hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,     \
-                       d_num_input, cap, F, sums);                                                             \
-    if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream, d_num_input, SS) !=     \
-        FGNN_OK)                                                                                               \
-      return FGNN_EHIP;                                                                                        \
     if (!KHOP2) FGNN_LAUNCH_KHOP2(SS, 0);                                                                      \
     else if (F <= 8) FGNN_LAUNCH_KHOP2(SS, 8);                                                                 \
     else if (F <= 16) FGNN_LAUNCH_KHOP2(SS, 16);                                                               \
@@ -351,13 +381,13 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream) {
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan) {
   if (!ht) return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht)
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht);
+                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan);
 }
 
 }  // namespace fgnn
