@@ -4,6 +4,7 @@
 //
 // Everything a batch needs is enqueued on one stream with device-resident sizes; the host gets one
 // pinned fgnn_batch_meta per batch.  Bit-identical to oracle fgnn_oracle_do_sample.
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -270,8 +271,9 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   {
     // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
     std::unique_lock<std::mutex> lk(s->mu);
-    s->cv.wait(lk, [&] { return seq < s->returned + kSlots; });
-    if (seq < s->returned) return FGNN_EINVAL;  // sequence numbers must be used once, in a window of kSlots
+    // sequence numbers must be consecutive and used once; a gap would wait forever, so give up loudly instead
+    if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return seq < s->returned + kSlots; })) return FGNN_EINVAL;
+    if (seq < s->returned) return FGNN_EINVAL;
   }
   SeqGuard guard{s, seq};
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
@@ -285,7 +287,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
     {
       std::unique_lock<std::mutex> lk(s->mu);
-      s->cv.wait(lk, [&] { return s->csr_passed >= seq; });
+      if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
     }
     FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
   }
