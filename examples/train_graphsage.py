@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""GraphSAGE training through the reference's Python API (`import samgraph.torch as sam`), single GPU (arch1),
+same call sequence as the reference's example/samgraph/train_graphsage.py: config -> init -> per step
+sample_once / get_next_batch / get_dgl_blocks -> forward / backward -> report.
+
+The only difference is the model: DGL has no ROCm wheel in this image, so the mean-aggregator SAGEConv is written
+with plain torch ops on the COO blocks the engine returns (row = local id of the sampled neighbour, col = local id
+of the seed; the first num_dst source nodes are the seeds themselves).  With DGL installed, get_dgl_blocks returns
+DGLBlocks and dgl.nn.SAGEConv works unchanged.
+
+    python examples/train_graphsage.py --dataset-path /tmp/ds/synth --num-epoch 3
+    python examples/train_graphsage.py --make-dataset products   # writes a products-shaped synthetic dataset first
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+import samgraph.torch as sam  # noqa: E402
+
+
+class SAGEConvMean(nn.Module):
+    """h_dst' = W_self h_dst + W_neigh mean_{(u->v)} h_u   (dgl.nn.SAGEConv(..., 'mean'))"""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=True)
+
+    def forward(self, block, h):
+        num_dst = block.number_of_dst_nodes()
+        row, col = block.row.long(), block.col.long()
+        agg = th.zeros((num_dst, h.shape[1]), dtype=h.dtype, device=h.device).index_add_(0, col, h[row])
+        deg = th.zeros(num_dst, dtype=h.dtype, device=h.device).index_add_(0, col, th.ones_like(col, dtype=h.dtype))
+        return self.fc_self(h[:num_dst]) + self.fc_neigh(agg / deg.clamp(min=1).unsqueeze(1))
+
+
+class SAGE(nn.Module):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout):
+        super().__init__()
+        dims = [in_feats] + [n_hidden] * (n_layers - 1) + [n_classes]
+        self.layers = nn.ModuleList(SAGEConvMean(dims[i], dims[i + 1]) for i in range(n_layers))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, blocks, x):
+        h = x
+        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+            h = layer(block, h)
+            if l != len(self.layers) - 1:
+                h = self.dropout(F.relu(h))
+        return h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset-path", default="/tmp/fgnn_ds/synth")
+    ap.add_argument("--make-dataset", default=None, choices=["products", "small"],
+                    help="write a synthetic dataset of that shape to --dataset-path first")
+    ap.add_argument("--fanout", nargs="+", type=int, default=[25, 10])
+    ap.add_argument("--batch-size", type=int, default=8000)
+    ap.add_argument("--num-epoch", type=int, default=3)
+    ap.add_argument("--num-hidden", type=int, default=256)
+    ap.add_argument("--lr", type=float, default=0.003)
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--sample-type", default="khop2")
+    args = ap.parse_args()
+
+    if args.make_dataset:
+        from fgnn_hip import synth
+        shape = dict(synth.DATASET_SHAPES["products"]) if args.make_dataset == "products" else \
+            dict(num_node=200000, num_edge=4000000, feat_dim=100, num_class=47, num_train=40000)
+        root, name = os.path.split(args.dataset_path.rstrip("/"))
+        t0 = time.time()
+        synth.write_dataset(root, name, shape["num_node"], shape["num_edge"], shape["feat_dim"], shape["num_class"],
+                            shape["num_train"], 1000, 1000)
+        print("dataset written in {:.1f}s".format(time.time() - t0))
+
+    run_config = dict(dataset_path=args.dataset_path, _arch=sam.kArch1, _sample_type=sam.sample_types[args.sample_type],
+                      batch_size=args.batch_size, num_epoch=args.num_epoch + 1,  # + one warm-up epoch (common_config.py:163)
+                      _cache_policy=sam.kCacheByPreSample, cache_percentage=0.0, max_sampling_jobs=10,
+                      max_copying_jobs=2, omp_thread_num=8, sampler_ctx="cuda:0", trainer_ctx="cuda:0",
+                      num_fanout=len(args.fanout), fanout=args.fanout)
+    sam.config(run_config)
+    sam.init()
+    dev = th.device("cuda:0")
+    num_layer = len(args.fanout)
+    model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout).to(dev)
+    loss_fcn = nn.CrossEntropyLoss()
+    opt = th.optim.Adam(model.parameters(), lr=args.lr)
+    num_epoch, num_step = sam.num_epoch(), sam.steps_per_epoch()
+    model.train()
+    epoch_total, epoch_sample, epoch_copy, epoch_train, edges = [], [], [], [], 0
+    for epoch in range(num_epoch):
+        t_epoch = time.time()
+        t_train = 0.0
+        for step in range(num_step):
+            sam.sample_once()
+            batch_key = sam.get_next_batch()
+            blocks, batch_input, batch_label = sam.get_dgl_blocks(batch_key, num_layer)
+            t1 = time.time()
+            loss = loss_fcn(model(blocks, batch_input), batch_label)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            th.cuda.synchronize()  # the batch's buffers are released at the next get_next_batch
+            t_train += time.time() - t1
+            if epoch == num_epoch - 1:
+                edges += sam.get_log_step_value(epoch, step, sam.kLogL1NumSample)
+        epoch_total.append(time.time() - t_epoch)
+        epoch_sample.append(sam.get_log_epoch_value(epoch, sam.kLogEpochSampleTime))
+        epoch_copy.append(sam.get_log_epoch_value(epoch, sam.kLogEpochCopyTime))
+        epoch_train.append(t_train)
+        print("Epoch {:03d} | {:.4f} s | sample {:.4f} | extract {:.4f} | train {:.4f} | loss {:.4f}".format(
+            epoch, epoch_total[-1], epoch_sample[-1], epoch_copy[-1], t_train, float(loss)))
+    sam.report_step_average(num_epoch - 1, num_step - 1)
+    # test_result lines in the reference's format (multi_gpu/train_graphsage.py:198-199)
+    for k, v in (("epoch_time:total", np.mean(epoch_total[1:])), ("epoch_time:sample_time", np.mean(epoch_sample[1:])),
+                 ("epoch_time:copy_time", np.mean(epoch_copy[1:])), ("epoch_time:train_total", np.mean(epoch_train[1:])),
+                 ("sampled_edges_per_epoch", edges)):
+        print("test_result:{:}={:.4f}".format(k, v))
+    sam.shutdown()
+
+
+if __name__ == "__main__":
+    main()

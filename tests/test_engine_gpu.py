@@ -34,3 +34,14 @@ def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     """FGNN: sampler processes -> shared pinned queue -> trainer processes, all on cuda:0
     (dist_loops_arch5.cc; the reference's --single-gpu topology, common_config.py:186-191)."""
     assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)
+
+
+def test_training_example_runs(tmp_path):
+    """examples/train_graphsage.py = the reference's single-GPU script shape (config -> init -> sample_once ->
+    get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's test_result lines."""
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_graphsage.py")
+    p = subprocess.run([sys.executable, ex, "--make-dataset", "small", "--dataset-path", str(tmp_path / "small"),
+                        "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch=" in p.stdout
