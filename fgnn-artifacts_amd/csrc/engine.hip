@@ -91,7 +91,11 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     return fail(FGNN_EINVAL);
   switch (cfg->sample_type) {
     case FGNN_KHOP0:
+    case FGNN_KHOP1:
     case FGNN_KHOP2:
+      break;
+    case FGNN_WEIGHTED_KHOP:
+      if (!cfg->prob_table || !cfg->alias_table) return fail(FGNN_EINVAL);
       break;
     case FGNN_WEIGHTED_KHOP_PREFIX:
       if (!cfg->prob_prefix) return fail(FGNN_EINVAL);
@@ -100,7 +104,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
       if (cfg->walk_len == 0 || cfg->num_walks == 0) return fail(FGNN_EINVAL);
       break;
     default:
-      return fail(FGNN_EINVAL);  // khop1 / weighted_khop / hash_dedup: not built yet
+      return fail(FGNN_EINVAL);  // weighted_khop_hash_dedup: not built
   }
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
@@ -122,7 +126,9 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
                 (s->max_edge_cap / 16 + 64) * sizeof(uint32_t);
   for (size_t l = 0; l < cfg->num_layers; ++l) {
     size_t need = 0;
-    if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX) need = fgnn_weighted_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
+    if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX || cfg->sample_type == FGNN_KHOP1 ||
+        cfg->sample_type == FGNN_WEIGHTED_KHOP)
+      need = fgnn_weighted_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
@@ -311,6 +317,13 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       rc = fgnn_sample_weighted_khop_prefix(s->cfg.indptr, s->cfg.indices, s->cfg.prob_prefix, cur, cur_n_host,
                                             d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
                                             s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream);
+    else if (s->cfg.sample_type == FGNN_KHOP1)
+      rc = fgnn_sample_khop1(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst,
+                             d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream);
+    else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
+      rc = fgnn_sample_weighted_khop(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
+                                     cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
+                                     s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream);
     else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
       // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
       rc = fgnn_sample_random_walk(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,

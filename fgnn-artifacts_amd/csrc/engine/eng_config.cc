@@ -103,8 +103,8 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
   if (const char *e = getenv("SAMGRAPH_EMPTY_FEAT")) option_empty_feat = strtoull(e, nullptr, 10);
   if (const char *e = getenv("SAMGRAPH_MQ_BYTES")) mq_budget_bytes = strtoull(e, nullptr, 10);
   switch (sample_type) {
-    case kKHop0: case kKHop2: case kWeightedKHopPrefix: case kRandomWalk: break;
-    default: SAM_FATAL << "sample type " << sample_type << " is not built (khop0, khop2, weighted_khop_prefix, random_walk)";
+    case kKHop0: case kKHop1: case kKHop2: case kWeightedKHop: case kWeightedKHopPrefix: case kRandomWalk: break;
+    default: SAM_FATAL << "sample type " << sample_type << " is not built (weighted_khop_hash_dedup)";
   }
   is_configured = true;
 }

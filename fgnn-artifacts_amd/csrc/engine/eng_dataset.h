@@ -17,7 +17,8 @@ struct HostArray {
 struct Dataset {
   size_t num_node = 0, num_edge = 0, feat_dim = 0, num_class = 0;
   size_t num_train = 0, num_test = 0, num_valid = 0;
-  HostArray indptr, indices, feat, label, train_set, test_set, valid_set, prob_prefix, ranking_file;
+  HostArray indptr, indices, feat, label, train_set, test_set, valid_set, prob_prefix, prob_table, alias_table,
+      ranking_file;
   uint32_t *ranking_nodes = nullptr;  // shared anonymous mapping for pre_sample, or the ranking file
   size_t feat_rows = 0;               // num_node, or 2^SAMGRAPH_EMPTY_FEAT
   void Load(const RunConfig &rc);

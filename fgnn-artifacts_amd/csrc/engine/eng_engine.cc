@@ -129,6 +129,12 @@ void Engine::UploadTopology(int device) {
     SAM_HIP(hipMalloc(&d_prefix_, ds_.prob_prefix.bytes ? ds_.prob_prefix.bytes : 4));
     SAM_HIP(hipMemcpy(d_prefix_, ds_.prob_prefix.ptr, ds_.prob_prefix.bytes, hipMemcpyHostToDevice));
   }
+  if (RC().sample_type == kWeightedKHop) {
+    SAM_HIP(hipMalloc(&d_prob_, ds_.prob_table.bytes ? ds_.prob_table.bytes : 4));
+    SAM_HIP(hipMalloc(&d_alias_, ds_.alias_table.bytes ? ds_.alias_table.bytes : 4));
+    SAM_HIP(hipMemcpy(d_prob_, ds_.prob_table.ptr, ds_.prob_table.bytes, hipMemcpyHostToDevice));
+    SAM_HIP(hipMemcpy(d_alias_, ds_.alias_table.ptr, ds_.alias_table.bytes, hipMemcpyHostToDevice));
+  }
 }
 
 void Engine::CreateSampler() {
@@ -137,6 +143,8 @@ void Engine::CreateSampler() {
   c.indptr = d_indptr_;
   c.indices = d_indices_;
   c.prob_prefix = d_prefix_;
+  c.prob_table = d_prob_;
+  c.alias_table = d_alias_;
   c.num_node = ds_.num_node;
   c.sample_type = RC().sample_type;
   c.num_layers = RC().fanout.size();

@@ -123,7 +123,8 @@ class Engine {
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
-  float *d_prefix_ = nullptr;
+  float *d_prefix_ = nullptr, *d_prob_ = nullptr;
+  uint32_t *d_alias_ = nullptr;
   void *d_feat_ = nullptr;    // arch1: full table in HBM
   void *d_label_ = nullptr;
   uint32_t *d_cache_table_ = nullptr;  // direct-map table u32[num_node]
@@ -158,7 +159,6 @@ class Engine {
   std::thread extract_thread_;
   std::atomic<bool> shutdown_{false};
   std::atomic<size_t> outer_counter_{0};
-  void *dev_mq_base_ = nullptr;  // unused: slots are addressed through hipHostGetDevicePointer per message
 };
 
 // presample.hip

@@ -24,10 +24,13 @@ __device__ __forceinline__ float uniform_float(uint32_t x) {
   return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1], 24 bits, as the oracle
 }
 
-// one lane per (seed, slot)
+// one lane per (seed, slot).  MODE 0: per-row prefix sums + binary search (weighted_khop_prefix.cu:41-92),
+// 1: uniform with replacement (khop1.cu:42-72), 2: alias method, alias table = node ids (weighted_khop.cu:41-76)
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *__restrict__ indptr,
                                                                const uint32_t *__restrict__ indices,
                                                                const float *__restrict__ prefix,
+                                                               const uint32_t *__restrict__ alias,
                                                                const uint32_t *__restrict__ input, size_t n_host,
                                                                const uint32_t *d_n, size_t cap, uint32_t F,
                                                                uint32_t *__restrict__ tmp_dst, uint64_t seed,
@@ -42,7 +45,15 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *_
     const uint32_t off = indptr[rid];
     const uint32_t len = indptr[rid + 1] - off;
     uint32_t pick = FGNN_EMPTY_KEY;
-    if (len != 0) {
+    if (len != 0 && MODE == 1) {
+      pick = indices[off + philox_u32(seed, batch_key, tag, (uint32_t)i, j) % len];
+    } else if (len != 0 && MODE == 2) {
+      const u32x4 blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 1);  // draws 2j, 2j+1 share a block
+      const uint32_t r0 = (j & 1u) ? blk.z : blk.x;
+      const uint32_t r1 = (j & 1u) ? blk.w : blk.y;
+      const uint32_t k = r0 % len;
+      pick = uniform_float(r1) < prefix[off + k] ? indices[off + k] : alias[off + k];
+    } else if (len != 0) {
       const float up = prefix[off + len - 1];
       const float x = uniform_float(philox_u32(seed, batch_key, tag, (uint32_t)i, j)) * up;
       if (x <= prefix[off]) {
@@ -151,12 +162,14 @@ extern "C" size_t fgnn_weighted_scratch_bytes(size_t num_input_cap, size_t fanou
   return (num_input_cap * fanout + 5 * num_input_cap + nb + 8) * sizeof(uint32_t) + temp + 256;
 }
 
-extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,
-                                                const uint32_t *input, size_t num_input,
-                                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
-                                                uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
-                                                uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
-                                                size_t ws_bytes, void *stream) {
+namespace fgnn {
+namespace {
+
+int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, const uint32_t *indices,
+                            const float *table_f, const uint32_t *alias, const uint32_t *input, size_t num_input,
+                            const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
+                            uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                            uint32_t layer, void *ws, size_t ws_bytes, void *stream) {
   auto st = static_cast<hipStream_t>(stream);
   size_t cap = d_num_input ? num_input_cap : num_input;
   if (fanout == 0 || fanout > 0xffffu) return FGNN_EINVAL;
@@ -164,10 +177,11 @@ extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const ui
     if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), st));
     return FGNN_OK;
   }
-  if (!indptr || !indices || !prefix || !input || cap * fanout >= 0x7fffffffull) return FGNN_EINVAL;
+  if (!indptr || !indices || !input || cap * fanout >= 0x7fffffffull) return FGNN_EINVAL;
+  if ((mode != 1 && !table_f) || (mode == 2 && !alias)) return FGNN_EINVAL;
   if (ws_bytes < fgnn_weighted_scratch_bytes(cap, fanout)) return FGNN_ENOSPC;
   const uint32_t F = (uint32_t)fanout;
-  const uint32_t tag = ((uint32_t)FGNN_WEIGHTED_KHOP_PREFIX << 8) | (layer & 0xffu);
+  const uint32_t tag = ((uint32_t)sample_type << 8) | (layer & 0xffu);
   const size_t nb = div_up(cap, kBlock);
   uint32_t *tmp_dst = static_cast<uint32_t *>(ws);
   uint32_t *keys = tmp_dst + cap * F;
@@ -181,8 +195,13 @@ extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const ui
 
   size_t blocks = div_up(cap * F, kBlock);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(weighted_draw_kernel, dim3(blocks), dim3(kBlock), 0, st, indptr, indices, prefix, input, num_input,
-                     d_num_input, cap, F, tmp_dst, seed, batch_key, tag);
+#define FGNN_DRAW(M)                                                                                              \
+  hipLaunchKernelGGL((weighted_draw_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, alias, \
+                     input, num_input, d_num_input, cap, F, tmp_dst, seed, batch_key, tag)
+  if (mode == 1) FGNN_DRAW(1);
+  else if (mode == 2) FGNN_DRAW(2);
+  else FGNN_DRAW(0);
+#undef FGNN_DRAW
   hipLaunchKernelGGL(weighted_count_kernel, dim3(nb), dim3(kBlock), 0, st, indptr, input, num_input, d_num_input, cap, F,
                      tmp_dst, keys, vals, cnt);
   FGNN_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, vals, order, cap, 0, 32, st));
@@ -191,4 +210,38 @@ extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const ui
   hipLaunchKernelGGL(weighted_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, order, cnt, cap, F, tmp_dst, sums,
                      out_src, out_dst, src_mode);
   return launch_status(__func__);
+}
+
+}  // namespace
+}  // namespace fgnn
+
+extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,
+                                                const uint32_t *input, size_t num_input,
+                                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                                uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
+                                                uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
+                                                size_t ws_bytes, void *stream) {
+  return fgnn::launch_with_replacement(0, FGNN_WEIGHTED_KHOP_PREFIX, indptr, indices, prefix, nullptr, input, num_input,
+                                       d_num_input, num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed,
+                                       batch_key, layer, ws, ws_bytes, stream);
+}
+
+extern "C" int fgnn_sample_khop1(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                                 size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                 uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed,
+                                 uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes, void *stream) {
+  return fgnn::launch_with_replacement(1, FGNN_KHOP1, indptr, indices, nullptr, nullptr, input, num_input, d_num_input,
+                                       num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed, batch_key,
+                                       layer, ws, ws_bytes, stream);
+}
+
+extern "C" int fgnn_sample_weighted_khop(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                                         const uint32_t *alias_table, const uint32_t *input, size_t num_input,
+                                         const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                         uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
+                                         uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
+                                         void *stream) {
+  return fgnn::launch_with_replacement(2, FGNN_WEIGHTED_KHOP, indptr, indices, prob_table, alias_table, input,
+                                       num_input, d_num_input, num_input_cap, fanout, out_src, out_dst, d_num_out,
+                                       src_mode, seed, batch_key, layer, ws, ws_bytes, stream);
 }

@@ -22,7 +22,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
 EXPORTS = [
     "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
-    "fgnn_sample_random_walk",
+    "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
@@ -128,6 +128,29 @@ def sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, seed, batc
                                               _ptr(out_dst), _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed),
                                               C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws),
                                               C.c_size_t(ws.numel()), _stream()), "fgnn_sample_weighted_khop_prefix")
+    return out_src, out_dst, d_num_out
+
+
+def sample_with_replacement(kind, indptr, indices, inp, fanout, seed, batch_key, layer, prob=None, alias=None,
+                            src_mode=SRC_GLOBAL):
+    """kind in {'khop1', 'weighted_khop'} (alias method)."""
+    L = load()
+    _need_gpu(indptr, indices, inp)
+    L.fgnn_weighted_scratch_bytes.restype = C.c_size_t
+    n, dev = inp.numel(), inp.device
+    out_src = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(n * fanout, 1), dtype=torch.int32, device=dev)
+    d_num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.fgnn_weighted_scratch_bytes(C.c_size_t(max(n, 1)), C.c_size_t(fanout)), dtype=torch.uint8,
+                     device=dev)
+    tail = (_ptr(inp), C.c_size_t(n), C.c_void_p(0), C.c_size_t(n), C.c_size_t(fanout), _ptr(out_src), _ptr(out_dst),
+            _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed), C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws),
+            C.c_size_t(ws.numel()), _stream())
+    if kind == "khop1":
+        _check(L.fgnn_sample_khop1(_ptr(indptr), _ptr(indices), *tail), "fgnn_sample_khop1")
+    else:
+        _check(L.fgnn_sample_weighted_khop(_ptr(indptr), _ptr(indices), _ptr(prob), _ptr(alias), *tail),
+               "fgnn_sample_weighted_khop")
     return out_src, out_dst, d_num_out
 
 
@@ -260,7 +283,7 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
 # batch driver (fgnn_sampler / fgnn_batch)
 
 MAX_LAYERS = 8
-KHOP0, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2 = 0, 3, 4, 5
+KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2 = 0, 1, 2, 3, 4, 5
 
 EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
@@ -276,7 +299,8 @@ class SamplerConfig(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("prob_prefix", C.c_void_p),
                 ("num_node", C.c_size_t), ("sample_type", C.c_int), ("num_layers", C.c_size_t),
                 ("fanout", C.c_size_t * MAX_LAYERS), ("max_batch_size", C.c_size_t), ("seed", C.c_uint64),
-                ("walk_len", C.c_size_t), ("num_walks", C.c_size_t), ("restart_prob", C.c_double)]
+                ("walk_len", C.c_size_t), ("num_walks", C.c_size_t), ("restart_prob", C.c_double),
+                ("prob_table", C.c_void_p), ("alias_table", C.c_void_p)]
 
 
 class BatchMeta(C.Structure):
@@ -308,7 +332,7 @@ class Sampler:
     """DoGPUSample / DoGetCacheMissIndex / DoGPUFeatureExtract on one GPU, no host round trips."""
 
     def __init__(self, indptr, indices, fanout, max_batch_size, sample_type=KHOP2, seed=0x5A4D47, prob_prefix=None,
-                 walk_len=0, num_walks=0, restart_prob=0.0):
+                 walk_len=0, num_walks=0, restart_prob=0.0, prob_table=None, alias_table=None):
         L = load()
         _need_gpu(indptr, indices)
         L.fgnn_sampler_create.restype = C.c_void_p
@@ -321,7 +345,7 @@ class Sampler:
             getattr(L, name).restype = C.c_void_p
         self.device = indptr.device
         torch.cuda.set_device(self.device)
-        self._keep = (indptr, indices, prob_prefix)
+        self._keep = (indptr, indices, prob_prefix, prob_table, alias_table)
         cfg = SamplerConfig()
         cfg.indptr, cfg.indices = indptr.data_ptr(), indices.data_ptr()
         cfg.prob_prefix = prob_prefix.data_ptr() if prob_prefix is not None else 0
@@ -332,6 +356,8 @@ class Sampler:
             cfg.fanout[i] = f
         cfg.max_batch_size, cfg.seed = max_batch_size, seed
         cfg.walk_len, cfg.num_walks, cfg.restart_prob = walk_len, num_walks, restart_prob
+        cfg.prob_table = prob_table.data_ptr() if prob_table is not None else 0
+        cfg.alias_table = alias_table.data_ptr() if alias_table is not None else 0
         err = C.c_int(0)
         self.h = C.c_void_p(L.fgnn_sampler_create(C.byref(cfg), C.byref(err)))
         if not self.h:

@@ -65,13 +65,43 @@ def prob_prefix_table(indptr, indices, seed=7):
     return prefix
 
 
+def alias_tables(indptr, indices, seed=9):
+    """prob_table f32[E], alias_table u32[E] (node ids) by the queue-based Vose construction of
+    utility/data-process/toolkit/weight/create_alias_table.cc:100-170, weights = kSrcSuffix policy."""
+    from collections import deque
+    num_node = len(indptr) - 1
+    out_deg = np.bincount(indices, minlength=num_node)
+    prob = np.ones(len(indices), dtype=np.float32)
+    alias = indices.copy()
+    ip = indptr.astype(np.int64)
+    for r in range(num_node):
+        a, b = ip[r], ip[r + 1]
+        n = int(b - a)
+        if n == 0:
+            continue
+        w = np.where(out_deg[indices[a:b]] < 10, 100.0, 1.0).astype(np.float32)
+        w = (w / w.sum(dtype=np.float32) * np.float32(n)).astype(np.float32)
+        small, large = deque(i for i in range(n) if w[i] < 1.0), deque(i for i in range(n) if w[i] >= 1.0)
+        while small and large:
+            si, li = small.popleft(), large.popleft()
+            prob[a + si] = w[si]
+            alias[a + si] = indices[a + li]
+            w[li] = np.float32(w[li] - (np.float32(1.0) - w[si]))
+            (small if w[li] < 1.0 else large).append(li)
+        for li in large:
+            prob[a + li] = 1.0
+        for si in small:
+            prob[a + si] = 1.0
+    return prob, alias.astype(np.uint32)
+
+
 def node_features(num_node, dim, seed=3, dtype=np.float32):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((num_node, dim), dtype=np.float32).astype(dtype)
 
 
 def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train, num_valid=0, num_test=0,
-                  seed=42, with_prefix=False):
+                  seed=42, with_prefix=False, with_alias=False):
     """Writes <root>/<name>/{meta.txt,indptr.bin,indices.bin,feat.bin,label.bin,*_set.bin}."""
     d = os.path.join(root, name)
     os.makedirs(d, exist_ok=True)
@@ -89,6 +119,14 @@ def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train
     test.tofile(os.path.join(d, "test_set.bin"))
     if with_prefix:
         prob_prefix_table(indptr, indices).tofile(os.path.join(d, "prob_prefix_table.bin"))
+    if with_alias:
+        prob, alias = alias_tables(indptr, indices)
+        prob.tofile(os.path.join(d, "prob_table.bin"))
+        alias.tofile(os.path.join(d, "alias_table.bin"))
+    # file-backed cache rankings (engine.cc:216-256): by in-degree (cache_by_degree.bin) and random
+    deg = indptr[1:].astype(np.int64) - indptr[:-1].astype(np.int64)
+    np.argsort(-deg, kind="stable").astype(np.uint32).tofile(os.path.join(d, "cache_by_degree.bin"))
+    rng.permutation(num_node).astype(np.uint32).tofile(os.path.join(d, "cache_by_random.bin"))
     with open(os.path.join(d, "meta.txt"), "w") as f:
         f.write(f"NUM_NODE {num_node}\nNUM_EDGE {num_edge}\nFEAT_DIM {feat_dim}\nNUM_CLASS {num_class}\n"
                 f"NUM_TRAIN_SET {len(train)}\nNUM_VALID_SET {len(valid)}\nNUM_TEST_SET {len(test)}\n")

@@ -35,7 +35,8 @@ extern "C" {
 /* DataType, common.h:38-46 */
 enum { FGNN_F32 = 0, FGNN_F64 = 1, FGNN_F16 = 2, FGNN_U8 = 3, FGNN_I32 = 4, FGNN_I8 = 5, FGNN_I64 = 6 };
 /* SampleType, common.h:50-58 (only used to derive RNG tags) */
-enum { FGNN_KHOP0 = 0, FGNN_RANDOM_WALK = 3, FGNN_WEIGHTED_KHOP_PREFIX = 4, FGNN_KHOP2 = 5 };
+enum { FGNN_KHOP0 = 0, FGNN_KHOP1 = 1, FGNN_WEIGHTED_KHOP = 2, FGNN_RANDOM_WALK = 3, FGNN_WEIGHTED_KHOP_PREFIX = 4,
+       FGNN_KHOP2 = 5 };
 
 /* out_src contents of the samplers */
 enum { FGNN_SRC_GLOBAL = 0, /* seed's global id, as the reference emits (khop2.cu:79) */
@@ -79,6 +80,20 @@ int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *ind
                                      size_t num_input_cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                                      size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                                      uint32_t layer, void *ws, size_t ws_bytes, void *stream);
+
+/* GPUSampleKHop1 (cuda_sampling_khop1.cu:130-234): uniform WITH replacement, same sort-by-src + adjacent-duplicate
+ * removal as the weighted samplers.  Scratch: fgnn_weighted_scratch_bytes. */
+int fgnn_sample_khop1(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,
+                      const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
+                      uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                      uint32_t layer, void *ws, size_t ws_bytes, void *stream);
+/* GPUSampleWeightedKHop (cuda_sampling_weighted_khop.cu:132-236): alias method with replacement; alias_table holds
+ * node ids (create_alias_table.cc:150-151).  Scratch: fgnn_weighted_scratch_bytes. */
+int fgnn_sample_weighted_khop(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                              const uint32_t *alias_table, const uint32_t *input, size_t num_input,
+                              const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
+                              uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                              uint32_t layer, void *ws, size_t ws_bytes, void *stream);
 
 /* GPUSampleRandomWalk + FrequencyHashmap::GetTopK (cuda_sampling_random_walk.cu:113-161,
  * cuda_frequency_hashmap.cu:1143-1367): num_walks restart walks of walk_len steps per seed; per seed
@@ -172,6 +187,8 @@ typedef struct {
   uint64_t seed;            /* Philox seed (replaces the clock seed of cuda_random_states.cu:105-107) */
   size_t walk_len, num_walks; /* random walk: RunConfig::random_walk_length / num_random_walk */
   double restart_prob;
+  const float *prob_table;     /* device, f32[num_edge]: weighted_khop (alias method) only */
+  const uint32_t *alias_table; /* device, u32[num_edge] node ids: weighted_khop only */
 } fgnn_sampler_config;
 
 /* Host-visible summary of one batch (Task / TrainGraph / MissCacheIndex sizes, common.h:186-222);

@@ -241,43 +241,9 @@ static int cmp_pair_src_stable(const void *a, const void *b) {
   return 0;
 }
 
-void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices,
-                                             const float *prob_prefix, const uint32_t *input,
-                                             size_t num_input, size_t fanout, uint32_t *out_src,
-                                             uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
-                                             uint64_t batch_key, uint32_t layer) {
-  const uint32_t tag = khop_tag(FGNN_WEIGHTED_KHOP_PREFIX, layer);
-  const size_t num_task = num_input * fanout;
-  pair_ord *tmp = (pair_ord *)malloc(sizeof(pair_ord) * (num_task ? num_task : 1));
-  if (rng->mode != FGNN_RNG_PHILOX) abort(); /* no CPU twin exists in the reference */
-  for (size_t t = 0; t < num_task; ++t) {
-    const size_t i = t / fanout, j = t % fanout;
-    const uint32_t rid = input[i];
-    const uint32_t off = indptr[rid];
-    const uint32_t len = indptr[rid + 1] - off;
-    tmp[t].ord = t;
-    if (len == 0) {
-      tmp[t].src = FGNN_EMPTY_KEY;
-      tmp[t].dst = FGNN_EMPTY_KEY;
-      continue;
-    }
-    const float upbound = prob_prefix[off + len - 1];
-    const float x =
-        philox_uniform_float(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j)) * upbound;
-    uint32_t pick;
-    if (x <= prob_prefix[off]) {
-      pick = indices[off];
-    } else {
-      size_t lo = off, hi = (size_t)off + len - 1;
-      while (hi - lo >= 2) {
-        size_t mid = (lo + hi) >> 1;
-        if (prob_prefix[mid] >= x) hi = mid; else lo = mid;
-      }
-      pick = indices[hi];
-    }
-    tmp[t].src = rid;
-    tmp[t].dst = pick;
-  }
+/* post-processing shared by the three with-replacement samplers (khop1.cu:130-234, weighted_khop.cu:132-236,
+ * weighted_khop_prefix.cu:148-255): stable sort by src, drop a pair equal to its successor, drop kEmptyKey */
+static size_t sort_and_adjacent_dedup(pair_ord *tmp, size_t num_task, uint32_t *out_src, uint32_t *out_dst) {
   /* cub::DeviceRadixSort::SortPairs(key = src, val = dst): stable, ascending, kEmptyKey last */
   qsort(tmp, num_task, sizeof(pair_ord), cmp_pair_src_stable);
   size_t w = 0;
@@ -289,8 +255,82 @@ void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint3
       keep = tmp[t].src != FGNN_EMPTY_KEY;
     if (keep) { out_src[w] = tmp[t].src; out_dst[w] = tmp[t].dst; ++w; }
   }
-  *num_out = w;
+  return w;
+}
+
+/* mode 0: weighted prefix (binary search), 1: khop1 (uniform with replacement), 2: alias method */
+static void sample_with_replacement(int mode, int sample_type, const uint32_t *indptr, const uint32_t *indices,
+                                    const float *table_f, const uint32_t *alias, const uint32_t *input,
+                                    size_t num_input, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                                    size_t *num_out, fgnn_rng *rng, uint64_t batch_key, uint32_t layer) {
+  const uint32_t tag = khop_tag(sample_type, layer);
+  const size_t num_task = num_input * fanout;
+  pair_ord *tmp = (pair_ord *)malloc(sizeof(pair_ord) * (num_task ? num_task : 1));
+  if (rng->mode != FGNN_RNG_PHILOX) abort(); /* no CPU twin exists in the reference (empty stubs) */
+  for (size_t t = 0; t < num_task; ++t) {
+    const size_t i = t / fanout, j = t % fanout;
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    tmp[t].ord = t;
+    if (len == 0) {
+      tmp[t].src = FGNN_EMPTY_KEY;
+      tmp[t].dst = FGNN_EMPTY_KEY;
+      continue;
+    }
+    uint32_t pick;
+    if (mode == 1) {
+      /* khop1.cu:64: curand() % len */
+      pick = indices[off + fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j) % len];
+    } else if (mode == 2) {
+      /* weighted_khop.cu:64-70: k = curand() % len; r = curand_uniform(); r < prob[k] ? indices[k] : alias[k] */
+      const uint32_t k = fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * (uint32_t)j) % len;
+      const float r = philox_uniform_float(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * (uint32_t)j + 1u));
+      pick = r < table_f[off + k] ? indices[off + k] : alias[off + k];
+    } else {
+      const float upbound = table_f[off + len - 1];
+      const float x =
+          philox_uniform_float(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, (uint32_t)j)) * upbound;
+      if (x <= table_f[off]) {
+        pick = indices[off];
+      } else {
+        size_t lo = off, hi = (size_t)off + len - 1;
+        while (hi - lo >= 2) {
+          size_t mid = (lo + hi) >> 1;
+          if (table_f[mid] >= x) hi = mid; else lo = mid;
+        }
+        pick = indices[hi];
+      }
+    }
+    tmp[t].src = rid;
+    tmp[t].dst = pick;
+  }
+  *num_out = sort_and_adjacent_dedup(tmp, num_task, out_src, out_dst);
   free(tmp);
+}
+
+void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices,
+                                             const float *prob_prefix, const uint32_t *input,
+                                             size_t num_input, size_t fanout, uint32_t *out_src,
+                                             uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
+                                             uint64_t batch_key, uint32_t layer) {
+  sample_with_replacement(0, FGNN_WEIGHTED_KHOP_PREFIX, indptr, indices, prob_prefix, NULL, input, num_input, fanout,
+                          out_src, out_dst, num_out, rng, batch_key, layer);
+}
+
+void fgnn_oracle_sample_khop1(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                              size_t num_input, size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *num_out,
+                              fgnn_rng *rng, uint64_t batch_key, uint32_t layer) {
+  sample_with_replacement(1, FGNN_KHOP1, indptr, indices, NULL, NULL, input, num_input, fanout, out_src, out_dst,
+                          num_out, rng, batch_key, layer);
+}
+
+void fgnn_oracle_sample_weighted_khop(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                                      const uint32_t *alias_table, const uint32_t *input, size_t num_input,
+                                      size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *num_out,
+                                      fgnn_rng *rng, uint64_t batch_key, uint32_t layer) {
+  sample_with_replacement(2, FGNN_WEIGHTED_KHOP, indptr, indices, prob_table, alias_table, input, num_input, fanout,
+                          out_src, out_dst, num_out, rng, batch_key, layer);
 }
 
 /* ------------------------------------------------------------------ random walk + top-K ---- */
@@ -454,6 +494,15 @@ fgnn_oracle_task *fgnn_oracle_do_sample(const uint32_t *indptr, uint32_t *indice
       case FGNN_WEIGHTED_KHOP_PREFIX:
         fgnn_oracle_sample_weighted_khop_prefix(indptr, indices, prob_prefix, cur_input, num_input, fanout,
                                                 out_src, out_dst, &num_out, rng, batch_key, (uint32_t)i);
+        break;
+      case FGNN_KHOP1:
+        fgnn_oracle_sample_khop1(indptr, indices, cur_input, num_input, fanout, out_src, out_dst, &num_out, rng,
+                                 batch_key, (uint32_t)i);
+        break;
+      case FGNN_WEIGHTED_KHOP:
+        /* prob_prefix carries the prob table, cfg->alias_table the alias ids */
+        fgnn_oracle_sample_weighted_khop(indptr, indices, prob_prefix, cfg->alias_table, cur_input, num_input, fanout,
+                                         out_src, out_dst, &num_out, rng, batch_key, (uint32_t)i);
         break;
       case FGNN_RANDOM_WALK:
         out_data = (uint32_t *)malloc(sizeof(uint32_t) * (cap ? cap : 1));

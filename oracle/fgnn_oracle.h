@@ -107,6 +107,19 @@ void fgnn_oracle_sample_weighted_khop_prefix(const uint32_t *indptr, const uint3
                                              uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
                                              uint64_t batch_key, uint32_t layer);
 
+/* cuda/cuda_sampling_khop1.cu:42-234: uniform WITH replacement (curand() % len per slot), then the same stable
+ * sort by src + adjacent-duplicate removal.  Philox mode only. */
+void fgnn_oracle_sample_khop1(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                              size_t num_input, size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *num_out,
+                              fgnn_rng *rng, uint64_t batch_key, uint32_t layer);
+
+/* cuda/cuda_sampling_weighted_khop.cu:41-236: alias method with replacement (alias table holds NODE IDS,
+ * utility/data-process/toolkit/weight/create_alias_table.cc:150-151), then sort + adjacent dedup. */
+void fgnn_oracle_sample_weighted_khop(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                                      const uint32_t *alias_table, const uint32_t *input, size_t num_input,
+                                      size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *num_out,
+                                      fgnn_rng *rng, uint64_t batch_key, uint32_t layer);
+
 /* cuda/cuda_sampling_random_walk.cu:43-109 + cuda/cuda_frequency_hashmap.cu:1143-1367:
  * num_walks restart-walks of walk_len steps per seed, visit-frequency top-K per seed.
  * Tie rule fixed to (count desc, first visit order asc) -- a legal outcome of the reference's race.
@@ -166,6 +179,7 @@ typedef struct {
   /* random walk */
   size_t walk_len, num_walks, num_neighbor;
   double restart_prob;
+  const uint32_t *alias_table; /* FGNN_WEIGHTED_KHOP only (prob table goes in the prob_prefix argument) */
 } fgnn_oracle_sample_cfg;
 
 /* DoGPUSample, cuda/cuda_loops.cc:50-267 (== dist/dist_loops.cc:51-269, cpu/cpu_loops.cc:55-191). */

@@ -41,7 +41,7 @@ class _Task(C.Structure):
 class _Cfg(C.Structure):
     _fields_ = [("sample_type", C.c_int), ("num_layers", C.c_size_t), ("fanout", C.POINTER(C.c_size_t)),
                 ("walk_len", C.c_size_t), ("num_walks", C.c_size_t), ("num_neighbor", C.c_size_t),
-                ("restart_prob", C.c_double)]
+                ("restart_prob", C.c_double), ("alias_table", C.POINTER(C.c_uint32))]
 
 
 def build():
@@ -134,6 +134,19 @@ def sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, rng, batch
                    layer, extra=(prefix.ctypes.data_as(C.POINTER(C.c_float)),))
 
 
+def sample_khop1(indptr, indices, inp, fanout, rng, batch_key=0, layer=0):
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    return _sample(lib().fgnn_oracle_sample_khop1, indptr, indices, inp, fanout, rng, batch_key, layer)
+
+
+def sample_weighted_khop(indptr, indices, prob, alias, inp, fanout, rng, batch_key=0, layer=0):
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    prob = np.ascontiguousarray(prob, dtype=np.float32)
+    alias = np.ascontiguousarray(alias, dtype=np.uint32)
+    return _sample(lib().fgnn_oracle_sample_weighted_khop, indptr, indices, inp, fanout, rng, batch_key, layer,
+                   extra=(prob.ctypes.data_as(C.POINTER(C.c_float)), alias.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+
 def sample_random_walk(indptr, indices, inp, walk_len, restart_prob, num_walks, K, rng, batch_key=0, layer=0):
     indptr, p_indptr = _u32(indptr)
     indices, p_idx = _u32(indices)
@@ -188,14 +201,18 @@ class HashTable:
 
 
 def do_sample(indptr, indices, seeds, fanout, sample_type, rng, batch_key, ht, prob_prefix=None, walk_len=0,
-              num_walks=0, num_neighbor=0, restart_prob=0.0):
+              num_walks=0, num_neighbor=0, restart_prob=0.0, alias_table=None):
     """DoGPUSample restatement.  `indices` (uint32, contiguous) is mutated when sample_type == KHOP2.
     Returns dict(graphs=[dict(row,col,data,num_src,num_dst,num_edge)], input_nodes, total_edges)."""
     assert indices.dtype == np.uint32 and indices.flags.c_contiguous
     indptr, p_indptr = _u32(indptr)
     seeds, p_seeds = _u32(seeds)
     fo = (C.c_size_t * len(fanout))(*fanout)
-    cfg = _Cfg(sample_type, len(fanout), fo, walk_len, num_walks, num_neighbor, restart_prob)
+    al = None
+    if alias_table is not None:
+        alias_table = np.ascontiguousarray(alias_table, dtype=np.uint32)
+        al = alias_table.ctypes.data_as(C.POINTER(C.c_uint32))
+    cfg = _Cfg(sample_type, len(fanout), fo, walk_len, num_walks, num_neighbor, restart_prob, al)
     pp = None
     if prob_prefix is not None:
         prob_prefix = np.ascontiguousarray(prob_prefix, dtype=np.float32)

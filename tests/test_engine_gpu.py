@@ -17,7 +17,8 @@ def _run(tmp_path, *args):
     return p.stdout
 
 
-@pytest.mark.parametrize("sample_type", ["khop2", "khop0", "weighted_khop_prefix", "random_walk"])
+@pytest.mark.parametrize("sample_type", ["khop2", "khop0", "weighted_khop_prefix", "random_walk", "khop1",
+                                         "weighted_khop"])
 def test_arch1_single_gpu(tmp_path, sample_type):
     """BASELINE config 2 in miniature: one GPU samples and extracts (cuda_loops_arch1.cc:44-80)."""
     assert "ok" in _run(tmp_path, "arch1", sample_type)
@@ -29,6 +30,7 @@ def test_arch1_single_gpu(tmp_path, sample_type):
     ("khop2", 2, 1, 0.25, "pipeline"),       # two samplers with disjoint step ranges, one trainer
     ("weighted_khop_prefix", 1, 2, 0.3, "pipeline"),  # config 4 in miniature
     ("random_walk", 2, 2, 0.2, "inline"),    # config 5 in miniature (edge data shipped)
+    ("khop1", 1, 1, 0.2, "pipeline"),
 ])
 def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     """FGNN: sampler processes -> shared pinned queue -> trainer processes, all on cuda:0

@@ -370,3 +370,61 @@ def test_batch_driver_other_samplers(hip, oracle, mode):
             if mode == "random_walk":
                 np.testing.assert_array_equal(host_u32(bt.graph_data(li)), g["data"])
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
+@pytest.mark.parametrize("kind", ["khop1", "weighted_khop"])
+@pytest.mark.parametrize("fanout", [1, 6, 15])
+def test_with_replacement_samplers_match_oracle(hip, oracle, kind, fanout):
+    """khop1 (uniform with replacement) and weighted_khop (alias method): SURVEY 8(f) rank 4."""
+    from fgnn_hip import synth
+    num_node = 4000
+    indptr, indices = synth.powerlaw_csr(num_node, 70000, seed=37)
+    prob, alias = synth.alias_tables(indptr, indices)
+    d_indptr, d_indices, d_prob, d_alias = dev(indptr), dev(indices), dev(prob), dev(alias)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for call, n in enumerate([1200, 1, 0, 501]):
+        inp = _seeds(n, num_node, seed=70 + call)
+        d_inp = dev(inp) if n else torch.empty(0, dtype=torch.int32, device="cuda")
+        if kind == "khop1":
+            o_src, o_dst = oracle.sample_khop1(indptr, indices, inp, fanout, rng, 4 + call, 1)
+        else:
+            o_src, o_dst = oracle.sample_weighted_khop(indptr, indices, prob, alias, inp, fanout, rng, 4 + call, 1)
+        src, dst, d_ne = hip.sample_with_replacement(kind, d_indptr, d_indices, d_inp, fanout, SEED, 4 + call, 1,
+                                                     prob=d_prob, alias=d_alias)
+        ne = int(d_ne.cpu()[0])
+        assert ne == len(o_dst)
+        np.testing.assert_array_equal(host_u32(src, ne), o_src)
+        np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
+
+
+@pytest.mark.parametrize("mode", ["khop1", "weighted_khop"])
+def test_batch_driver_with_replacement(hip, oracle, mode):
+    from fgnn_hip import synth
+    num_node = 20000
+    indptr, indices = synth.powerlaw_csr(num_node, 300000, seed=39)
+    prob, alias = synth.alias_tables(indptr, indices)
+    fanouts, batch = [4, 6], 200
+    if mode == "khop1":
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.KHOP1, seed=SEED)
+        okw, ost = {}, oracle.KHOP1
+    else:
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.WEIGHTED_KHOP, seed=SEED,
+                              prob_table=dev(prob), alias_table=dev(alias))
+        okw, ost = dict(prob_prefix=prob, alias_table=alias), oracle.WEIGHTED_KHOP
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    for b in range(2):
+        seeds = _seeds(batch, num_node, seed=80 + b)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht, **okw)
+        for li in range(2):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
