@@ -92,6 +92,85 @@ __global__ __launch_bounds__(kBlock) void cache_split_kernel(const uint32_t *__r
   }
 }
 
+// count + scan + split in ONE launch (batch driver path): a workgroup owns `rounds` x 256 consecutive nodes,
+// looks every node up once, learns the number of misses before its chunk by a decoupled look-back over the
+// earlier workgroups and writes both lists.  Same output as cache_count_kernel -> scan -> cache_split_kernel.
+__global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_t *__restrict__ table,
+                                                                   const uint32_t *__restrict__ nodes, size_t n_host,
+                                                                   const uint32_t *d_n, size_t cap,
+                                                                   uint32_t *__restrict__ slot,
+                                                                   uint32_t *__restrict__ miss_src,
+                                                                   uint32_t *__restrict__ miss_dst,
+                                                                   uint32_t *__restrict__ cache_src,
+                                                                   uint32_t *__restrict__ cache_dst,
+                                                                   uint32_t *__restrict__ d_counts, ScanWs scan,
+                                                                   uint32_t ablate) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  __shared__ uint32_t sh_tile;
+  const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);  // cap < 2^32 (host check)
+  const uint32_t per_round = kBlock * gridDim.x;
+  const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
+  const uint32_t chunk = rounds * kBlock;
+  const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
+  const uint32_t tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  phase_mark(scan, tile, 0);
+  const size_t chunk0 = (size_t)tile * chunk;
+  uint32_t miss_mask = 0, cnt = 0;
+  // four rounds at a time: their loads are independent, keep them all in flight
+  for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
+    uint32_t nd[4], sv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+      ok[u] = r0 + u < rounds && i < n;
+      nd[u] = ok[u] ? nodes[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sv[u] = ok[u] && !(ablate & 1u) ? table[nd[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ok[u]) {
+        if (!(ablate & 2u)) slot[chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x] = sv[u];
+        if (sv[u] == FGNN_EMPTY_KEY) {
+          miss_mask |= 1u << (r0 + u);
+          ++cnt;
+        }
+      }
+    }
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan<kWavesPerBlock>(cnt, sh, &tot);
+  phase_mark(scan, tile, 1);
+  uint32_t miss_before = (ablate & 8u) ? 0u : scan_lookback(scan, tile, tot, &sh_tile);
+  phase_mark(scan, tile, 2);
+  if (tile == ntiles - 1 && threadIdx.x == 0) {
+    d_counts[0] = miss_before + tot;
+    d_counts[1] = (uint32_t)n - (miss_before + tot);
+  }
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const size_t row0 = chunk0 + (size_t)r * kBlock;
+    const size_t i = row0 + threadIdx.x;
+    const bool is_miss = (miss_mask >> r) & 1u;
+    uint32_t t2;
+    const uint32_t mrank = block_exclusive_rank<kWavesPerBlock>(is_miss, sh, &t2);
+    if (i < n && !(ablate & 4u)) {
+      if (is_miss) {
+        const uint32_t p = miss_before + mrank;
+        miss_dst[p] = (uint32_t)i;
+        miss_src[p] = nodes[i];
+      } else {
+        const uint32_t p = (uint32_t)(row0 - miss_before) + (threadIdx.x - mrank);
+        cache_dst[p] = (uint32_t)i;
+        cache_src[p] = slot[i];
+      }
+    }
+    miss_before += t2;
+  }
+  phase_mark(scan, tile, 3);
+}
+
 struct alignas(16) chunk16 { uint32_t a, b, c, d; };
 
 // flat 16-byte-chunk gather; chunks_per_row = row_bytes / 16.  A workgroup walks tiles of
@@ -199,6 +278,14 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
                                          const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
                                          uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst,
                                          uint32_t *d_counts, void *ws, size_t ws_bytes, void *stream) {
+  return fgnn::get_miss_cache_index_ex(table, nodes, num_nodes, d_num_nodes, num_nodes_cap, miss_src, miss_dst,
+                                       cache_src, cache_dst, d_counts, ws, ws_bytes, stream, nullptr);
+}
+
+int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
+                                  const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
+                                  uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts,
+                                  void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan) {
   auto s = static_cast<hipStream_t>(stream);
   size_t cap = d_num_nodes ? num_nodes_cap : num_nodes;
   if (!d_counts) return FGNN_EINVAL;
@@ -215,6 +302,25 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
   uint32_t *slot = static_cast<uint32_t *>(ws);
   uint32_t *sums = slot + cap;
   uint32_t *total = sums + nb;
+  if (scan && ipt == 1) {
+    // single-pass path: grid resident at once (ticketless look-back), a chunk at most 32 rounds
+    static int per_cu = -1;
+    if (per_cu < 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cache_split_fused_kernel, kBlock, 0) != hipSuccess)
+      per_cu = 0;
+    size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
+    if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
+    if (grid > nb) grid = nb;
+    if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
+      const char *e_ab = getenv("FGNN_SPLIT_ABLATE");  // profiling only; results are wrong when set
+      const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
+      if (const char *e_g = getenv("FGNN_SPLIT_GRID")) grid = (size_t)atoi(e_g) < grid ? (size_t)atoi(e_g) : grid;
+      hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid), dim3(kBlock), 0, s, table, nodes, num_nodes,
+                         d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
+                         scan->next(true, 2), ablate);
+      return launch_status(__func__);
+    }
+  }
   if (ipt == 1)
     hipLaunchKernelGGL((cache_count_kernel<1>), dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes, d_num_nodes, cap,
                        slot, sums);
@@ -256,7 +362,9 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
     // loads (profiles/r01_gather_sweep.csv)
     const bool nt = e_nt ? atoi(e_nt) != 0 : true;
     const char *e_nts = getenv("FGNN_GATHER_NTS");
-    const bool nts = e_nts ? atoi(e_nts) != 0 : false;
+    // non-temporal stores too: 256 MB of gathered rows left as dirty lines in the Infinity Cache slow down the
+    // cold random reads of the next batch's sampling chain (whole step 0.228 -> 0.207 ms)
+    const bool nts = e_nts ? atoi(e_nts) != 0 : true;
 #define FGNN_GATHER3(U, C, N)                                                                                    \
   do {                                                                                                           \
     size_t blocks = div_up(total, (size_t)kBlock * U);                                                           \

@@ -8,7 +8,14 @@ static thread_local char g_last_error[512] = "";
 void set_last_error(const char *what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
 }
+static unsigned long long *g_phase_log = nullptr;
+unsigned long long *phase_log_base() { return g_phase_log; }
 }  // namespace fgnn
+
+extern "C" size_t fgnn_debug_phase_log_bytes(void) {
+  return (size_t)fgnn::kPhaseLogKinds * fgnn::kPhaseLogTiles * 8 * sizeof(unsigned long long);
+}
+extern "C" void fgnn_debug_phase_log(unsigned long long *d_buf) { fgnn::g_phase_log = d_buf; }
 
 extern "C" const char *fgnn_last_error(void) { return fgnn::g_last_error; }
 

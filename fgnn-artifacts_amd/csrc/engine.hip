@@ -6,6 +6,7 @@
 // pinned fgnn_batch_meta per batch.  Bit-identical to oracle fgnn_oracle_do_sample.
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -61,6 +62,7 @@ struct fgnn_batch {
   hipEvent_t done;
   hipEvent_t t0, t1;                      // optional: bracket the feature gather (fgnn_batch_enable_timing)
   bool timing, timed;
+  fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
 };
 
 namespace fgnn {
@@ -184,6 +186,10 @@ extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
   if (b->d_meta) (void)hipFree(b->d_meta);
   if (b->h_meta) (void)hipHostFree(b->h_meta);
   if (b->ws) (void)hipFree(b->ws);
+  if (b->scan) {
+    b->scan->destroy();
+    delete b->scan;
+  }
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->t0) (void)hipEventDestroy(b->t0);
   if (b->t1) (void)hipEventDestroy(b->t1);
@@ -227,6 +233,8 @@ extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim,
                  hipSuccess;
   b->ws_bytes = fgnn_scratch_bytes(s->max_nodes);
   ok = ok && hipMalloc(&b->ws, b->ws_bytes) == hipSuccess;
+  b->scan = new (std::nothrow) fgnn::ScanWsHost();
+  ok = ok && b->scan && b->scan->create(4096) == FGNN_OK;
   ok = ok && hipEventCreateWithFlags(&b->done, hipEventDisableTiming) == hipSuccess;
   if (!ok) return fail(FGNN_EHIP, b);
   if (hipMemset(b->d_meta, 0, sizeof(fgnn_batch_meta)) != hipSuccess) return fail(FGNN_EHIP, b);
@@ -345,7 +353,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted);
+                                      inserted, nullptr);
     if (rc != FGNN_OK) return rc;
     in_cap += ecap;
     cur = out->input_nodes;
@@ -354,7 +362,8 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   }
   if (mutates && num_seeds == 0) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
   // wipe the table for the slot's next batch (Reset, cuda_hashtable.cu:714-723), then mark the slot reusable
-  rc = fgnn_hashtable_reset(ht, stream);
+  static const bool skip_wipe = getenv("FGNN_ABLATE_WIPE") != nullptr;  // profiling only: results are wrong when set
+  if (!skip_wipe) rc = fgnn_hashtable_reset(ht, stream);
   if (rc != FGNN_OK) return rc;
   FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
   sl.was_used = true;
@@ -386,9 +395,9 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
   if (!b || !cache_table) return FGNN_EINVAL;
   // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
-  return fgnn_get_miss_cache_index(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
-                                   b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
-                                   b->ws_bytes, stream);
+  return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
+                                       b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
+                                       b->ws_bytes, stream, b->scan);
 }
 
 extern "C" int fgnn_batch_enable_timing(fgnn_batch *b, int on) {

@@ -6,6 +6,8 @@
 
 #include "fgnn_hip.h"
 
+namespace fgnn { struct ScanWsHost; }
+
 // OrderedHashTable state (hashtable.hip); the samplers insert into it directly (fused path)
 struct fgnn_hashtable {
   unsigned long long *table;  // capacity buckets of {key:hi32, value:lo32}
@@ -15,6 +17,7 @@ struct fgnn_hashtable {
   size_t capacity;            // power of two
   size_t max_items;
   uint32_t shift;             // 32 - log2(capacity)
+  fgnn::ScanWsHost *scan;     // look-back descriptors of the single-pass count+assign kernel
 };
 
 namespace fgnn {
@@ -219,7 +222,15 @@ struct ScanWs {
   uint32_t *error;           // [1] set to 1 if a spin timed out
   uint32_t gen;              // this launch's generation (1 .. 2^30-1)
   uint32_t max_tiles;
+  unsigned long long *log;   // diagnostics (fgnn_debug_phase_log): [tile][8] wall-clock stamps per phase, or null
 };
+
+constexpr uint32_t kPhaseLogTiles = 4096, kPhaseLogKinds = 4;
+// phase timestamps of the single-pass kernels (100 MHz wall clock); a no-op unless a log buffer is installed
+__device__ __forceinline__ void phase_mark(const ScanWs &w, uint32_t tile, int phase) {
+  if (w.log && threadIdx.x == 0 && tile < kPhaseLogTiles) w.log[(size_t)tile * 8 + phase] = wall_clock64();
+}
+unsigned long long *phase_log_base();  // capi.hip
 
 constexpr uint32_t kScanAggregate = 1u, kScanInclusive = 2u;
 
@@ -246,53 +257,37 @@ __device__ __forceinline__ uint32_t scan_take_tile(const ScanWs &w, uint32_t *sh
 }
 
 // exclusive prefix of `aggregate` over tiles [0, tile); call from all threads (`sh` = one LDS word).
-// Wave 0 looks back 64 predecessors at a time (lane l polls tile - 1 - l): the nearest predecessor that already
-// knows its inclusive prefix ends the walk; everything nearer contributes its aggregate.
+// Grids here are at most a few thousand tiles and start together, so a chained look-back (walk back until a
+// tile that already knows its inclusive prefix) degenerates into tile/64 dependent round trips.  Instead every
+// tile publishes only its aggregate and sums ALL its predecessors' aggregates itself: thread j polls tiles
+// j, j + blockDim, ... (coalesced 8-byte loads), i.e. ONE memory round trip after the slowest predecessor has
+// published, no dependence between tiles.  O(tiles^2) 8-byte loads in total -- ~1 M for 1500 tiles, noise.
 __device__ __forceinline__ uint32_t scan_lookback(const ScanWs &w, uint32_t tile, uint32_t aggregate, uint32_t *sh) {
-  if (threadIdx.x < kWave) {
-    const int lane = (int)threadIdx.x;
-    uint32_t excl = 0;
-    if (tile == 0) {
-      if (lane == 0) scan_publish(w, 0, kScanInclusive, aggregate);
-    } else {
-      if (lane == 0) scan_publish(w, tile, kScanAggregate, aggregate);
-      uint32_t hi = tile;  // tiles [0, hi) still to be accounted for
-      uint32_t spins = 0;
-      while (hi > 0) {
-        const bool valid = (uint32_t)lane < hi;
-        unsigned long long word = 0;
-        if (valid) word = __hip_atomic_load(&w.desc[hi - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t tag = (uint32_t)(word >> 32);
-        const bool ready = !valid || ((tag >> 2) == w.gen && (tag & 3u) != 0);
-        const unsigned long long inc = __ballot(valid && ready && (tag & 3u) == kScanInclusive);
-        const unsigned long long notready = __ballot(!ready);
-        // lanes nearer than the first not-ready lane are usable; an inclusive one among them ends the walk
-        const int first_bad = notready ? __builtin_ctzll(notready) : kWave;
-        const int first_inc = inc ? __builtin_ctzll(inc) : kWave;
-        if (first_inc < first_bad) {
-          uint32_t v = (lane <= first_inc) ? (uint32_t)word : 0u;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-          excl += v;
-          hi = 0;
-        } else if (first_bad == kWave) {  // a full window of aggregates: take them all and continue further back
-          uint32_t v = valid ? (uint32_t)word : 0u;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-          excl += v;
-          hi = hi > (uint32_t)kWave ? hi - kWave : 0;
-        } else {
-          if (++spins > (1u << 22)) {  // seconds: terminate with a wrong prefix rather than hang the GPU
-            if (lane == 0 && w.error) *w.error = 1u;
-            hi = 0;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (lane == 0) scan_publish(w, tile, kScanInclusive, excl + aggregate);
-    }
-    if (lane == 0) *sh = excl;
+  if (threadIdx.x == 0) {
+    scan_publish(w, tile, kScanAggregate, aggregate);
+    *sh = 0;
   }
+  __syncthreads();
+  uint32_t part = 0;
+  for (uint32_t j = threadIdx.x; j < tile; j += blockDim.x) {
+    uint32_t spins = 0;
+    for (;;) {
+      const unsigned long long word = __hip_atomic_load(&w.desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tag = (uint32_t)(word >> 32);
+      if ((tag >> 2) == w.gen && (tag & 3u) != 0) {
+        part += (uint32_t)word;
+        break;
+      }
+      if (++spins > (1u << 22)) {  // seconds: terminate with a wrong prefix rather than hang the GPU
+        if (w.error) *w.error = 1u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, kWave);
+  if (lane_id() == 0 && part) atomicAdd(sh, part);
   __syncthreads();
   const uint32_t r = *sh;
   __syncthreads();
@@ -320,16 +315,32 @@ int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *
 
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// compute units of the current device (256 on MI355X)
+inline int device_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
 // host side of ScanWs: owns the descriptors and hands out generations
 struct ScanWsHost {
-  ScanWs ws{nullptr, nullptr, nullptr, 0, 0};
+  ScanWs ws{nullptr, nullptr, nullptr, 0, 0, nullptr};
   int create(size_t max_tiles);
   void destroy();
   // descriptor view for the next launch; all_resident: the caller guarantees grid <= resident workgroups
-  ScanWs next(bool all_resident) {
+  // kind: which kernel family the launch belongs to (0 sampler, 1 dedup count+assign, 2 cache split) -- selects
+  // the section of the diagnostic phase log
+  ScanWs next(bool all_resident, uint32_t kind = 0) {
     ws.gen = ws.gen >= 0x3FFFFFFEu ? 1u : ws.gen + 1u;
     ScanWs v = ws;
     if (all_resident) v.ticket = nullptr;
+    unsigned long long *log = phase_log_base();
+    v.log = log ? log + (size_t)(kind % kPhaseLogKinds) * kPhaseLogTiles * 8 : nullptr;
     return v;
   }
 };
@@ -343,7 +354,13 @@ struct LayerSummary {
 };
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
-                                 size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted);
+                                 size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
+                                 ScanWsHost *scan);
+// fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
+int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
+                            const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,
+                            uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts, void *ws, size_t ws_bytes,
+                            void *stream, ScanWsHost *scan);
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).

@@ -86,6 +86,24 @@ __global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(unsigned long lo
   }
 }
 
+// Reset (cuda_hashtable.cu:714-723): all buckets empty, counts zero.  Non-temporal 16-byte stores: the wiped
+// table is not read again before the next batch has gone through the whole chain, and 64 MiB of ordinary stores
+// would sit as dirty lines in the Infinity Cache and be evicted by -- i.e. slow down -- the random reads of the
+// kernels that follow (measured: 500 K cold 4-byte reads take 21 us instead of 8 us right after a large write).
+__global__ __launch_bounds__(kBlock) void ht_wipe_kernel(unsigned long long *table, size_t capacity,
+                                                         uint32_t *d_num_items) {
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  v4 *t = reinterpret_cast<v4 *>(table);
+  const size_t n16 = capacity / 2;  // capacity is a power of two >= 1024
+  const v4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock)
+    __builtin_nontemporal_store(ones, &t[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    d_num_items[0] = 0;
+    d_num_items[1] = 0;
+  }
+}
+
 __global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_items[0] += add; }
 
 // pass 1: insert every item with value PENDING|i; remember its bucket
@@ -93,9 +111,10 @@ template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *table, uint32_t shift, uint32_t mask,
                                                            const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
-                                                           uint32_t *__restrict__ pos) {
+                                                           uint32_t *__restrict__ pos, uint32_t *d_num_items) {
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
+  if (blockIdx.x == 0 && threadIdx.x == 0) d_num_items[1] = d_num_items[0];  // count before this fill
 #pragma unroll
   for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
@@ -171,6 +190,103 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
   }
 }
 
+// passes 2 + 3 (+ most of 4) in ONE launch: a workgroup owns a contiguous chunk of `rounds` x 256 items
+// (rounds from the device-side item count, so the whole grid shares the work evenly), counts its owners, gets
+// the number of owners before it by a decoupled look-back over the earlier workgroups (fgnn_device.h) and
+// assigns local ids -- every bucket is read ONCE instead of in a count kernel and again in an assign kernel,
+// and the scan kernel between them is gone.  The remap is resolved on the spot for owners and for keys that
+// already had a local id before this fill; only duplicates WITHIN the fill (value still PENDING|other) are
+// left for ht_map_fix_kernel.  d_num_items[1] must hold the item count before the fill (set by pass 1).
+__global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(unsigned long long *table,
+                                                                 const uint32_t *__restrict__ items, size_t n_host,
+                                                                 const size_t *d_n, size_t cap,
+                                                                 const uint32_t *__restrict__ pos,
+                                                                 uint32_t *d_num_items, uint32_t *__restrict__ n2o,
+                                                                 size_t max_items, LayerSummary summary,
+                                                                 uint32_t *mapped, ScanWs scan) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  __shared__ uint32_t sh_tile;
+  const uint32_t n = (uint32_t)resolve_count64(n_host, d_n, cap);  // cap < 2^31 (host check)
+  const uint32_t per_round = kBlock * gridDim.x;
+  const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
+  const uint32_t chunk = rounds * kBlock;
+  const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
+  const uint32_t tile = blockIdx.x;
+  if (tile >= ntiles) return;  // whole workgroup; nobody looks back at an unused tile
+  phase_mark(scan, tile, 0);
+  const uint32_t old = d_num_items[1];
+  const size_t chunk0 = (size_t)tile * chunk;
+  uint32_t owner_mask = 0, cnt = 0;
+  // four rounds at a time: their loads are independent, keep them all in flight
+  for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
+    uint32_t bk[4], v[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+      ok[u] = r0 + u < rounds && i < n;
+      bk[u] = ok[u] ? pos[i] : kNoBucket;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? (uint32_t)table[bk[u]] : FGNN_EMPTY_KEY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ok[u]) {
+        const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+        if (bk[u] != kNoBucket && v[u] == (kPending | (uint32_t)i)) {
+          owner_mask |= 1u << (r0 + u);
+          ++cnt;
+        } else if (mapped) {
+          mapped[i] = v[u];  // final local id, or PENDING|owner (fixed up later), or EMPTY (no bucket)
+        }
+      }
+    }
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan<kWavesPerBlock>(cnt, sh, &tot);
+  phase_mark(scan, tile, 1);
+  const uint32_t before = scan_lookback(scan, tile, tot, &sh_tile);
+  phase_mark(scan, tile, 2);
+  if (tile == ntiles - 1 && threadIdx.x == 0) {
+    const uint32_t now = old + before + tot;
+    d_num_items[0] = now;
+    if (summary.num_dst) *summary.num_dst = old;
+    if (summary.num_src) *summary.num_src = now;
+    if (summary.num_total) *summary.num_total = now;
+  }
+  uint32_t running = old + before;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const size_t i = chunk0 + (size_t)r * kBlock + threadIdx.x;
+    const bool owner = (owner_mask >> r) & 1u;
+    uint32_t t2;
+    const uint32_t rank = block_exclusive_rank<kWavesPerBlock>(owner, sh, &t2);
+    if (owner) {
+      const uint32_t local = running + rank;
+      if (local < max_items) {
+        reinterpret_cast<uint32_t *>(&table[pos[i]])[0] = local;  // low half of the little-endian bucket = value
+        n2o[local] = items[i];
+      }
+      if (mapped) mapped[i] = local < max_items ? local : FGNN_EMPTY_KEY;
+    }
+    running += t2;
+  }
+  phase_mark(scan, tile, 3);
+}
+
+// the remap entries ht_count_assign_kernel could not resolve: duplicates inside the fill whose owner had not
+// been numbered yet.  Only those touch the table again.
+__global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(const unsigned long long *__restrict__ table,
+                                                            size_t n_host, const size_t *d_n, size_t cap,
+                                                            const uint32_t *__restrict__ pos,
+                                                            uint32_t *__restrict__ mapped) {
+  const size_t n = resolve_count64(n_host, d_n, cap);
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    const uint32_t m = mapped[i];
+    if ((m & kPending) && m != FGNN_EMPTY_KEY) mapped[i] = (uint32_t)table[pos[i]];
+  }
+}
+
 // pass 4: mapped[i] = local id of items[i] (bucket known)
 template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long long *__restrict__ table,
@@ -230,7 +346,9 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err) {
   ht->n2o = nullptr;
   ht->n2o_owned = nullptr;
   ht->d_num_items = nullptr;
-  if (hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
+  ht->scan = new ScanWsHost();
+  if (ht->scan->create(4096) != FGNN_OK ||
+      hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&ht->n2o_owned, max_items * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&ht->d_num_items, 2 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ht->table, 0xFF, cap * sizeof(unsigned long long)) != hipSuccess ||
@@ -265,6 +383,10 @@ extern "C" void fgnn_hashtable_destroy(fgnn_hashtable *ht) {
   if (ht->table) (void)hipFree(ht->table);
   if (ht->n2o_owned) (void)hipFree(ht->n2o_owned);
   if (ht->d_num_items) (void)hipFree(ht->d_num_items);
+  if (ht->scan) {
+    ht->scan->destroy();
+    delete ht->scan;
+  }
   delete ht;
 }
 
@@ -277,9 +399,11 @@ extern "C" const uint32_t *fgnn_hashtable_d_num_items(const fgnn_hashtable *ht) 
 extern "C" int fgnn_hashtable_reset(fgnn_hashtable *ht, void *stream) {
   if (!ht) return FGNN_EINVAL;
   auto s = static_cast<hipStream_t>(stream);
-  FGNN_HIP_CHECK(hipMemsetAsync(ht->table, 0xFF, ht->capacity * sizeof(unsigned long long), s));
-  FGNN_HIP_CHECK(hipMemsetAsync(ht->d_num_items, 0, 2 * sizeof(uint32_t), s));
-  return FGNN_OK;
+  size_t blocks = div_up(ht->capacity / 2, (size_t)kBlock * 4);
+  const size_t max_blocks = (size_t)device_cu_count() * 8;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(ht_wipe_kernel, dim3(blocks), dim3(kBlock), 0, s, ht->table, ht->capacity, ht->d_num_items);
+  return launch_status(__func__);
 }
 
 extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
@@ -299,12 +423,13 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
                                               const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped,
                                               void *ws, size_t ws_bytes, void *stream) {
   return fgnn::hashtable_fill_duplicates_ex(ht, items, num_items, d_num_items, num_items_cap, mapped, ws, ws_bytes,
-                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false);
+                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false, nullptr);
 }
 
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
-                                       size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted) {
+                                       size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
+                                       ScanWsHost *scan) {
   if (!ht) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
@@ -325,7 +450,28 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     else hipLaunchKernelGGL((KERNEL<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
-  if (!already_inserted) FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos);
+  if (!already_inserted)
+    FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos, ht->d_num_items);
+  if (!scan) scan = ht->scan;
+  if (scan && ipt == 1) {
+    // single-pass path: the grid must be resident at once (ticketless look-back) and a chunk at most 32 rounds
+    static int per_cu = -1;
+    if (per_cu < 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_count_assign_kernel, kBlock, 0) != hipSuccess)
+      per_cu = 0;
+    size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
+    if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
+    if (grid > nb) grid = nb;
+    if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
+      hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, ht->table, items, num_items,
+                         d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
+                         scan->next(true, 1));
+      if (mapped)
+        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap,
+                           pos, mapped);
+      return launch_status(__func__);
+    }
+  }
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
   FGNN_HT(ht_count_kernel, ht->table, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s, nullptr,

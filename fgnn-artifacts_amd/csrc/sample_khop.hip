@@ -67,6 +67,7 @@ struct FuseArgs {               // dedup insert fused into phase B (engine path)
   unsigned long long *table;    // null = not fused
   uint32_t shift, mask;
   uint32_t *pos;                // bucket of every emitted edge
+  uint32_t *d_num_items;        // the table's {count, count before the running fill}
 };
 
 // S seeds per workgroup handled by T >= S threads: the per-seed phases (0, A, C) use the first S threads, the
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
 
   const int tid = threadIdx.x;
   const size_t n = resolve_count(num_input, d_num_input, cap);
+  // this kernel is pass 1 of the dedup fill: the later passes want the item count from before the fill
+  if (fuse.table && blockIdx.x == 0 && tid == 0) fuse.d_num_items[1] = fuse.d_num_items[0];
   // single-pass mode (scan.desc != null): the workgroup's position in the seed list is an ordered ticket and the
   // output offset comes from a look-back over the earlier workgroups' edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
@@ -99,9 +102,12 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   const uint32_t tile = single_pass ? scan_take_tile(scan, &sh_tile) : blockIdx.x;
   const size_t first = (size_t)tile * S;
   if (!single_pass && first >= n) return;  // whole workgroup exits together
-  const size_t i = first + tid;
-
-  const bool seed_lane = tid < S;
+  phase_mark(scan, tile, 0);
+  // the per-seed phases (0, A, C) run on ONE S-lane group of the workgroup; which one rotates with the tile id so
+  // that the ALU-heavy swap simulation of the workgroups sharing a CU does not pile up on the same SIMD
+  const int k = tid % S;
+  const bool seed_lane = (uint32_t)(tid / S) == tile % (uint32_t)(T / S);
+  const size_t i = first + k;
   uint32_t rid = 0, off = 0, len = 0;
   if (seed_lane && i < n) {
     rid = input[i];
@@ -112,10 +118,10 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   uint32_t total;
   const uint32_t lo = block_exclusive_scan<NW>(c, sh_scan, &total);
   if (seed_lane) {
-    sh_off[tid] = off;
-    sh_len[tid] = len;
-    sh_rid[tid] = rid;
-    sh_lo[tid] = lo;
+    sh_off[k] = off;
+    sh_len[k] = len;
+    sh_rid[k] = rid;
+    sh_lo[k] = lo;
   }
   if (tid == 0) sh_lo[S] = total;
   const bool big = seed_lane && len > F;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   // ---- phase A: which CSR positions does a long row emit? ---------------------------------
   if (KHOP2) {
     if (big && (ablate & 1u)) {  // profiling only: skip the swap simulation
-      for (uint32_t j = 0; j < F; ++j) { sh_s[j * S + tid] = j; sh_w[j * S + tid] = j; sh_o[j * S + tid] = j; }
+      for (uint32_t j = 0; j < F; ++j) { sh_s[j * S + k] = j; sh_w[j * S + k] = j; sh_o[j * S + k] = j; }
     } else if (big) {
       // Simulate `for j: sel = draw % (len-j); emit A[sel]; swap(A[sel], A[len-1-j])` on POSITIONS.
       // Content of a position p at step j = origin written by the last earlier step i with
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
             }
             rs[j] = sel;
             rw[j] = w;
-            sh_w[j * S + tid] = w;
-            sh_o[j * S + tid] = o;
+            sh_w[j * S + k] = w;
+            sh_o[j * S + k] = o;
           }
         }
         // write-back flag (bit 31 of the logged position; row offsets stay below 2^31 by the host check):
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
             bool wb = rs[j] < len - F;
 #pragma unroll
             for (int q = j + 1; q < FMAX; ++q) wb = wb && !((uint32_t)q < F && rs[q] == rs[j]);
-            sh_s[j * S + tid] = rs[j] | (wb ? kWriteBack : 0u);
+            sh_s[j * S + k] = rs[j] | (wb ? kWriteBack : 0u);
           }
         }
       } else {
@@ -172,27 +178,27 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
           const uint32_t t = len - 1 - j;
           uint32_t o = sel, w = t;
           for (uint32_t q = 0; q < j; ++q) {
-            const uint32_t sq = sh_s[q * S + tid];
-            const uint32_t wq = sh_w[q * S + tid];
+            const uint32_t sq = sh_s[q * S + k];
+            const uint32_t wq = sh_w[q * S + k];
             if (sq == sel) o = wq;
             if (sq == t) w = wq;
           }
-          sh_s[j * S + tid] = sel;
-          sh_w[j * S + tid] = w;
-          sh_o[j * S + tid] = o;
+          sh_s[j * S + k] = sel;
+          sh_w[j * S + k] = w;
+          sh_o[j * S + k] = o;
         }
         for (uint32_t j = 0; j < F; ++j) {
-          const uint32_t sj = sh_s[j * S + tid];
+          const uint32_t sj = sh_s[j * S + k];
           bool wb = sj < len - F;
-          for (uint32_t q = j + 1; q < F && wb; ++q) wb = (sh_s[q * S + tid] & ~kWriteBack) != sj;
-          if (wb) sh_s[j * S + tid] = sj | kWriteBack;
+          for (uint32_t q = j + 1; q < F && wb; ++q) wb = (sh_s[q * S + k] & ~kWriteBack) != sj;
+          if (wb) sh_s[j * S + k] = sj | kWriteBack;
         }
       }
     }
   } else {
     // reservoir: slot k ends up with A[max{j >= F : draw_j % (j+1) == k}], or A[k] if none.
     if (seed_lane)
-      for (uint32_t q = 0; q < F; ++q) sh_o[q * S + tid] = q;
+      for (uint32_t q = 0; q < F; ++q) sh_o[q * S + k] = q;
     __syncthreads();
     // wave-parallel over each long row of this workgroup (rows can be millions long)
     for (int k = wave_id(); k < S; k += NW) {
@@ -214,11 +220,13 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
   }
   __syncthreads();
+  phase_mark(scan, tile, 1);
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   size_t base;
   if (single_pass) {
     base = scan_lookback(scan, tile, total, &sh_tile);
+    phase_mark(scan, tile, 2);
     if (tile == gridDim.x - 1 && tid == 0 && d_num_out) *d_num_out = base + total;
   } else {
     base = block_offsets[tile];
@@ -274,16 +282,18 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   }
 
   // ---- phase C (khop2): apply the swaps to the CSR row, one lane per long row -------------------
+  phase_mark(scan, tile, 3);
   if (KHOP2 && !(ablate & 4u)) {
     __syncthreads();  // every read of the old row contents above has been consumed
     if (big) {
       for (uint32_t j = 0; j < F; ++j) {
-        indices[off + len - 1 - j] = sh_o[j * S + tid];  // the emitted value moves to the consumed tail slot
-        const uint32_t sj = sh_s[j * S + tid];
-        if (sj & kWriteBack) indices[off + (sj & ~kWriteBack)] = sh_w[j * S + tid];
+        indices[off + len - 1 - j] = sh_o[j * S + k];  // the emitted value moves to the consumed tail slot
+        const uint32_t sj = sh_s[j * S + k];
+        if (sj & kWriteBack) indices[off + (sj & ~kWriteBack)] = sh_w[j * S + k];
       }
     }
   }
+  phase_mark(scan, tile, 4);
 }
 
 template <bool KHOP2>
@@ -306,11 +316,15 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   // small workgroups for small frontiers: the kernel is latency-bound, more resident waves hide more of it
   int S = 256;
   while (S > 64 && (words_per_seed * S * 4 > 120 * 1024 || cap / S < 2048)) S >>= 1;
+  if (const char *e_s = getenv("FGNN_KHOP_S")) {  // tuning knob (profiles/ sweeps only)
+    const int v = atoi(e_s);
+    if (v == 64 || v == 128 || v == 256) S = v;
+  }
   if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
   const size_t nb = div_up(cap, (size_t)S);
   const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
   const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
-  FuseArgs fuse{nullptr, 0, 0, nullptr};
+  FuseArgs fuse{nullptr, 0, 0, nullptr, nullptr};
   uint32_t *sums = static_cast<uint32_t *>(ws);
   if (fuse_ht) {
     // ws = pos[cap*F] (consumed by the dedup passes) | dedup sums | ... ; this kernel's offsets go at the very end
@@ -319,12 +333,13 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     fuse.shift = fuse_ht->shift;
     fuse.mask = (uint32_t)(fuse_ht->capacity - 1);
     fuse.pos = static_cast<uint32_t *>(ws);
+    fuse.d_num_items = fuse_ht->d_num_items;
     sums = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes) - (nb + 4);
   } else if (ws_bytes < (nb + 1) * sizeof(uint32_t)) {
     return FGNN_ENOSPC;
   }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
-  ScanWs scan{nullptr, nullptr, nullptr, 0, 0};
+  ScanWs scan{nullptr, nullptr, nullptr, 0, 0, nullptr};
   bool want_scan = scan_host && nb <= scan_host->ws.max_tiles;
 
 #define FGNN_LAUNCH_KHOP2(SS, FM)                                                                              \
@@ -349,6 +364,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
       if (nb <= (size_t)per_cu * 256 * 3 / 4) scan = scan_host->next(true);                                    \
     }                                                                                                          \
     if (!scan.desc) {                                                                                          \
+      scan.log = phase_log_base();                                                                             \
       hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,   \
                          d_num_input, cap, F, sums);                                                           \
       if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, stream, d_num_input, SS) !=   \

@@ -47,6 +47,11 @@ const char *fgnn_version(void);
 /* text of the last HIP runtime failure on this thread (FGNN_EHIP) */
 const char *fgnn_last_error(void);
 int fgnn_device_count(void);
+/* Diagnostics (tools/phase_probe.py): install a device buffer of fgnn_debug_phase_log_bytes() bytes and the
+ * single-pass kernels (sampler, dedup count+assign, cache split) stamp a 100 MHz wall clock per workgroup at
+ * their phase boundaries: u64[kind 0..3][tile 0..4095][phase 0..7].  NULL (the default) switches it off. */
+size_t fgnn_debug_phase_log_bytes(void);
+void fgnn_debug_phase_log(unsigned long long *d_buf);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);
