@@ -29,11 +29,42 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 WORKLOADS = {
     # name: shape + run config (reference defaults: batch 8000, common_config.py:63; fanout train_graphsage.py:77)
-    "papers100M": dict(**synth.DATASET_SHAPES["papers100M"], fanout=[25, 10], batch_size=8000),
-    "products": dict(**synth.DATASET_SHAPES["products"], fanout=[25, 10], batch_size=8000),
+    "papers100M": dict(**synth.DATASET_SHAPES["papers100M"], fanout=[25, 10], batch_size=8000, sample_type="khop2"),
+    "products": dict(**synth.DATASET_SHAPES["products"], fanout=[25, 10], batch_size=8000, sample_type="khop2"),
+    # BASELINE.json config 4's sampler side: GCN with weighted sampling (multi_gpu/train_gcn.py:72 fanout [5,10,15])
+    "twitter": dict(**synth.DATASET_SHAPES["twitter"], fanout=[5, 10, 15], batch_size=8000,
+                    sample_type="weighted_khop_prefix"),
+    # config 5's sampler side: PinSAGE random walks (multi_gpu/train_pinsage.py:130-134 with num_walks = 25)
+    "uk-2006-05": dict(**synth.DATASET_SHAPES["uk-2006-05"], fanout=[5, 5, 5], batch_size=8000,
+                       sample_type="random_walk", walk_len=3, num_walks=25, restart_prob=0.5),
     "small": dict(num_node=1_000_000, num_edge=20_000_000, feat_dim=128, num_class=47, num_train=100_000,
-                  fanout=[25, 10], batch_size=8000),
+                  fanout=[25, 10], batch_size=8000, sample_type="khop2"),
 }
+SAMPLE_TYPES = {"khop0": lib.KHOP0, "khop1": lib.KHOP1, "khop2": lib.KHOP2, "weighted_khop_prefix": lib.WEIGHTED_KHOP_PREFIX,
+                "random_walk": lib.RANDOM_WALK}
+
+
+def gen_prefix_on_gpu(indptr, total, seed, device):
+    """prob_prefix_table (f32[E], per-row inclusive prefix sums of random edge weights), built in row chunks."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(total, dtype=torch.float32, device=device)
+    ip = indptr.to(torch.int64) & 0xFFFFFFFF
+    n = ip.numel() - 1
+    rows_per = 1 << 22
+    for r0 in range(0, n, rows_per):
+        r1 = min(n, r0 + rows_per)
+        a, b = int(ip[r0]), int(ip[r1])
+        if b == a:
+            continue
+        wts = torch.rand(b - a, generator=g, device=device, dtype=torch.float32).to(torch.float64) + 1e-3
+        cs = torch.cumsum(wts, 0)
+        lens = ip[r0 + 1:r1 + 1] - ip[r0:r1]
+        starts = ip[r0:r1] - a
+        base = torch.where(starts > 0, cs[(starts - 1).clamp_(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+        out[a:b] = (cs - torch.repeat_interleave(base, lens)).to(torch.float32)
+        del wts, cs, lens, starts, base
+    return out
 
 
 def gen_graph_on_gpu(num_node, num_edge, seed, device):
@@ -194,6 +225,50 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
     }
 
 
+def cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train, budget_s=12.0):
+    """Weighted / random-walk workloads: the oracle's single-thread restatement of the same pipeline (the reference
+    has no CPU twin of these samplers: its arch0 supports khop0/khop2 only, cpu_loops.cc:84-97), a few batches."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as oracle
+    oracle.build()
+    h_indptr = indptr.cpu().numpy().view(np.uint32)
+    h_indices = indices.cpu().numpy().view(np.uint32).copy()
+    h_prefix = prefix.cpu().numpy() if prefix is not None else None
+    mock_bits = min(24, int(np.floor(np.log2(feat.shape[0]))))
+    h_feat = feat[:1 << mock_bits].cpu().numpy()
+    mask = (1 << mock_bits) - 1
+    fan, bs = w["fanout"], w["batch_size"]
+    num_node = h_indptr.shape[0] - 1
+    st = {"weighted_khop_prefix": oracle.WEIGHTED_KHOP_PREFIX, "random_walk": oracle.RANDOM_WALK,
+          "khop1": oracle.KHOP1}[args.sample_type]
+    kw = {}
+    if st == oracle.WEIGHTED_KHOP_PREFIX:
+        kw = dict(prob_prefix=h_prefix)
+    if st == oracle.RANDOM_WALK:
+        kw = dict(walk_len=w["walk_len"], num_walks=w["num_walks"], num_neighbor=fan[0], restart_prob=w["restart_prob"])
+    rng = oracle.make_rng(oracle.RNG_PHILOX, args.seed)
+    ht = oracle.HashTable(num_node, oracle.predict_num_nodes(bs, fan))
+    h_train = train.cpu().numpy().view(np.uint32)
+    edges = rows = nb = 0
+    t_total = 0.0
+    k = 0
+    while t_total < budget_s and (k + 1) * bs <= len(h_train):
+        seeds = np.ascontiguousarray(h_train[k * bs:(k + 1) * bs])
+        t1 = time.time()
+        task = oracle.do_sample(h_indptr, h_indices, seeds, fan, st, rng, k, ht, **kw)
+        _ = h_feat[task["input_nodes"] & mask]
+        t_total += time.time() - t1
+        edges += task["total_edges"]
+        rows += len(task["input_nodes"])
+        nb += 1
+        k += 1
+    return {"value": edges / t_total, "unit": "sampled-edges/s", "cores": 1, "kind": "port",
+            "sample": f"{nb} batches of {bs} seeds, {args.sample_type} fanout {fan}, same graph, whole path (sample + dedup "
+                      f"+ remap + feature gather) in {t_total:.1f}s, single thread (oracle restatement; the reference has "
+                      f"no CPU twin of this sampler); feature table masked to 2^{mock_bits} rows",
+            "rows_per_s": rows / t_total, "host_cpus": os.cpu_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,8 +279,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
     ap.add_argument("--host-threads", type=int, default=2, help="host threads = HIP streams = batches in flight")
-    ap.add_argument("--sample-type", default="khop2", choices=["khop2", "khop0"],
-                    help="khop2 = the reference's default for GraphSAGE (multi_gpu/train_graphsage.py:75)")
+    ap.add_argument("--sample-type", default=None, choices=list(SAMPLE_TYPES),
+                    help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
+                         "multi_gpu/train_graphsage.py:75)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
     args = ap.parse_args()
 
@@ -224,6 +300,8 @@ def main():
     lib.load()
 
     w = WORKLOADS[args.workload]
+    if args.sample_type is None:
+        args.sample_type = w["sample_type"]
     t_setup = time.time()
     indptr, indices, num_edge = gen_graph_on_gpu(w["num_node"], w["num_edge"], 42, dev)
     feat = gen_features_on_gpu(w["num_node"], w["feat_dim"], dev)
@@ -247,8 +325,10 @@ def main():
     steps_per_epoch = (train.numel() + bs - 1) // bs
     local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
-    sampler = lib.Sampler(indptr, indices, w["fanout"], bs,
-                          sample_type=lib.KHOP2 if args.sample_type == "khop2" else lib.KHOP0, seed=args.seed)
+    prefix = gen_prefix_on_gpu(indptr, num_edge, 11, dev) if args.sample_type == "weighted_khop_prefix" else None
+    sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=SAMPLE_TYPES[args.sample_type], seed=args.seed,
+                          prob_prefix=prefix, walk_len=w.get("walk_len", 3), num_walks=w.get("num_walks", 4),
+                          restart_prob=w.get("restart_prob", 0.5))
     NT = 1 if args.no_overlap else args.host_threads
     NBUF = 2 * NT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
@@ -270,6 +350,8 @@ def main():
         step = (local_first + i) % steps_per_epoch
         return step, train[step * bs:min(train.numel(), (step + 1) * bs)]
 
+    extract = [True]  # False: sample + dedup + remap + cache-index split only (the sampler-side stage)
+
     def worker(t, first, last, timed):
         torch.cuda.set_device(dev)
         if t >= NT:
@@ -281,16 +363,19 @@ def main():
                 m = bt.wait()
                 if timed:
                     mine.append(m)
-                    gm.append(bt.gather_ms())
+                    gm.append(bt.gather_ms() if extract[0] else -1.0)
             step, seeds = seeds_of(i)
             t_h = time.perf_counter()
-            sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[t])
+            if extract[0]:
+                sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[t])
+            else:
+                sampler.run_batch(i, seeds, step, bt, table, None, None, stream=streams[t])
             host_busy[t] += time.perf_counter() - t_h
         for i in range(max(first, last - NBUF) + ((t - max(first, last - NBUF)) % NT), last, NT):
             m = batches[i % NBUF].wait()
             if timed:
                 mine.append(m)
-                gm.append(batches[i % NBUF].gather_ms())
+                gm.append(batches[i % NBUF].gather_ms() if extract[0] else -1.0)
         with lock:
             metas.extend(mine)
             gather_ms.extend(gm)
@@ -322,12 +407,32 @@ def main():
     # the same kernel with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency
     # from the slowdown it accepts when it shares the chip with the next batch's sampling chain
     serial = None
+    next_seq = args.warmup + args.steps  # sequence numbers must stay consecutive
+    metas_t, gather_t = list(metas), list(gather_ms)
+    # the sampler-side stage alone (what the reference's kLogEpochSampleTotalTime covers: shuffle slice + sample +
+    # dedup + remap + cache-index split, dist_loops_arch5.cc:98-105), same overlap, no feature gather
+    metas.clear()
+    gather_ms.clear()
+    extract[0] = False
+    n_stage = min(args.steps, 64)
+    run_region(next_seq, next_seq + 8, False)
+    next_seq += 8
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_region(next_seq, next_seq + n_stage, True)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t1
+    next_seq += n_stage
+    stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+    sample_stage = {"edges_per_s": stage_edges / t_stage, "ms_per_step": t_stage / n_stage * 1e3, "steps": n_stage,
+                    "note": "sample + dedup + remap + cache-index split only (no feature gather), same overlap"}
+    extract[0] = True
+    metas.clear()
+    gather_ms.clear()
     if NT > 1:
-        metas_t, gather_t, nt_saved = list(metas), list(gather_ms), NT
-        metas.clear()
-        gather_ms.clear()
+        nt_saved = NT
         NT = 1
-        base_seq = args.warmup + args.steps  # sequence numbers must stay consecutive
+        base_seq = next_seq
         run_region(base_seq, base_seq + 24, True)
         torch.cuda.synchronize()
         g = [x for x in gather_ms if x >= 0]
@@ -337,8 +442,8 @@ def main():
             serial = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(g)), "unit": "GB/s",
                       "note": "same launch with no concurrent batch (1 host thread / stream)"}
         NT = nt_saved
-        metas[:] = metas_t
-        gather_ms[:] = gather_t
+    metas[:] = metas_t
+    gather_ms[:] = gather_t
 
     # metas hold ctypes structs that alias nothing (copied by value in wait())
     edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
@@ -356,8 +461,8 @@ def main():
     ratio = pmc_traffic_ratio()
     if rank == 0:
         out = {
-            "metric": "sampled-edges/sec (GraphSAGE fanout 25/10, batch 8000, full hot path: sample + dedup + remap + "
-                      "cache-index split + feature/label gather)",
+            "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, full hot "
+                      "path: sample + dedup + remap + cache-index split + feature/label gather)",
             "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -378,6 +483,7 @@ def main():
             "epoch_time_s": {"sample_plus_extract": steps_per_epoch * (elapsed / args.steps) / world,
                              "note": f"{steps_per_epoch} steps/epoch x ms_per_step / n_gpus; no training step -- the "
                                      "reference's Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s)"},
+            "sample_stage": sample_stage if world == 1 else None,
             "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps / world,
             "input_nodes_per_step": rows / args.steps / world,
             "algorithmic_bytes_per_step": {k: v / len(metas) for k, v in ab.items()},
@@ -387,7 +493,10 @@ def main():
             "host_threads": NT, "host_enqueue_ms_per_step": sum(host_busy) / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)
+            if args.sample_type in ("khop2", "khop0"):
+                out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)
+            else:
+                out["cpu_baseline"] = cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

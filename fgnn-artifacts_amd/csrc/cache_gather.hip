@@ -302,15 +302,16 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
   uint32_t *slot = static_cast<uint32_t *>(ws);
   uint32_t *sums = slot + cap;
   uint32_t *total = sums + nb;
-  if (scan && ipt == 1) {
+  if (scan) {
     // single-pass path: grid resident at once (ticketless look-back), a chunk at most 32 rounds
     static int per_cu = -1;
     if (per_cu < 0 &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cache_split_fused_kernel, kBlock, 0) != hipSuccess)
       per_cu = 0;
+    const size_t nb1 = div_up(cap, (size_t)kBlock);
     size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
     if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
-    if (grid > nb) grid = nb;
+    if (grid > nb1) grid = nb1;
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
       const char *e_ab = getenv("FGNN_SPLIT_ABLATE");  // profiling only; results are wrong when set
       const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;

@@ -453,21 +453,22 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (!already_inserted)
     FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos, ht->d_num_items);
   if (!scan) scan = ht->scan;
-  if (scan && ipt == 1) {
+  if (scan) {
     // single-pass path: the grid must be resident at once (ticketless look-back) and a chunk at most 32 rounds
     static int per_cu = -1;
     if (per_cu < 0 &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_count_assign_kernel, kBlock, 0) != hipSuccess)
       per_cu = 0;
+    const size_t nb1 = div_up(cap, (size_t)kBlock);
     size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
     if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
-    if (grid > nb) grid = nb;
+    if (grid > nb1) grid = nb1;
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, ht->table, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
                          scan->next(true, 1));
       if (mapped)
-        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap,
+        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap,
                            pos, mapped);
       return launch_status(__func__);
     }

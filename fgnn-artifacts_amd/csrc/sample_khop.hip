@@ -128,29 +128,53 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
 
   // ---- phase A: which CSR positions does a long row emit? ---------------------------------
   if (KHOP2) {
+    // A.1 (all T threads): the draws.  sel_j = philox(item, j) % (len - j) depends only on the row length, so the
+    // T/S lane groups split the Philox blocks of every long row between them and leave sel_j in the swap-log slots.
+    // This takes the Philox rounds and the 32-bit modulos off the one wave that runs the serial recurrence below.
+    __syncthreads();  // sh_len of every seed is visible
+    {
+      constexpr uint32_t G = T / S;
+      const uint32_t klen = sh_len[k];
+      if (klen > F && !(ablate & 1u)) {
+        const uint32_t item = (uint32_t)(first + k);
+        for (uint32_t blk_id = (uint32_t)tid / S; blk_id * 4 < F; blk_id += G) {
+          const u32x4 blk = philox_block(seed, batch_key, tag, item, blk_id);
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t j = blk_id * 4 + u;
+            if (j < F) sh_s[j * S + k] = pick_word(blk, u) % (klen - j);
+          }
+        }
+      }
+    }
+    __syncthreads();
     if (big && (ablate & 1u)) {  // profiling only: skip the swap simulation
       for (uint32_t j = 0; j < F; ++j) { sh_s[j * S + k] = j; sh_w[j * S + k] = j; sh_o[j * S + k] = j; }
     } else if (big) {
-      // Simulate `for j: sel = draw % (len-j); emit A[sel]; swap(A[sel], A[len-1-j])` on POSITIONS.
+      // A.2 (one lane per long row): simulate `for j: emit A[sel_j]; swap(A[sel_j], A[len-1-j])` on POSITIONS.
       // Content of a position p at step j = origin written by the last earlier step i with
       // s_i == p, else p itself (a consumed tail position len-1-i is never touched again).
       //   o_j = content(sel_j)      -> emitted origin
       //   w_j = content(len-1-j)    -> origin that moves into position sel_j
       if (FMAX > 0) {
         // fanout <= FMAX: the swap log lives in registers (fully unrolled, static indices); the LDS
-        // copies below are write-only here -- no LDS round trip inside the O(F^2) recurrence
+        // copies below are write-only here -- no LDS round trip inside the O(F^2) recurrence.
+        // Write-back flag (bit 31 of the logged position; row offsets stay below 2^31 by the host check):
+        // position s_j receives a value iff it is not a consumed tail slot and no later step writes it again;
+        // "a later step hits the same position" is the very comparison the recurrence makes for o_j.
         uint32_t rs[FMAX > 0 ? FMAX : 1], rw[FMAX > 0 ? FMAX : 1];
-        u32x4 blk{0, 0, 0, 0};
+        uint32_t keep = 0xffffffffu;  // bit q: step q's write to s_q is still the last one
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
           if ((uint32_t)j < F) {
-            if ((j & 3) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, (uint32_t)j >> 2);
-            const uint32_t sel = pick_word(blk, (uint32_t)j) % (len - (uint32_t)j);
+            const uint32_t sel = sh_s[j * S + k];
             const uint32_t t = len - 1 - (uint32_t)j;
             uint32_t o = sel, w = t;
 #pragma unroll
             for (int q = 0; q < j; ++q) {
-              o = rs[q] == sel ? rw[q] : o;
+              const bool hit = rs[q] == sel;
+              o = hit ? rw[q] : o;
+              keep = hit ? keep & ~(1u << q) : keep;
               w = rs[q] == t ? rw[q] : w;
             }
             rs[j] = sel;
@@ -159,22 +183,16 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
             sh_o[j * S + k] = o;
           }
         }
-        // write-back flag (bit 31 of the logged position; row offsets stay below 2^31 by the host check):
-        // position s_j receives a value iff it is not a consumed tail slot and no later step writes it again
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
           if ((uint32_t)j < F) {
-            bool wb = rs[j] < len - F;
-#pragma unroll
-            for (int q = j + 1; q < FMAX; ++q) wb = wb && !((uint32_t)q < F && rs[q] == rs[j]);
+            const bool wb = rs[j] < len - F && ((keep >> j) & 1u);
             sh_s[j * S + k] = rs[j] | (wb ? kWriteBack : 0u);
           }
         }
       } else {
-        u32x4 blk{0, 0, 0, 0};
         for (uint32_t j = 0; j < F; ++j) {
-          if ((j & 3u) == 0) blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 2);
-          const uint32_t sel = pick_word(blk, j) % (len - j);
+          const uint32_t sel = sh_s[j * S + k];
           const uint32_t t = len - 1 - j;
           uint32_t o = sel, w = t;
           for (uint32_t q = 0; q < j; ++q) {
@@ -183,7 +201,6 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
             if (sq == sel) o = wq;
             if (sq == t) w = wq;
           }
-          sh_s[j * S + k] = sel;
           sh_w[j * S + k] = w;
           sh_o[j * S + k] = o;
         }

@@ -428,3 +428,45 @@ def test_batch_driver_with_replacement(hip, oracle, mode):
             np.testing.assert_array_equal(host_u32(row), g["row"])
             np.testing.assert_array_equal(host_u32(col), g["col"])
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
+@pytest.mark.gpu
+def test_batch_driver_large_frontier(hip, oracle):
+    """A frontier of millions of edges / nodes (GCN-style fanout [5,10,15]): the single-launch dedup and cache-split
+    kernels then run many rounds per workgroup and the worst-case capacity exceeds 4 M items."""
+    from fgnn_hip import synth
+    num_node, batch, fanouts, dim = 6_000_000, 12000, [6, 10, 15], 4
+    indptr, indices = synth.powerlaw_csr(num_node, 90_000_000, seed=12)
+    rank = np.random.default_rng(2).permutation(num_node).astype(np.uint32)
+    table = oracle.cache_table_build(rank, num_node // 5, num_node)
+    feat = synth.node_features(num_node, dim)
+    label = np.random.default_rng(1).integers(0, 47, size=num_node).astype(np.int64)
+    d_indices = dev(indices.copy())
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=hip.KHOP2, seed=SEED)
+    assert sampler.max_nodes == oracle.predict_num_nodes(batch, fanouts) > (4 << 20)
+    bt = sampler.new_batch(dim, hip.F32, hip.I64)
+    d_feat, d_label, d_table = dev(feat), dev(label), dev(table)
+    o_indices = indices.copy()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for b in range(2):
+        seeds = _seeds(batch, num_node, seed=300 + b)
+        sampler.sample(dev(seeds), 50 + b, bt)
+        bt.cache_index(d_table)
+        bt.extract(d_feat, d_label)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, oracle.KHOP2, rng, 50 + b, oht)
+        assert m.overflow == 0 and m.num_input == len(want["input_nodes"]) > 1_600_000  # > 4 rounds of 1536 x 256
+        for li in range(len(fanouts)):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        nodes = host_u32(bt.input_nodes())
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        for got, w in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(table, nodes)):
+            np.testing.assert_array_equal(host_u32(got), w)
+        assert bt.feat().cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
