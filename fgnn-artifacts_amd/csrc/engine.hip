@@ -99,6 +99,11 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     case FGNN_WEIGHTED_KHOP:
       if (!cfg->prob_table || !cfg->alias_table) return fail(FGNN_EINVAL);
       break;
+    case FGNN_WEIGHTED_KHOP_HASH_DEDUP:
+      if (!cfg->prob_table || !cfg->alias_table) return fail(FGNN_EINVAL);
+      for (size_t l = 0; l < cfg->num_layers; ++l)
+        if (cfg->fanout[l] > 50) return fail(FGNN_EINVAL);  // the reference's 50-slot table
+      break;
     case FGNN_WEIGHTED_KHOP_PREFIX:
       if (!cfg->prob_prefix) return fail(FGNN_EINVAL);
       break;
@@ -106,7 +111,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
       if (cfg->walk_len == 0 || cfg->num_walks == 0) return fail(FGNN_EINVAL);
       break;
     default:
-      return fail(FGNN_EINVAL);  // weighted_khop_hash_dedup: not built
+      return fail(FGNN_EINVAL);
   }
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
@@ -332,6 +337,10 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       rc = fgnn_sample_weighted_khop(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
                                      cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
                                      s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream);
+    else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
+      rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
+                                   cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
+                                   s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream, &sl.scan_sample);
     else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
       // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
       rc = fgnn_sample_random_walk(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,

@@ -104,7 +104,12 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
   if (const char *e = getenv("SAMGRAPH_MQ_BYTES")) mq_budget_bytes = strtoull(e, nullptr, 10);
   switch (sample_type) {
     case kKHop0: case kKHop1: case kKHop2: case kWeightedKHop: case kWeightedKHopPrefix: case kRandomWalk: break;
-    default: SAM_FATAL << "sample type " << sample_type << " is not built (weighted_khop_hash_dedup)";
+    case kWeightedKHopHashDedup:
+      // the reference's per-thread table has 50 slots (cuda_sampling_weighted_khop_hash_dedup.cu:43-72); with a
+      // larger fanout its sampler never returns
+      for (size_t f : fanout) SAM_CHECK(f <= 50) << "weighted_khop_hash_dedup: fanout " << f << " > 50";
+      break;
+    default: SAM_FATAL << "unknown sample type " << sample_type;
   }
   is_configured = true;
 }

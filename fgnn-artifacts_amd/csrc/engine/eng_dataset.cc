@@ -103,7 +103,7 @@ void Dataset::Load(const RunConfig &rc) {
   }
   if (rc.sample_type == kWeightedKHopPrefix)
     prob_prefix = MapFile(dir + "prob_prefix_table.bin", num_edge * 4, true);
-  if (rc.sample_type == kWeightedKHop) {  // engine.cc:175-186
+  if (rc.sample_type == kWeightedKHop || rc.sample_type == kWeightedKHopHashDedup) {  // engine.cc:175-186
     prob_table = MapFile(dir + "prob_table.bin", num_edge * 4, true);
     alias_table = MapFile(dir + "alias_table.bin", num_edge * 4, true);
   }

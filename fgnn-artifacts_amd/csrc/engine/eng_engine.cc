@@ -129,7 +129,7 @@ void Engine::UploadTopology(int device) {
     SAM_HIP(hipMalloc(&d_prefix_, ds_.prob_prefix.bytes ? ds_.prob_prefix.bytes : 4));
     SAM_HIP(hipMemcpy(d_prefix_, ds_.prob_prefix.ptr, ds_.prob_prefix.bytes, hipMemcpyHostToDevice));
   }
-  if (RC().sample_type == kWeightedKHop) {
+  if (RC().sample_type == kWeightedKHop || RC().sample_type == kWeightedKHopHashDedup) {
     SAM_HIP(hipMalloc(&d_prob_, ds_.prob_table.bytes ? ds_.prob_table.bytes : 4));
     SAM_HIP(hipMalloc(&d_alias_, ds_.alias_table.bytes ? ds_.alias_table.bytes : 4));
     SAM_HIP(hipMemcpy(d_prob_, ds_.prob_table.ptr, ds_.prob_table.bytes, hipMemcpyHostToDevice));

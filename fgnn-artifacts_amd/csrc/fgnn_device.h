@@ -361,6 +361,12 @@ int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,
                             uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts, void *ws, size_t ws_bytes,
                             void *stream, ScanWsHost *scan);
+// fgnn_sample_weighted_khop_hash_dedup with the slot's look-back descriptors (scan == null: descriptors in ws)
+int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                      const uint32_t *alias_table, const uint32_t *input, size_t num_input, const uint32_t *d_num_input,
+                      size_t num_input_cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out,
+                      int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
+                      void *stream, ScanWsHost *scan_host);
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).

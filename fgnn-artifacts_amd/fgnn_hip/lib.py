@@ -23,6 +23,7 @@ EXPORTS = [
     "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
+    "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
     "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
@@ -136,7 +137,7 @@ def sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, seed, batc
 
 def sample_with_replacement(kind, indptr, indices, inp, fanout, seed, batch_key, layer, prob=None, alias=None,
                             src_mode=SRC_GLOBAL):
-    """kind in {'khop1', 'weighted_khop'} (alias method)."""
+    """kind in {'khop1', 'weighted_khop' (alias method), 'weighted_khop_hash_dedup'}."""
     L = load()
     _need_gpu(indptr, indices, inp)
     L.fgnn_weighted_scratch_bytes.restype = C.c_size_t
@@ -151,6 +152,9 @@ def sample_with_replacement(kind, indptr, indices, inp, fanout, seed, batch_key,
             C.c_size_t(ws.numel()), _stream())
     if kind == "khop1":
         _check(L.fgnn_sample_khop1(_ptr(indptr), _ptr(indices), *tail), "fgnn_sample_khop1")
+    elif kind == "weighted_khop_hash_dedup":
+        _check(L.fgnn_sample_weighted_khop_hash_dedup(_ptr(indptr), _ptr(indices), _ptr(prob), _ptr(alias), *tail),
+               "fgnn_sample_weighted_khop_hash_dedup")
     else:
         _check(L.fgnn_sample_weighted_khop(_ptr(indptr), _ptr(indices), _ptr(prob), _ptr(alias), *tail),
                "fgnn_sample_weighted_khop")
@@ -286,7 +290,7 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
 # batch driver (fgnn_sampler / fgnn_batch)
 
 MAX_LAYERS = 8
-KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2 = 0, 1, 2, 3, 4, 5
+KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2, WEIGHTED_KHOP_HASH_DEDUP = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",

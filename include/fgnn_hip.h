@@ -36,7 +36,7 @@ extern "C" {
 enum { FGNN_F32 = 0, FGNN_F64 = 1, FGNN_F16 = 2, FGNN_U8 = 3, FGNN_I32 = 4, FGNN_I8 = 5, FGNN_I64 = 6 };
 /* SampleType, common.h:50-58 (only used to derive RNG tags) */
 enum { FGNN_KHOP0 = 0, FGNN_KHOP1 = 1, FGNN_WEIGHTED_KHOP = 2, FGNN_RANDOM_WALK = 3, FGNN_WEIGHTED_KHOP_PREFIX = 4,
-       FGNN_KHOP2 = 5 };
+       FGNN_KHOP2 = 5, FGNN_WEIGHTED_KHOP_HASH_DEDUP = 6 };
 
 /* out_src contents of the samplers */
 enum { FGNN_SRC_GLOBAL = 0, /* seed's global id, as the reference emits (khop2.cu:79) */
@@ -99,6 +99,17 @@ int fgnn_sample_weighted_khop(const uint32_t *indptr, const uint32_t *indices, c
                               const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                               uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                               uint32_t layer, void *ws, size_t ws_bytes, void *stream);
+/* GPUSampleWeightedKHopHashDedup (cuda_sampling_weighted_khop_hash_dedup.cu:206-282): alias-method draws, a draw whose
+ * value the seed already selected is rejected until `fanout` distinct neighbours are found (rows of length <= fanout
+ * are taken whole); output in seed order, no sort.  fanout <= 50 (the reference's per-thread table).  A seed gives up
+ * after 64 * fanout attempts (the reference would spin forever).  Scratch: fgnn_hash_dedup_scratch_bytes. */
+size_t fgnn_hash_dedup_scratch_bytes(size_t num_input_cap);
+int fgnn_sample_weighted_khop_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
+                                         const uint32_t *alias_table, const uint32_t *input, size_t num_input,
+                                         const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
+                                         uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
+                                         uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
+                                         void *stream);
 
 /* GPUSampleRandomWalk + FrequencyHashmap::GetTopK (cuda_sampling_random_walk.cu:113-161,
  * cuda_frequency_hashmap.cu:1143-1367): num_walks restart walks of walk_len steps per seed; per seed

@@ -11,8 +11,8 @@
  *
  * Supported run architectures (RunArch, common.h:70-79): arch1 (one GPU samples and extracts,
  * cuda/cuda_loops_arch1.cc) and arch5 (FGNN: sampler processes + trainer processes linked by the
- * pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc).  Sample types: khop0, khop1,
- * khop2, weighted_khop, weighted_khop_prefix, random_walk (all but weighted_khop_hash_dedup).  Cache policies: pre_sample (computed at sample_init,
+ * pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc).  Sample types: all seven (khop0,
+ * khop1, khop2, weighted_khop, weighted_khop_hash_dedup, weighted_khop_prefix, random_walk).  Cache policies: pre_sample (computed at sample_init,
  * dist/pre_sampler.cc) and the file-backed rankings (cache_by_*.bin, engine.cc:216-256).
  */
 #ifndef SAMGRAPH_H

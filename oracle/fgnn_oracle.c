@@ -333,6 +333,49 @@ void fgnn_oracle_sample_weighted_khop(const uint32_t *indptr, const uint32_t *in
                           out_src, out_dst, num_out, rng, batch_key, layer);
 }
 
+/* weighted_khop_hash_dedup (cuda_sampling_weighted_khop_hash_dedup.cu:41-111): alias-method draws, a draw whose
+ * VALUE this seed has already selected is rejected (the per-thread 50-slot table tagged with the seed id is a set
+ * membership test), until `fanout` distinct values are found; rows of length <= fanout are taken whole in CSR
+ * order.  Output padded to fanout per seed, then count + compact (seed-major, no sort).
+ * Attempt t of a seed uses draws 2t (k = draw % len) and 2t+1 (r = uniform (0,1]); r > prob[k] picks the alias.
+ * Deviation, stated: the reference never terminates on a row with fewer than `fanout` distinct selectable values
+ * (and for fanout > 50, its table size); here a seed gives up after FGNN_HASH_DEDUP_MAX_ATTEMPTS(fanout) attempts and
+ * emits what it has, and fanout > FGNN_HASH_DEDUP_MAX_FANOUT is rejected by the callers. */
+void fgnn_oracle_sample_weighted_khop_hash_dedup(const uint32_t *indptr, const uint32_t *indices,
+                                                 const float *prob_table, const uint32_t *alias_table,
+                                                 const uint32_t *input, size_t num_input, size_t fanout,
+                                                 uint32_t *out_src, uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
+                                                 uint64_t batch_key, uint32_t layer) {
+  const uint32_t tag = khop_tag(FGNN_WEIGHTED_KHOP_HASH_DEDUP, layer);
+  if (rng->mode != FGNN_RNG_PHILOX || fanout > FGNN_HASH_DEDUP_MAX_FANOUT) abort();
+  for (size_t t = 0; t < num_input * fanout; ++t) out_src[t] = out_dst[t] = FGNN_EMPTY_KEY;
+  for (size_t i = 0; i < num_input; ++i) {
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    uint32_t *src = out_src + i * fanout, *dst = out_dst + i * fanout;
+    if (len <= fanout) {
+      for (uint32_t j = 0; j < len; ++j) { src[j] = rid; dst[j] = indices[off + j]; }
+      continue;
+    }
+    size_t selected = 0;
+    const uint32_t max_attempts = FGNN_HASH_DEDUP_MAX_ATTEMPTS(fanout);
+    for (uint32_t a = 0; a < max_attempts && selected < fanout; ++a) {
+      const uint32_t k = fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * a) % len;
+      const float r = philox_uniform_float(fgnn_philox_u32(rng->seed, batch_key, tag, (uint32_t)i, 2u * a + 1u));
+      uint32_t v = indices[off + k];
+      if (r > prob_table[off + k]) v = alias_table[off + k];
+      int seen = 0;
+      for (size_t q = 0; q < selected; ++q) seen |= dst[q] == v;
+      if (seen) continue;
+      src[selected] = rid;
+      dst[selected] = v;
+      ++selected;
+    }
+  }
+  *num_out = compact_padded(out_src, out_dst, num_input * fanout);
+}
+
 /* ------------------------------------------------------------------ random walk + top-K ---- */
 
 typedef struct { uint32_t dst, count; size_t first; } visit_cnt;
@@ -503,6 +546,10 @@ fgnn_oracle_task *fgnn_oracle_do_sample(const uint32_t *indptr, uint32_t *indice
         /* prob_prefix carries the prob table, cfg->alias_table the alias ids */
         fgnn_oracle_sample_weighted_khop(indptr, indices, prob_prefix, cfg->alias_table, cur_input, num_input, fanout,
                                          out_src, out_dst, &num_out, rng, batch_key, (uint32_t)i);
+        break;
+      case FGNN_WEIGHTED_KHOP_HASH_DEDUP:
+        fgnn_oracle_sample_weighted_khop_hash_dedup(indptr, indices, prob_prefix, cfg->alias_table, cur_input, num_input,
+                                                    fanout, out_src, out_dst, &num_out, rng, batch_key, (uint32_t)i);
         break;
       case FGNN_RANDOM_WALK:
         out_data = (uint32_t *)malloc(sizeof(uint32_t) * (cap ? cap : 1));

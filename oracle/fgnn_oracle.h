@@ -120,6 +120,17 @@ void fgnn_oracle_sample_weighted_khop(const uint32_t *indptr, const uint32_t *in
                                       size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *num_out,
                                       fgnn_rng *rng, uint64_t batch_key, uint32_t layer);
 
+/* cuda/cuda_sampling_weighted_khop_hash_dedup.cu:41-111: alias draws, per-seed rejection of already selected
+ * VALUES until `fanout` distinct ones are found, padded + count + compact (no sort).  See the .c file for the
+ * termination rule the reference lacks. */
+#define FGNN_HASH_DEDUP_MAX_FANOUT 50u               /* the reference's per-thread table has 50 slots */
+#define FGNN_HASH_DEDUP_MAX_ATTEMPTS(f) (64u * (uint32_t)(f))
+void fgnn_oracle_sample_weighted_khop_hash_dedup(const uint32_t *indptr, const uint32_t *indices,
+                                                 const float *prob_table, const uint32_t *alias_table,
+                                                 const uint32_t *input, size_t num_input, size_t fanout,
+                                                 uint32_t *out_src, uint32_t *out_dst, size_t *num_out, fgnn_rng *rng,
+                                                 uint64_t batch_key, uint32_t layer);
+
 /* cuda/cuda_sampling_random_walk.cu:43-109 + cuda/cuda_frequency_hashmap.cu:1143-1367:
  * num_walks restart-walks of walk_len steps per seed, visit-frequency top-K per seed.
  * Tie rule fixed to (count desc, first visit order asc) -- a legal outcome of the reference's race.

@@ -147,6 +147,14 @@ def sample_weighted_khop(indptr, indices, prob, alias, inp, fanout, rng, batch_k
                    extra=(prob.ctypes.data_as(C.POINTER(C.c_float)), alias.ctypes.data_as(C.POINTER(C.c_uint32))))
 
 
+def sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, rng, batch_key=0, layer=0):
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    prob = np.ascontiguousarray(prob, dtype=np.float32)
+    alias = np.ascontiguousarray(alias, dtype=np.uint32)
+    return _sample(lib().fgnn_oracle_sample_weighted_khop_hash_dedup, indptr, indices, inp, fanout, rng, batch_key,
+                   layer, extra=(prob.ctypes.data_as(C.POINTER(C.c_float)), alias.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+
 def sample_random_walk(indptr, indices, inp, walk_len, restart_prob, num_walks, K, rng, batch_key=0, layer=0):
     indptr, p_indptr = _u32(indptr)
     indices, p_idx = _u32(indices)

@@ -26,7 +26,7 @@ def dataset(workdir, sample_type):
     from fgnn_hip import synth
     return synth.write_dataset(workdir, "synth", NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN, 100, 100, seed=17,
                                with_prefix=(sample_type == "weighted_khop_prefix"),
-                               with_alias=(sample_type == "weighted_khop"))
+                               with_alias=(sample_type in ("weighted_khop", "weighted_khop_hash_dedup")))
 
 
 def base_config(path, arch, sample_type):
@@ -56,6 +56,7 @@ class OracleReplay:
         self.prefix = (np.fromfile(os.path.join(path, "prob_prefix_table.bin"), dtype=np.float32)
                        if sample_type == "weighted_khop_prefix" else None)
         self.st = dict(khop0=oracle.KHOP0, khop1=oracle.KHOP1, khop2=oracle.KHOP2, weighted_khop=oracle.WEIGHTED_KHOP,
+                       weighted_khop_hash_dedup=oracle.WEIGHTED_KHOP_HASH_DEDUP,
                        weighted_khop_prefix=oracle.WEIGHTED_KHOP_PREFIX, random_walk=oracle.RANDOM_WALK)[sample_type]
         self.kw = {}
         if sample_type == "random_walk":
@@ -64,7 +65,7 @@ class OracleReplay:
         elif sample_type == "weighted_khop_prefix":
             self.fan = [3, 4, 2]
             self.kw = dict(prob_prefix=self.prefix)
-        elif sample_type == "weighted_khop":
+        elif sample_type in ("weighted_khop", "weighted_khop_hash_dedup"):
             self.fan = [5, 3]
             self.kw = dict(prob_prefix=np.fromfile(os.path.join(path, "prob_table.bin"), dtype=np.float32),
                            alias_table=np.fromfile(os.path.join(path, "alias_table.bin"), dtype=np.uint32))

@@ -18,7 +18,7 @@ def _run(tmp_path, *args):
 
 
 @pytest.mark.parametrize("sample_type", ["khop2", "khop0", "weighted_khop_prefix", "random_walk", "khop1",
-                                         "weighted_khop"])
+                                         "weighted_khop", "weighted_khop_hash_dedup"])
 def test_arch1_single_gpu(tmp_path, sample_type):
     """BASELINE config 2 in miniature: one GPU samples and extracts (cuda_loops_arch1.cc:44-80)."""
     assert "ok" in _run(tmp_path, "arch1", sample_type)

@@ -372,10 +372,11 @@ def test_batch_driver_other_samplers(hip, oracle, mode):
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
 
 
-@pytest.mark.parametrize("kind", ["khop1", "weighted_khop"])
-@pytest.mark.parametrize("fanout", [1, 6, 15])
+@pytest.mark.parametrize("kind", ["khop1", "weighted_khop", "weighted_khop_hash_dedup"])
+@pytest.mark.parametrize("fanout", [1, 6, 15, 50])
 def test_with_replacement_samplers_match_oracle(hip, oracle, kind, fanout):
-    """khop1 (uniform with replacement) and weighted_khop (alias method): SURVEY 8(f) rank 4."""
+    """khop1 (uniform with replacement), weighted_khop (alias method) and weighted_khop_hash_dedup (alias draws,
+    repeated values rejected): SURVEY 8(f) rank 4."""
     from fgnn_hip import synth
     num_node = 4000
     indptr, indices = synth.powerlaw_csr(num_node, 70000, seed=37)
@@ -387,6 +388,9 @@ def test_with_replacement_samplers_match_oracle(hip, oracle, kind, fanout):
         d_inp = dev(inp) if n else torch.empty(0, dtype=torch.int32, device="cuda")
         if kind == "khop1":
             o_src, o_dst = oracle.sample_khop1(indptr, indices, inp, fanout, rng, 4 + call, 1)
+        elif kind == "weighted_khop_hash_dedup":
+            o_src, o_dst = oracle.sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, rng,
+                                                                  4 + call, 1)
         else:
             o_src, o_dst = oracle.sample_weighted_khop(indptr, indices, prob, alias, inp, fanout, rng, 4 + call, 1)
         src, dst, d_ne = hip.sample_with_replacement(kind, d_indptr, d_indices, d_inp, fanout, SEED, 4 + call, 1,
@@ -397,7 +401,29 @@ def test_with_replacement_samplers_match_oracle(hip, oracle, kind, fanout):
         np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
 
 
-@pytest.mark.parametrize("mode", ["khop1", "weighted_khop"])
+def test_hash_dedup_gives_up_on_rows_without_enough_distinct_values(hip, oracle):
+    """Rows longer than the fanout whose neighbours (and aliases) hold fewer distinct values than the fanout: the
+    reference never returns; the build stops after 64 * fanout attempts and emits what it found."""
+    num_node, fanout = 64, 6
+    deg = np.full(num_node, 12, dtype=np.uint32)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint32)
+    rows = np.arange(num_node, dtype=np.uint32)[:, None]
+    indices = ((rows + (np.arange(12, dtype=np.uint32)[None, :] % 2) + 1) % num_node).astype(np.uint32).ravel()  # 2 values
+    prob = np.full(indices.shape, 0.5, dtype=np.float32)
+    alias = indices.copy()
+    alias[::3] = (alias[::3] + 7) % num_node  # a third distinct value through the alias table for some rows
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    inp = np.arange(num_node, dtype=np.uint32)
+    o_src, o_dst = oracle.sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, rng, 3, 0)
+    src, dst, d_ne = hip.sample_with_replacement("weighted_khop_hash_dedup", dev(indptr), dev(indices), dev(inp), fanout,
+                                                 SEED, 3, 0, prob=dev(prob), alias=dev(alias))
+    ne = int(d_ne.cpu()[0])
+    assert ne == len(o_dst) and 2 * num_node <= ne < fanout * num_node
+    np.testing.assert_array_equal(host_u32(src, ne), o_src)
+    np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
+
+
+@pytest.mark.parametrize("mode", ["khop1", "weighted_khop", "weighted_khop_hash_dedup"])
 def test_batch_driver_with_replacement(hip, oracle, mode):
     from fgnn_hip import synth
     num_node = 20000
@@ -408,9 +434,11 @@ def test_batch_driver_with_replacement(hip, oracle, mode):
         sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.KHOP1, seed=SEED)
         okw, ost = {}, oracle.KHOP1
     else:
-        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.WEIGHTED_KHOP, seed=SEED,
+        hst, ost = ((hip.WEIGHTED_KHOP, oracle.WEIGHTED_KHOP) if mode == "weighted_khop" else
+                    (hip.WEIGHTED_KHOP_HASH_DEDUP, oracle.WEIGHTED_KHOP_HASH_DEDUP))
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hst, seed=SEED,
                               prob_table=dev(prob), alias_table=dev(alias))
-        okw, ost = dict(prob_prefix=prob, alias_table=alias), oracle.WEIGHTED_KHOP
+        okw = dict(prob_prefix=prob, alias_table=alias)
     bt = sampler.new_batch()
     oht = oracle.HashTable(num_node, sampler.max_nodes)
     rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
