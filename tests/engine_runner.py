@@ -241,10 +241,91 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
 
 
+def _switch_sampler_proc(barrier, sem, stop, err):
+    try:
+        import samgraph.torch as sam
+        sam.sample_init(0, "cuda:0")
+        barrier.wait()
+        for _ in range(NUM_EPOCH):
+            for _ in range(sam.num_local_step()):
+                sam.sample_once()
+                sem.release()  # one permit per published batch (balance_switcher/train_pinsage.py: mq_sem)
+        stop.set()
+        sam.shutdown()
+    except BaseException:
+        traceback.print_exc()
+        err.value = 1
+        os._exit(1)
+
+
+def _switch_consumer_proc(is_switcher, path, sample_type, barrier, sem, stop, seen_keys, err):
+    try:
+        import samgraph.torch as sam
+        barrier.wait()
+        if is_switcher:
+            # the sampler GPU turns into a trainer once its sampling is done (dist_engine.cc:425-431)
+            sam.switch_init(0, "cuda:0", 0.1)
+            stop.wait()
+        else:
+            sam.train_init(0, "cuda:0")
+        rep = OracleReplay(path, sample_type, 0, 1, True)
+        expected = {key: (seeds, task) for key, seeds, task in rep.epochs()}
+        n = 0
+        while sem.acquire(timeout=2.0 if (is_switcher or stop.is_set()) else 20.0):
+            sam.sample_once()
+            key = sam.get_next_batch()
+            seeds, task = expected[key]
+            check_batch(sam, key, seeds, task, rep, "%s key %d" % ("switcher" if is_switcher else "trainer", key))
+            with seen_keys.get_lock():
+                seen_keys[key] += 1
+            n += 1
+        sam.shutdown()
+        print("%s checked %d batches" % ("switcher" if is_switcher else "trainer", n))
+    except BaseException:
+        traceback.print_exc()
+        err.value = 1
+        os._exit(1)
+
+
+def run_arch5_switcher(sample_type, workdir):
+    """BASELINE config 5's control flow in miniature: 1 sampler + 1 trainer + the sampler's switcher, `have_switcher`
+    on (input nodes are shipped, every consumer splits hits / misses against its own cache, task_queue.cc:93-95)."""
+    path = dataset(workdir, sample_type)
+    import samgraph.torch as sam
+    cfg = base_config(path, sam.kArch5, sample_type)
+    cfg.update(num_sample_worker=1, num_train_worker=1, cache_percentage=0.2, have_switcher=1)
+    sam.config(cfg)
+    sam.data_init()
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(3)
+    sem, stop, err = ctx.Semaphore(0), ctx.Event(), ctx.Value("i", 0)
+    total = NUM_EPOCH * ((NUM_TRAIN + BATCH - 1) // BATCH)
+    seen = ctx.Array("i", total)
+    procs = [ctx.Process(target=_switch_sampler_proc, args=(barrier, sem, stop, err)),
+             ctx.Process(target=_switch_consumer_proc, args=(False, path, sample_type, barrier, sem, stop, seen, err)),
+             ctx.Process(target=_switch_consumer_proc, args=(True, path, sample_type, barrier, sem, stop, seen, err))]
+    for p in procs:
+        p.start()
+    bad = 0
+    for p in procs:
+        p.join(timeout=300)
+        if p.is_alive():
+            p.terminate()
+            bad = 1
+        elif p.exitcode != 0:
+            bad = 1
+    if bad or err.value or list(seen) != [1] * total:
+        print("seen", list(seen))
+        sys.exit(1)
+    print("arch5 switcher %s ok: %d batches, each consumed once" % (sample_type, total))
+
+
 if __name__ == "__main__":
     mode, st, wd = sys.argv[1:4]
     if mode == "arch1":
         run_arch1(st, wd)
+    elif mode == "switcher":
+        run_arch5_switcher(st, wd)
     else:
         run_arch5(st, wd, int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]),
                   pipeline=(len(sys.argv) < 8 or sys.argv[7] == "pipeline"))

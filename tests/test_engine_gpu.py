@@ -38,6 +38,13 @@ def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)
 
 
+@pytest.mark.parametrize("sample_type", ["random_walk", "khop2"])
+def test_arch5_switcher(tmp_path, sample_type):
+    """BASELINE config 5's switcher flow: with `have_switcher` the sampler ships input nodes, the trainer and the
+    sampler's co-located switcher (samgraph_switch_init, own smaller cache) both drain the queue."""
+    assert "ok" in _run(tmp_path, "switcher", sample_type)
+
+
 def test_training_example_runs(tmp_path):
     """examples/train_graphsage.py = the reference's single-GPU script shape (config -> init -> sample_once ->
     get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's test_result lines."""
