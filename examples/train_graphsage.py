@@ -23,39 +23,11 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
 import samgraph.torch as sam  # noqa: E402
 
 
-class SAGEConvMean(nn.Module):
-    """h_dst' = W_self h_dst + W_neigh mean_{(u->v)} h_u   (dgl.nn.SAGEConv(..., 'mean'))"""
-
-    def __init__(self, in_feats, out_feats):
-        super().__init__()
-        self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
-        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=True)
-
-    def forward(self, block, h):
-        num_dst = block.number_of_dst_nodes()
-        row, col = block.row.long(), block.col.long()
-        agg = th.zeros((num_dst, h.shape[1]), dtype=h.dtype, device=h.device).index_add_(0, col, h[row])
-        deg = th.zeros(num_dst, dtype=h.dtype, device=h.device).index_add_(0, col, th.ones_like(col, dtype=h.dtype))
-        return self.fc_self(h[:num_dst]) + self.fc_neigh(agg / deg.clamp(min=1).unsqueeze(1))
-
-
-class SAGE(nn.Module):
-    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout):
-        super().__init__()
-        dims = [in_feats] + [n_hidden] * (n_layers - 1) + [n_classes]
-        self.layers = nn.ModuleList(SAGEConvMean(dims[i], dims[i + 1]) for i in range(n_layers))
-        self.dropout = nn.Dropout(dropout)
-
-    def forward(self, blocks, x):
-        h = x
-        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
-            h = layer(block, h)
-            if l != len(self.layers) - 1:
-                h = self.dropout(F.relu(h))
-        return h
+from models import SAGE  # noqa: E402  (examples/models.py: torch-op SAGEConv on the engine's COO blocks)
 
 
 def main():

@@ -54,3 +54,20 @@ def test_training_example_runs(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch=" in p.stdout
+
+
+@pytest.mark.parametrize("model,extra", [
+    ("graphsage", ["--cache-percentage", "0.2", "--fanout", "10", "5"]),
+    ("gcn", ["--sample-type", "weighted_khop_prefix", "--fanout", "3", "4", "5", "--cache-percentage", "0.1"]),
+    ("pinsage", ["--num-random-walk", "6", "--num-sample-worker", "2"]),
+])
+def test_fgnn_training_example_runs(tmp_path, model, extra):
+    """examples/multi_gpu/train_fgnn.py = the reference's multi_gpu scripts' shape (parent config + data_init, forked
+    sampler and trainer processes, pinned queue in between), all workers on cuda:0."""
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "multi_gpu",
+                      "train_fgnn.py")
+    p = subprocess.run([sys.executable, ex, "--model", model, "--make-dataset", "small", "--dataset-path",
+                        str(tmp_path / "small"), "--num-epoch", "2", "--batch-size", "2000", "--single-gpu"] + extra,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "test_result:pipeline_train_epoch_time=" in p.stdout and "test_result:sample_time=" in p.stdout
