@@ -10,13 +10,15 @@
 // MI355X design: ONE launch.  A workgroup owns 256 consecutive seeds, one lane per seed; the selected values of a
 // seed live in LDS (column `lane` of sel[fanout][256], conflict-free), where the rejection test scans them and
 // from where they are emitted -- no padded temporaries, no count / scan / compact kernels: the output offset of a
-// workgroup comes from the cross-workgroup prefix of fgnn_device.h.  Workgroups walk the tiles in increasing
-// order (tile += gridDim), so a grid smaller than the tile count is fine.
+// workgroup comes from the cross-workgroup prefix of fgnn_device.h (a workgroup waits only for lower-numbered ones,
+// which were dispatched before it: safe next to other streams' kernels).  Frontiers of more than kMaxScanTiles
+// workgroups take two launches of the same kernel instead (count, one-workgroup scan, emit).
 #include "fgnn_device.h"
 
 namespace fgnn {
 namespace {
 
+constexpr uint32_t kMaxScanTiles = 2048;  // all-predecessor prefix: O(tiles^2) descriptor loads
 constexpr uint32_t kMaxFanout = 50;  // the reference's per-thread table has 50 slots (hash_dedup.cu:43,72)
 __host__ __device__ constexpr uint32_t max_attempts(uint32_t fanout) { return 64u * fanout; }
 
@@ -33,14 +35,22 @@ __global__ __launch_bounds__(kBlock) void hash_dedup_kernel(const uint32_t *__re
                                                             uint32_t *__restrict__ out_src,
                                                             uint32_t *__restrict__ out_dst, int src_mode,
                                                             uint64_t seed, uint64_t batch_key, uint32_t tag,
-                                                            ScanWs scan, size_t *d_num_out) {
+                                                            ScanWs scan, size_t *d_num_out, int mode,
+                                                            uint32_t *__restrict__ block_sums) {
+  // mode 0: single pass (offsets by look-back); 1: count only (block_sums[tile] = edges of the tile);
+  // 2: emit with the scanned block_sums as offsets
   extern __shared__ uint32_t sel[];  // [F][kBlock]
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile;
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);
   const uint32_t ntiles = n ? (n - 1) / kBlock + 1 : 1u;
   const int tid = threadIdx.x;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const uint32_t tile = blockIdx.x;
+  if (tile >= ntiles) {
+    if (mode == 1 && tid == 0) block_sums[tile] = 0;
+    return;
+  }
+  {
     const uint32_t i = tile * kBlock + tid;
     uint32_t rid = 0, c = 0;
     if (i < n) {
@@ -70,14 +80,17 @@ __global__ __launch_bounds__(kBlock) void hash_dedup_kernel(const uint32_t *__re
     }
     uint32_t total;
     const uint32_t lo = block_exclusive_scan<kWavesPerBlock>(c, sh, &total);
-    const size_t base = scan_lookback(scan, tile, total, &sh_tile);
-    if (tile == ntiles - 1 && tid == 0 && d_num_out) *d_num_out = base + total;
+    if (mode == 1) {
+      if (tid == 0) block_sums[tile] = total;
+      return;
+    }
+    const size_t base = mode == 0 ? (size_t)scan_lookback(scan, tile, total, &sh_tile) : (size_t)block_sums[tile];
+    if (mode == 0 && tile == ntiles - 1 && tid == 0 && d_num_out) *d_num_out = base + total;
     const uint32_t src = src_mode == FGNN_SRC_LOCAL ? i : rid;
     for (uint32_t j = 0; j < c; ++j) {
       out_src[base + lo + j] = src;
       out_dst[base + lo + j] = sel[j * kBlock + tid];
     }
-    __syncthreads();  // sel is reused by the next tile
   }
 }
 
@@ -100,16 +113,14 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
   const uint32_t tag = ((uint32_t)FGNN_WEIGHTED_KHOP_HASH_DEDUP << 8) | (layer & 0xffu);
   const size_t lds = (size_t)F * kBlock * sizeof(uint32_t);
   const size_t nb = div_up(cap, (size_t)kBlock);
-  static int per_cu = -1;
-  static size_t occ_lds = 0;
-  if (per_cu < 0 || occ_lds != lds) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hash_dedup_kernel, kBlock, lds) != hipSuccess) per_cu = 1;
-    occ_lds = lds;
-  }
-  size_t grid = (size_t)(per_cu > 0 ? per_cu : 1) * device_cu_count() * 3 / 4;
-  if (grid > nb) grid = nb;
   ScanWs scan{nullptr, nullptr, nullptr, 0, 0, nullptr};
-  if (scan_host && nb <= scan_host->ws.max_tiles) {
+  uint32_t *sums = nullptr;
+  int mode = 0;
+  if (nb > kMaxScanTiles) {
+    if (ws_bytes < (nb + 2) * sizeof(uint32_t)) return FGNN_ENOSPC;
+    sums = static_cast<uint32_t *>(ws);
+    mode = 1;
+  } else if (scan_host && nb <= scan_host->ws.max_tiles) {
     scan = scan_host->next(true, 0);
   } else {
     // stateless entry point: descriptors in the caller's scratch, zeroed, generation 1
@@ -119,16 +130,25 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
     scan.gen = 1;
     scan.max_tiles = (uint32_t)nb;
   }
-  hipLaunchKernelGGL(hash_dedup_kernel, dim3(grid), dim3(kBlock), lds, st, indptr, indices, prob_table, alias_table,
-                     input, num_input, d_num_input, cap, F, out_src, out_dst, src_mode, seed, batch_key, tag, scan,
-                     d_num_out);
+#define FGNN_HD(MODE)                                                                                              \
+  hipLaunchKernelGGL(hash_dedup_kernel, dim3(nb), dim3(kBlock), lds, st, indptr, indices, prob_table, alias_table, \
+                     input, num_input, d_num_input, cap, F, out_src, out_dst, src_mode, seed, batch_key, tag, scan, \
+                     d_num_out, MODE, sums)
+  if (mode == 0) {
+    FGNN_HD(0);
+  } else {
+    FGNN_HD(1);
+    if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
+    FGNN_HD(2);
+  }
+#undef FGNN_HD
   return launch_status(__func__);
 }
 
 }  // namespace fgnn
 
 extern "C" size_t fgnn_hash_dedup_scratch_bytes(size_t num_input_cap) {
-  return (fgnn::div_up(num_input_cap, (size_t)fgnn::kBlock) + 1) * sizeof(unsigned long long);
+  return (fgnn::div_up(num_input_cap, (size_t)fgnn::kBlock) + 2) * sizeof(unsigned long long);
 }
 
 extern "C" int fgnn_sample_weighted_khop_hash_dedup(const uint32_t *indptr, const uint32_t *indices,

@@ -498,3 +498,23 @@ def test_batch_driver_large_frontier(hip, oracle):
             np.testing.assert_array_equal(host_u32(got), w)
         assert bt.feat().cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
+def test_hash_dedup_large_frontier_two_pass(hip, oracle):
+    """More than 2048 workgroups of seeds: the sampler takes the count / scan / emit route instead of the look-back."""
+    from fgnn_hip import synth
+    num_node, fanout = 700_000, 3
+    indptr, indices = synth.powerlaw_csr(num_node, 6_000_000, seed=44)
+    rng_np = np.random.default_rng(8)
+    prob = rng_np.random(len(indices), dtype=np.float32)
+    alias = np.roll(indices, 1).astype(np.uint32)  # any node id will do for parity
+    inp = rng_np.permutation(num_node)[:600_000].astype(np.uint32)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_src, o_dst = oracle.sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, rng, 7, 2)
+    src, dst, d_ne = hip.sample_with_replacement("weighted_khop_hash_dedup", dev(indptr), dev(indices), dev(inp), fanout,
+                                                 SEED, 7, 2, prob=dev(prob), alias=dev(alias))
+    ne = int(d_ne.cpu()[0])
+    assert ne == len(o_dst) > 1_000_000
+    np.testing.assert_array_equal(host_u32(src, ne), o_src)
+    np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
