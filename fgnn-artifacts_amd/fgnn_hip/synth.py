@@ -72,7 +72,7 @@ def alias_tables(indptr, indices, seed=9):
     num_node = len(indptr) - 1
     out_deg = np.bincount(indices, minlength=num_node)
     prob = np.ones(len(indices), dtype=np.float32)
-    alias = indices.copy()
+    alias = np.zeros(len(indices), dtype=np.uint32)  # columns with prob 1 keep alias 0 (create_alias_table.cc:211)
     ip = indptr.astype(np.int64)
     for r in range(num_node):
         a, b = ip[r], ip[r + 1]
@@ -93,6 +93,14 @@ def alias_tables(indptr, indices, seed=9):
         for si in small:
             prob[a + si] = 1.0
     return prob, alias.astype(np.uint32)
+
+
+def cache_by_degree(indices, num_node):
+    """Node ranking by descending (out-degree, id) -- utility/data-process/toolkit/cache/cache_by_degree.cc:29-48
+    (a node's out-degree = the number of rows it appears in, graph_loader.cc:126-137)."""
+    out = np.bincount(indices, minlength=num_node).astype(np.int64)
+    ids = np.arange(num_node, dtype=np.int64)
+    return np.lexsort((-ids, -out)).astype(np.uint32)
 
 
 def node_features(num_node, dim, seed=3, dtype=np.float32):
@@ -124,8 +132,7 @@ def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train
         prob.tofile(os.path.join(d, "prob_table.bin"))
         alias.tofile(os.path.join(d, "alias_table.bin"))
     # file-backed cache rankings (engine.cc:216-256): by in-degree (cache_by_degree.bin) and random
-    deg = indptr[1:].astype(np.int64) - indptr[:-1].astype(np.int64)
-    np.argsort(-deg, kind="stable").astype(np.uint32).tofile(os.path.join(d, "cache_by_degree.bin"))
+    cache_by_degree(indices, num_node).tofile(os.path.join(d, "cache_by_degree.bin"))
     rng.permutation(num_node).astype(np.uint32).tofile(os.path.join(d, "cache_by_random.bin"))
     with open(os.path.join(d, "meta.txt"), "w") as f:
         f.write(f"NUM_NODE {num_node}\nNUM_EDGE {num_edge}\nFEAT_DIM {feat_dim}\nNUM_CLASS {num_class}\n"
