@@ -336,7 +336,15 @@ struct ScanWsHost {
   // kind: which kernel family the launch belongs to (0 sampler, 1 dedup count+assign, 2 cache split) -- selects
   // the section of the diagnostic phase log
   ScanWs next(bool all_resident, uint32_t kind = 0) {
-    ws.gen = ws.gen >= 0x3FFFFFFEu ? 1u : ws.gen + 1u;
+    if (ws.gen >= 0x3FFFFFFEu) {
+      // generations are about to repeat (once per 2^30 launches): descriptors stamped during the previous cycle
+      // must not read as fresh, so start the new cycle from zeroed descriptors, fenced against everything in flight
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(ws.desc, 0, (size_t)ws.max_tiles * sizeof(unsigned long long));
+      (void)hipDeviceSynchronize();
+      ws.gen = 0;
+    }
+    ws.gen += 1u;
     ScanWs v = ws;
     if (all_resident) v.ticket = nullptr;
     unsigned long long *log = phase_log_base();
