@@ -8,6 +8,10 @@ static thread_local char g_last_error[512] = "";
 void set_last_error(const char *what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
 }
+uint32_t *&scan_error_sink() {
+  static thread_local uint32_t *sink = nullptr;
+  return sink;
+}
 static unsigned long long *g_phase_log = nullptr;
 unsigned long long *phase_log_base() { return g_phase_log; }
 }  // namespace fgnn

@@ -295,6 +295,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (seq < s->returned) return FGNN_EINVAL;
   }
   SeqGuard guard{s, seq};
+  fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
   fgnn_hashtable *ht = sl.ht;
   uint32_t *tmp_dst = sl.tmp_dst;
@@ -403,6 +404,7 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
 
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
   if (!b || !cache_table) return FGNN_EINVAL;
+  fgnn::ScanErrorSink sink(&b->d_meta->overflow);
   // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
   return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
                                        b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,

@@ -231,6 +231,14 @@ __device__ __forceinline__ void phase_mark(const ScanWs &w, uint32_t tile, int p
   if (w.log && threadIdx.x == 0 && tile < kPhaseLogTiles) w.log[(size_t)tile * 8 + phase] = wall_clock64();
 }
 unsigned long long *phase_log_base();  // capi.hip
+// Where a timed-out cross-workgroup wait is reported for launches made by this host thread: the batch driver points
+// it at the batch summary's `overflow` word (so the host sees it with the batch), otherwise the descriptors' own word.
+uint32_t *&scan_error_sink();           // capi.hip (thread-local)
+struct ScanErrorSink {
+  uint32_t *prev;
+  explicit ScanErrorSink(uint32_t *p) : prev(scan_error_sink()) { scan_error_sink() = p; }
+  ~ScanErrorSink() { scan_error_sink() = prev; }
+};
 
 constexpr uint32_t kScanAggregate = 1u, kScanInclusive = 2u;
 
@@ -347,6 +355,7 @@ struct ScanWsHost {
     ws.gen += 1u;
     ScanWs v = ws;
     if (all_resident) v.ticket = nullptr;
+    if (uint32_t *sink = scan_error_sink()) v.error = sink;
     unsigned long long *log = phase_log_base();
     v.log = log ? log + (size_t)(kind % kPhaseLogKinds) * kPhaseLogTiles * 8 : nullptr;
     return v;

@@ -446,6 +446,9 @@ class Batch:
         m = BatchMeta()
         _check(load().fgnn_batch_wait(self.h, C.byref(m)), "fgnn_batch_wait")
         self.meta = m
+        if m.overflow:
+            raise FgnnError(f"batch {m.key} is invalid (overflow flag {m.overflow}): a capacity was exceeded or a "
+                            "cross-workgroup wait timed out")
         return m
 
     # views of the device buffers, sized by the (waited-for) summary

@@ -218,7 +218,8 @@ typedef struct fgnn_batch_meta_s {
   uint32_t num_input;                 /* |input_nodes| */
   uint32_t num_output;                /* |output_nodes| = batch size */
   uint32_t num_miss, num_cache;
-  uint32_t overflow;                  /* non-zero if a capacity was exceeded (results truncated) */
+  uint32_t overflow;                  /* non-zero: the batch is invalid (a capacity was exceeded, or a cross-workgroup
+                                         wait inside a single-pass kernel timed out) -- callers must not use it */
 } fgnn_batch_meta;
 
 fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);
