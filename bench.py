@@ -163,11 +163,12 @@ def algorithmic_bytes(metas, feat_dim, batch_size):
     return dict(sample=sample, dedup_remap=dedup, cache_split=split, gather=gather)
 
 
-def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
-    """The reference's CPU sampling path (CPUSampleKHop2 + CPUHashTable2 + CPUExtract driven as DoCPUSample /
-    DoFeatureExtract, cpu/cpu_loops.cc:55-227) restated in oracle/ and timed on this host on a bounded number of
-    batches of the same workload: once multi-threaded like the reference runs it (OpenMP, static schedules,
-    per-thread mt19937) and once with the single-thread variant that is pinned bit-exactly to the reference."""
+def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="khop2"):
+    """The reference's CPU sampling path (CPUSampleKHop0/2 + CPUHashTable2 + CPUExtract driven as DoCPUSample /
+    DoFeatureExtract, cpu/cpu_loops.cc:55-227) timed on this host on a bounded number of batches of the same
+    workload, multi-threaded (OpenMP, a few thread counts) and single-threaded.  kind "reference": the reference's own
+    sources as compiled into oracle/_ref by `make -C oracle _ref` (built files travel with the repo snapshot);
+    kind "port": the oracle's restatement of the same functions when oracle/_ref is not there."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as oracle
     oracle.build()
@@ -189,11 +190,18 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
         cands = [int(os.environ["FGNN_CPU_BASELINE_THREADS"])]
     else:
         cands = sorted({t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)} or {1})
+    use_ref = oracle.RefBaseline.available()
     res = {}
     runs = [("omp%d" % t, t) for t in cands] + [("single", 1)]
     budget_s = budget_s / len(runs)
+    max_edges = max(bs * int(np.prod([f + 1 for f in fan[i + 1:]])) * fan[i] for i in range(len(fan)))
+    ref = oracle.RefBaseline(num_node, max_edges, cap, 1) if use_ref else None
     for label, T in runs:
-        ctx = oracle.OmpBaseline(num_node, cap, T)
+        if use_ref:
+            ref.set_threads(T)
+            ctx = None
+        else:
+            ctx = oracle.OmpBaseline(num_node, cap, T)
         edges = rows = nb = 0
         t_total = 0.0
         warm = 2  # untimed: OpenMP thread-pool start-up and first touch of the tables
@@ -201,7 +209,11 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
         while t_total < budget_s and (k + 1) * bs <= len(h_train):
             seeds = np.ascontiguousarray(h_train[k * bs:(k + 1) * bs])
             t1 = time.time()
-            e, n_in = ctx.sample_batch(h_indptr, h_indices, seeds, fan, h_feat, mask, out)
+            if use_ref:
+                e, n_in = ref.sample_batch(h_indptr, h_indices, seeds, fan,
+                                           oracle.KHOP2 if sample_type == "khop2" else oracle.KHOP0, h_feat, mock_bits, out)
+            else:
+                e, n_in = ctx.sample_batch(h_indptr, h_indices, seeds, fan, h_feat, mask, out)
             dt = time.time() - t1
             k += 1
             if k <= warm:
@@ -211,14 +223,19 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0):
             rows += n_in
             nb += 1
         res[label] = dict(threads=T, batches=nb, seconds=t_total, edges_per_s=edges / t_total, rows_per_s=rows / t_total)
+    if ref is not None:
+        ref.close()
     best = max(res.values(), key=lambda r: r["edges_per_s"])
+    what = ("the reference's own CPU sources (cpu_sampling_khop2.cc, cpu_hashtable2.cc, cpu_extraction.cc, cpu_random.cc "
+            "compiled unmodified into oracle/_ref, driven as DoCPUSample / DoFeatureExtract, cpu_loops.cc:55-227)"
+            if use_ref else "oracle restatement of CPUSampleKHop2 + CPUHashTable2 + CPUExtract (oracle/_ref not present)")
     return {
-        "value": best["edges_per_s"], "unit": "sampled-edges/s", "cores": best["threads"], "kind": "port",
+        "value": best["edges_per_s"], "unit": "sampled-edges/s", "cores": best["threads"],
+        "kind": "reference" if use_ref else "port",
         "sample": f"{best['batches']} batches of {bs} seeds, fanout {fan}, same graph, whole path (sample + dedup + remap "
                   f"+ feature gather) in {best['seconds']:.1f}s with {best['threads']} OpenMP threads; single thread: "
-                  f"{res['single']['edges_per_s']:.3e} edges/s; feature table masked to 2^{mock_bits} rows like "
-                  f"SAMGRAPH_EMPTY_FEAT; host copy of CSR/features {copy_s:.1f}s not counted; oracle restatement of "
-                  f"CPUSampleKHop2 + CPUHashTable2 + CPUExtract",
+                  f"{res['single']['edges_per_s']:.3e} edges/s; feature table masked to 2^{mock_bits} rows "
+                  f"(SAMGRAPH_EMPTY_FEAT / CPUMockExtract); host copy of CSR/features {copy_s:.1f}s not counted; {what}",
         "rows_per_s": best["rows_per_s"], "single_thread_edges_per_s": res["single"]["edges_per_s"],
         "all_runs": res,
         "host_cpus": os.cpu_count(),
@@ -494,7 +511,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             if args.sample_type in ("khop2", "khop0"):
-                out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train)
+                out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train, sample_type=args.sample_type)
             else:
                 out["cpu_baseline"] = cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train)
         print(json.dumps(out))

@@ -340,3 +340,68 @@ class OmpBaseline:
                                             C.c_size_t(len(fanout)), fp, C.c_size_t(dim), C.c_uint32(feat_row_mask),
                                             fo_p, C.byref(n_in))
         return edges, n_in.value
+
+
+class RefBaseline:
+    """The REFERENCE's own CPU sampling path (oracle/_ref/libref_driver.so, compiled from /root/reference's unmodified
+    cpu/*.cc; ref_driver.cc:ref_bench_*), timing only.  Present only where `make -C oracle _ref` has run (the build
+    container; the built files travel to the GPU box with the snapshot)."""
+    _DIR = os.path.join(_HERE, "_ref")
+
+    @classmethod
+    def available(cls):
+        return all(os.path.exists(os.path.join(cls._DIR, f)) for f in ("libref_driver.so", "libref_loader.so"))
+
+    def __init__(self, num_node, max_edges_per_layer, max_unique, threads):
+        loader = C.CDLL(os.path.join(self._DIR, "libref_loader.so"))
+        loader.ref_loader_open.restype = C.c_void_p
+        loader.ref_loader_sym.restype = C.c_void_p
+        loader.ref_loader_sym.argtypes = [C.c_void_p, C.c_char_p]
+        drv = loader.ref_loader_open(os.path.join(self._DIR, "libref_driver.so").encode())
+        if not drv:
+            raise OSError("cannot open libref_driver.so")
+
+        def fn(name, restype, *argtypes):
+            addr = loader.ref_loader_sym(C.c_void_p(drv), name.encode())
+            if not addr:
+                raise OSError(name + " not found in libref_driver.so")
+            return C.CFUNCTYPE(restype, *argtypes)(addr)
+
+        self._keep = loader
+        self._create = fn("ref_bench_create", C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int)
+        self._destroy = fn("ref_bench_destroy", None, C.c_void_p)
+        self._set_threads = fn("ref_bench_set_threads", None, C.c_int)
+        P = C.POINTER(C.c_uint32)
+        self._batch = fn("ref_bench_batch", C.c_int, C.c_void_p, P, P, P, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t,
+                         C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t),
+                         C.POINTER(C.c_size_t))
+        self.h = self._create(num_node, max_edges_per_layer, max_unique, threads)
+        if not self.h:
+            raise MemoryError("ref_bench_create failed")
+        self.threads = threads
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_threads(self, threads):
+        self._set_threads(threads)
+        self.threads = threads
+
+    def sample_batch(self, indptr, indices, seeds, fanout, sample_type=KHOP2, feat=None, empty_feat_bits=0,
+                     feat_out=None):
+        """indices (uint32, contiguous) is mutated for KHOP2.  Returns (edges, input_nodes)."""
+        fo = (C.c_size_t * len(fanout))(*fanout)
+        P = C.POINTER(C.c_uint32)
+        e, n = C.c_size_t(0), C.c_size_t(0)
+        fp = feat.ctypes.data_as(C.c_void_p) if feat is not None else None
+        fo_p = feat_out.ctypes.data_as(C.c_void_p) if feat_out is not None else None
+        rc = self._batch(self.h, indptr.ctypes.data_as(P), indices.ctypes.data_as(P), seeds.ctypes.data_as(P), len(seeds),
+                         fo, len(fanout), sample_type, fp, feat.shape[1] if feat is not None else 0, empty_feat_bits,
+                         fo_p, C.byref(e), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("ref_bench_batch: buffers too small")
+        return e.value, n.value

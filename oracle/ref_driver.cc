@@ -143,3 +143,85 @@ extern "C" int ref_driver_main(const char *jobfile) {
   }
   return 0;
 }
+
+
+/* ---- timing entry points (bench.py's cpu_baseline, kind "reference") ---------------------------------------------
+ * The reference's CPU sampling path exactly as DoCPUSample / DoFeatureExtract drive it (cpu/cpu_loops.cc:55-227):
+ * Reset + Populate(seeds), then per layer (last fanout first) CPUSampleKHop0/2 -> Populate -> MapNodes -> MapEdges,
+ * then CPU[Mock]Extract of the input nodes' feature rows -- the reference's own functions, its OpenMP pragmas with
+ * RunConfig::omp_thread_num threads, its per-thread mt19937.  The table is built like CPUHashTable2's constructor
+ * does (direct-indexed, one bucket per graph node) but in malloc'd storage (see the header comment). */
+struct RefBench {
+  CPUHashTable2 *ht;
+  std::vector<IdType> src, dst, new_src, new_dst, unique, cur;
+};
+
+extern "C" void *ref_bench_create(size_t num_node, size_t max_edges_per_layer, size_t max_unique, int threads) {
+  RunConfig::omp_thread_num = threads;
+  auto *b = new RefBench();
+  b->ht = static_cast<CPUHashTable2 *>(malloc(sizeof(CPUHashTable2)));
+  memset(static_cast<void *>(b->ht), 0, sizeof(CPUHashTable2));
+  b->ht->_o2n_table = static_cast<CPUHashTable2::BucketO2N *>(malloc(num_node * sizeof(CPUHashTable2::BucketO2N)));
+  b->ht->_n2o_table = static_cast<CPUHashTable2::BucketN2O *>(malloc(num_node * sizeof(CPUHashTable2::BucketN2O)));
+  if (!b->ht->_o2n_table || !b->ht->_n2o_table) return nullptr;
+  b->ht->_capacity = num_node;
+  b->ht->CPUHashTable2::InitTable();
+  b->src.resize(max_edges_per_layer + 1);
+  b->dst.resize(max_edges_per_layer + 1);
+  b->new_src.resize(max_edges_per_layer + 1);
+  b->new_dst.resize(max_edges_per_layer + 1);
+  b->unique.resize(max_unique + 1);
+  b->cur.resize(max_unique + 1);
+  return b;
+}
+
+extern "C" void ref_bench_set_threads(int threads) { RunConfig::omp_thread_num = threads; }
+
+extern "C" void ref_bench_destroy(void *h) {
+  auto *b = static_cast<RefBench *>(h);
+  if (!b) return;
+  free(b->ht->_o2n_table);
+  free(b->ht->_n2o_table);
+  free(b->ht);
+  delete b;
+}
+
+/* one mini-batch; sample_type 0 = khop0, 5 = khop2 (mutates indices); returns 0, edge / input-node counts by pointer */
+extern "C" int ref_bench_batch(void *h, const IdType *indptr, IdType *indices, const IdType *seeds, size_t num_seeds,
+                               const size_t *fanout, size_t num_layers, int sample_type, const void *feat,
+                               size_t feat_dim, size_t empty_feat_bits, void *feat_out, size_t *out_edges,
+                               size_t *out_inputs) {
+  auto *b = static_cast<RefBench *>(h);
+  CPUHashTable2 *ht = b->ht;
+  ht->CPUHashTable2::Reset();
+  ht->CPUHashTable2::Populate(seeds, num_seeds);
+  memcpy(b->cur.data(), seeds, num_seeds * sizeof(IdType));
+  size_t num_input = num_seeds, edges = 0;
+  for (long l = (long)num_layers - 1; l >= 0; --l) {
+    size_t num_out = 0;
+    if (num_input * fanout[l] >= b->src.size()) return 1;
+    if (sample_type == 0)
+      cpu::CPUSampleKHop0(indptr, indices, b->cur.data(), num_input, b->src.data(), b->dst.data(), &num_out, fanout[l]);
+    else
+      cpu::CPUSampleKHop2(indptr, indices, b->cur.data(), num_input, b->src.data(), b->dst.data(), &num_out, fanout[l]);
+    ht->CPUHashTable2::Populate(b->dst.data(), num_out);
+    const size_t num_unique = ht->CPUHashTable2::NumItems();
+    if (num_unique >= b->unique.size()) return 1;
+    ht->CPUHashTable2::MapNodes(b->unique.data(), num_unique);
+    ht->CPUHashTable2::MapEdges(b->src.data(), b->dst.data(), num_out, b->new_src.data(), b->new_dst.data());
+    b->cur.swap(b->unique);
+    num_input = num_unique;
+    edges += num_out;
+  }
+  if (feat && feat_out) {
+    if (empty_feat_bits) {
+      RunConfig::option_empty_feat = empty_feat_bits;
+      cpu::CPUMockExtract(feat_out, feat, b->cur.data(), num_input, feat_dim, kF32);
+    } else {
+      cpu::CPUExtract(feat_out, feat, b->cur.data(), num_input, feat_dim, kF32);
+    }
+  }
+  *out_edges = edges;
+  *out_inputs = num_input;
+  return 0;
+}

@@ -200,3 +200,37 @@ def test_hash_dedup_sampler_invariants(oracle):
     # same seed and key: same draws
     src2, dst2 = oracle.sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, rng, 1, 0)
     np.testing.assert_array_equal(dst, dst2)
+
+
+def test_reference_cpu_build_agrees_with_oracle_twin(oracle):
+    """bench.py times oracle/_ref (the reference's own CPU sources) as its CPU baseline; the same entry point run with
+    one thread must reproduce the oracle's CPU-twin mode (default-seeded mt19937) edge for edge."""
+    if not oracle.RefBaseline.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_py as o
+from fgnn_hip import synth
+N, fan, bs = 50000, [7, 4], 900
+indptr, indices = synth.powerlaw_csr(N, 900000, seed=5)
+cap = o.predict_num_nodes(bs, fan)
+seeds = np.random.default_rng(1).choice(N, bs, replace=False).astype(np.uint32)
+feat = synth.node_features(1 << 12, 8)
+out = np.zeros((cap, 8), dtype=np.float32)
+rb = o.RefBaseline(N, bs * 5 * 7 + bs * 4, cap, 1)
+ind = indices.copy()
+e, n = rb.sample_batch(indptr, ind, seeds, fan, o.KHOP2, feat, 12, out)
+oind = indices.copy()
+w = o.do_sample(indptr, oind, seeds, fan, o.KHOP2, o.make_rng(o.RNG_MT_CPU_TWIN, 0), 0, o.HashTable(N, cap))
+assert (e, n) == (w["total_edges"], len(w["input_nodes"])), (e, n, w["total_edges"])
+assert (ind == oind).all()
+assert (out[:n] == feat[w["input_nodes"] & 4095]).all()
+print("same")
+''' % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fgnn-artifacts_amd"))
+    # own process: the reference keeps its mt19937 thread_local per process, it must start fresh
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.returncode == 0 and "same" in p.stdout, p.stderr[-2000:]
