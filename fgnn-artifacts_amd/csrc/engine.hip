@@ -141,7 +141,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   }
   for (auto &sl : s->slot) {
     int err = FGNN_OK;
-    sl.ht = fgnn_hashtable_create(s->max_nodes, &err);
+    sl.ht = fgnn_hashtable_create_ex(s->max_nodes, s->max_edge_cap, &err);  // fills are at most a layer's edges
     bool ok = sl.ht != nullptr;
     ok = ok && hipMalloc(&sl.tmp_dst, s->max_edge_cap * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
@@ -372,8 +372,8 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   }
   if (mutates && num_seeds == 0) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
   // wipe the table for the slot's next batch (Reset, cuda_hashtable.cu:714-723), then mark the slot reusable
-  static const bool skip_wipe = getenv("FGNN_ABLATE_WIPE") != nullptr;  // profiling only: results are wrong when set
-  if (!skip_wipe) rc = fgnn_hashtable_reset(ht, stream);
+  // Reset (cuda_hashtable.cu:714-723) for the slot's next batch: a generation bump, no memory traffic
+  rc = fgnn::hashtable_next_generation(ht, stream, false);
   if (rc != FGNN_OK) return rc;
   FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
   sl.was_used = true;

@@ -18,6 +18,12 @@ struct fgnn_hashtable {
   size_t max_items;
   uint32_t shift;             // 32 - log2(capacity)
   fgnn::ScanWsHost *scan;     // look-back descriptors of the single-pass count+assign kernel
+  // bucket value = [generation : 32 - vp1 bits][pending : 1][index : vp1 - 1 bits].  A bucket whose generation is not
+  // the current one is EMPTY: Reset() is a generation bump, the table is only really wiped when the counter wraps.
+  uint32_t vp1;               // bits of pending flag + index (<= 31)
+  uint32_t gen;               // current generation, 0 .. gen_limit - 1
+  uint32_t gen_limit;         // (1 << (32 - vp1)) - 1: the all-ones generation marks never-used / wiped buckets
+  size_t max_fill_items;      // largest fill (pending index) the value field can hold
 };
 
 namespace fgnn {
@@ -82,68 +88,90 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t batch_key
 
 // ---- dedup hash table probes (see hashtable.hip for the design) -----------------------------------
 constexpr unsigned long long kEmpty64 = 0xFFFFFFFFFFFFFFFFull;
-constexpr uint32_t kPending = 0x80000000u;
+constexpr uint32_t kPosOwner = 0x80000000u;  // flag on a remembered bucket index (three-kernel path): item owns its key
 constexpr uint32_t kNoBucket = 0x7FFFFFFFu;  // capacity <= 2^31, so never a real bucket index
+
+// what the kernels need of a table: the current generation is baked in at launch time
+struct HtView {
+  unsigned long long *table;
+  uint32_t shift, mask;
+  uint32_t vp1;       // bits of pending + index
+  uint32_t gen_base;  // generation << vp1
+  uint32_t pend;      // pending flag = 1 << (vp1 - 1): value = pend | i while item i is a pending first occurrence
+};
+inline HtView ht_view(const fgnn_hashtable *ht) {
+  return HtView{ht->table, ht->shift, (uint32_t)(ht->capacity - 1), ht->vp1, ht->gen << ht->vp1, 1u << (ht->vp1 - 1)};
+}
 
 __device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t shift, uint32_t mask) {
   return ((id * 0x9E3779B1u) >> shift) & mask;
 }
+// does this bucket word belong to the view's generation?  (stale generations and the wiped pattern read as empty)
+__device__ __forceinline__ bool ht_live(const HtView &t, unsigned long long word) {
+  return (((uint32_t)word ^ t.gen_base) >> t.vp1) == 0u;
+}
+// value field without the generation
+__device__ __forceinline__ uint32_t ht_value(const HtView &t, unsigned long long word) {
+  return (uint32_t)word ^ t.gen_base;
+}
 
-// Inserts (id, value) keeping the minimum value per key.  Returns the bucket index.
-__device__ __forceinline__ uint32_t ht_insert_min(unsigned long long *table, uint32_t shift, uint32_t mask,
-                                                  uint32_t id, uint32_t value) {
-  const unsigned long long mine = ((unsigned long long)id << 32) | value;
-  uint32_t h = hash_slot(id, shift, mask);
+// Inserts (id, value) keeping the minimum value per key.  `value` = pend|index or a local id.  Returns the bucket.
+__device__ __forceinline__ uint32_t ht_insert_min(const HtView &t, uint32_t id, uint32_t value) {
+  const uint32_t mine_v = t.gen_base | value;
+  const unsigned long long mine = ((unsigned long long)id << 32) | mine_v;
+  uint32_t h = hash_slot(id, t.shift, t.mask);
   // load factor <= 0.5 by construction; the bound only keeps a violated contract (more distinct
   // keys than max_items) from hanging the GPU
-  for (uint32_t probes = 0; probes <= mask; ++probes) {
-    unsigned long long cur = table[h];
-    if (cur == kEmpty64) {
-      cur = atomicCAS(&table[h], kEmpty64, mine);
-      if (cur == kEmpty64) return h;
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+    unsigned long long cur = t.table[h];
+    for (int tries = 0; tries < 4 && !ht_live(t, cur); ++tries) {  // free for this generation: claim it
+      const unsigned long long old = atomicCAS(&t.table[h], cur, mine);
+      if (old == cur) return h;
+      cur = old;  // the word we read was out of date: look at what is really there
     }
-    if ((uint32_t)(cur >> 32) == id) {
-      if ((uint32_t)cur > value) atomicMin(&table[h], mine);
+    if (ht_live(t, cur) && (uint32_t)(cur >> 32) == id) {
+      if ((uint32_t)cur > mine_v) atomicMin(&t.table[h], mine);
       return h;
     }
-    h = (h + 1) & mask;
+    h = (h + 1) & t.mask;
   }
   return kNoBucket;
 }
-
 
 // UB independent inserts with their memory operations overlapped: all probe loads are issued first, then all
 // CAS, and only keys that collide with a different key fall back to the sequential probe loop.  A lane that
 // inserts its UB edges one after the other pays UB dependent (load + CAS) round trips to the memory-side
 // atomic unit; here it pays about one.
 template <int UB>
-__device__ __forceinline__ void ht_insert_min_batch(unsigned long long *table, uint32_t shift, uint32_t mask,
-                                                    const uint32_t (&key)[UB], const uint32_t (&val)[UB],
-                                                    const bool (&live)[UB], uint32_t (&bucket)[UB]) {
+__device__ __forceinline__ void ht_insert_min_batch(const HtView &t, const uint32_t (&key)[UB],
+                                                    const uint32_t (&val)[UB], const bool (&live)[UB],
+                                                    uint32_t (&bucket)[UB]) {
   uint32_t h[UB];
   unsigned long long cur[UB];
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
-    h[u] = hash_slot(key[u], shift, mask);
-    cur[u] = live[u] ? table[h[u]] : 0ull;
+    h[u] = hash_slot(key[u], t.shift, t.mask);
+    cur[u] = live[u] ? t.table[h[u]] : 0ull;
   }
   unsigned long long old[UB];
+  bool tried[UB];
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     old[u] = cur[u];
-    if (live[u] && cur[u] == kEmpty64)
-      old[u] = atomicCAS(&table[h[u]], kEmpty64, ((unsigned long long)key[u] << 32) | val[u]);
+    tried[u] = live[u] && !ht_live(t, cur[u]);
+    if (tried[u]) old[u] = atomicCAS(&t.table[h[u]], cur[u], ((unsigned long long)key[u] << 32) | t.gen_base | val[u]);
   }
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     if (!live[u]) continue;
-    if (cur[u] == kEmpty64 && old[u] == kEmpty64) {  // our CAS installed the key
+    const uint32_t mine_v = t.gen_base | val[u];
+    if (tried[u] && old[u] == cur[u]) {  // our CAS installed the key
       bucket[u] = h[u];
-    } else if ((uint32_t)(old[u] >> 32) == key[u]) {  // key already there: keep the minimum value
-      if ((uint32_t)old[u] > val[u]) atomicMin(&table[h[u]], ((unsigned long long)key[u] << 32) | val[u]);
+    } else if (ht_live(t, old[u]) && (uint32_t)(old[u] >> 32) == key[u]) {  // key already there: keep the minimum
+      if ((uint32_t)old[u] > mine_v) atomicMin(&t.table[h[u]], ((unsigned long long)key[u] << 32) | mine_v);
       bucket[u] = h[u];
-    } else {  // slot taken by another key: ordinary probing from here
-      bucket[u] = ht_insert_min(table, shift, mask, key[u], val[u]);
+    } else {  // slot taken by another key, or our view of it was out of date: ordinary probing from here
+      bucket[u] = ht_insert_min(t, key[u], val[u]);
     }
   }
 }
@@ -373,6 +401,8 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                  ScanWsHost *scan);
+// Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts
+int hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_counts);
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,

@@ -10,8 +10,11 @@
 //    {key,local,index,version}: a whole insert is a single 8-byte CAS, duplicates resolve to the
 //    minimum index with one 8-byte atomicMin (the key half is identical, so u64 min == value min);
 //    half the table footprint keeps the table inside the 256 MiB Infinity Cache;
-//  * value = 0x80000000|i while item i is the pending first occurrence of a new key, a local id
-//    (< 2^31) once assigned -- replaces the `version` field and the per-batch version bump;
+//  * value = [generation | pending flag | index]: pending|i while item i is the pending first occurrence of a new
+//    key, a local id once assigned.  A bucket whose generation is not the table's current one is EMPTY, so
+//    Reset() (cuda_hashtable.cu:714-723, a 137 MB memset per batch in the reference) is a generation bump; the
+//    table is really wiped only when the generation counter wraps (every 2^(32 - index bits - 1) - 1 batches:
+//    511 for GraphSAGE [25,10] at batch 8000).  A free bucket is claimed by CAS(expected = the word just read);
 //  * device-scope atomics on CDNA4 execute at the memory side (~20 G scattered atomics/s chip-wide),
 //    so the insert first READS the bucket and only issues an atomic when it can change something:
 //    a key that is already present with a smaller value costs one 8-byte load, no atomic.
@@ -27,30 +30,28 @@
 namespace fgnn {
 namespace {
 
-__device__ __forceinline__ uint32_t ht_find(const unsigned long long *table, uint32_t shift, uint32_t mask,
-                                            uint32_t id, uint32_t *bucket) {
-  uint32_t h = hash_slot(id, shift, mask);
+__device__ __forceinline__ uint32_t ht_find(const HtView &t, uint32_t id, uint32_t *bucket) {
+  uint32_t h = hash_slot(id, t.shift, t.mask);
   // the key is present by contract; bound the probe anyway so a violated contract cannot hang the GPU
-  for (uint32_t probes = 0; probes <= mask; ++probes) {
-    const unsigned long long cur = table[h];
-    if ((uint32_t)(cur >> 32) == id) { *bucket = h; return (uint32_t)cur; }
-    if (cur == kEmpty64) break;
-    h = (h + 1) & mask;
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+    const unsigned long long cur = t.table[h];
+    if (!ht_live(t, cur)) break;
+    if ((uint32_t)(cur >> 32) == id) { *bucket = h; return ht_value(t, cur); }
+    h = (h + 1) & t.mask;
   }
   *bucket = 0;
   return FGNN_EMPTY_KEY;
 }
 
 // FillWithUnique: item i -> local id base + i
-__global__ __launch_bounds__(kBlock) void ht_fill_unique_kernel(unsigned long long *table, uint32_t shift,
-                                                                uint32_t mask, const uint32_t *__restrict__ items,
+__global__ __launch_bounds__(kBlock) void ht_fill_unique_kernel(HtView t, const uint32_t *__restrict__ items,
                                                                 size_t n, uint32_t *__restrict__ n2o,
                                                                 uint32_t *d_num_items, size_t max_items) {
   const uint32_t base = d_num_items[0];
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n && base + i < max_items) {
     const uint32_t id = items[i];
-    (void)ht_insert_min(table, shift, mask, id, (uint32_t)(base + i));
+    (void)ht_insert_min(t, id, (uint32_t)(base + i));
     n2o[base + i] = id;
   }
 }
@@ -58,8 +59,7 @@ __global__ __launch_bounds__(kBlock) void ht_fill_unique_kernel(unsigned long lo
 // first fill of a batch on a freshly reset table: item i -> local id i; also copies the items (the
 // batch's output_nodes), initialises the batch summary and sets the item count -- one launch instead
 // of memset + fill + advance + copy
-__global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(unsigned long long *table, uint32_t shift,
-                                                                uint32_t mask, const uint32_t *__restrict__ items,
+__global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(HtView t, const uint32_t *__restrict__ items,
                                                                 size_t n, uint32_t *__restrict__ n2o,
                                                                 uint32_t *__restrict__ items_copy,
                                                                 uint32_t *d_num_items, fgnn_batch_meta *meta,
@@ -80,13 +80,14 @@ __global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(unsigned long lo
   }
   if (i < n) {
     const uint32_t id = items[i];
-    (void)ht_insert_min(table, shift, mask, id, (uint32_t)i);
+    (void)ht_insert_min(t, id, (uint32_t)i);
     n2o[i] = id;
     if (items_copy) items_copy[i] = id;
   }
 }
 
-// Reset (cuda_hashtable.cu:714-723): all buckets empty, counts zero.  Non-temporal 16-byte stores: the wiped
+// The real wipe behind Reset (only when the generation counter wraps): all buckets to the never-used pattern,
+// counts zero.  Non-temporal 16-byte stores: the wiped
 // table is not read again before the next batch has gone through the whole chain, and 64 MiB of ordinary stores
 // would sit as dirty lines in the Infinity Cache and be evicted by -- i.e. slow down -- the random reads of the
 // kernels that follow (measured: 500 K cold 4-byte reads take 21 us instead of 8 us right after a large write).
@@ -108,8 +109,7 @@ __global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_i
 
 // pass 1: insert every item with value PENDING|i; remember its bucket
 template <int IPT>
-__global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *table, uint32_t shift, uint32_t mask,
-                                                           const uint32_t *__restrict__ items, size_t n_host,
+__global__ __launch_bounds__(kBlock) void ht_insert_kernel(HtView t, const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
                                                            uint32_t *__restrict__ pos, uint32_t *d_num_items) {
   const size_t n = resolve_count64(n_host, d_n, cap);
@@ -118,14 +118,13 @@ __global__ __launch_bounds__(kBlock) void ht_insert_kernel(unsigned long long *t
 #pragma unroll
   for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
-    if (i < n) pos[i] = ht_insert_min(table, shift, mask, items[i], kPending | (uint32_t)i);
+    if (i < n) pos[i] = ht_insert_min(t, items[i], t.pend | (uint32_t)i);
   }
 }
 
 // pass 2: owner(i) <=> bucket value == PENDING|i ; per-workgroup owner counts; flag kept in pos bit 31
 template <int IPT>
-__global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long long *__restrict__ table,
-                                                          size_t n_host, const size_t *d_n, size_t cap,
+__global__ __launch_bounds__(kBlock) void ht_count_kernel(HtView t, size_t n_host, const size_t *d_n, size_t cap,
                                                           uint32_t *__restrict__ pos,
                                                           uint32_t *__restrict__ block_sums,
                                                           uint32_t *d_num_items) {
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long lo
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t b = pos[i];
-      const bool owner = b != kNoBucket && (uint32_t)table[b] == (kPending | (uint32_t)i);
-      if (owner) { pos[i] = b | kPending; ++cnt; }
+      const bool owner = b != kNoBucket && ht_value(t, t.table[b]) == (t.pend | (uint32_t)i);
+      if (owner) { pos[i] = b | kPosOwner; ++cnt; }
     }
   }
   uint32_t tot;
@@ -150,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void ht_count_kernel(const unsigned long lo
 
 // pass 3: owners take local id = old_num_items + rank (rank in item order) and append to N2O
 template <int IPT>
-__global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *table,
-                                                           const uint32_t *__restrict__ items, size_t n_host,
+__global__ __launch_bounds__(kBlock) void ht_assign_kernel(HtView t, const uint32_t *__restrict__ items,
+                                                           size_t n_host,
                                                            const size_t *d_n, size_t cap,
                                                            const uint32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ block_offsets,
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
     bool owner = false;
     if (i < n) {
       b = pos[i];
-      owner = (b & kPending) != 0;
+      owner = (b & kPosOwner) != 0;
     }
     uint32_t tot;
     const uint32_t rank = block_exclusive_rank<kWavesPerBlock>(owner, sh, &tot);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
       const uint32_t local = running + rank;
       if (local < max_items) {
         // low half of the little-endian 64-bit bucket = value
-        reinterpret_cast<uint32_t *>(&table[b & ~kPending])[0] = local;
+        reinterpret_cast<uint32_t *>(&t.table[b & ~kPosOwner])[0] = t.gen_base | local;
         n2o[local] = items[i];
       }
     }
@@ -197,8 +196,8 @@ __global__ __launch_bounds__(kBlock) void ht_assign_kernel(unsigned long long *t
 // and the scan kernel between them is gone.  The remap is resolved on the spot for owners and for keys that
 // already had a local id before this fill; only duplicates WITHIN the fill (value still PENDING|other) are
 // left for ht_map_fix_kernel.  d_num_items[1] must hold the item count before the fill (set by pass 1).
-__global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(unsigned long long *table,
-                                                                 const uint32_t *__restrict__ items, size_t n_host,
+__global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const uint32_t *__restrict__ items,
+                                                                 size_t n_host,
                                                                  const size_t *d_n, size_t cap,
                                                                  const uint32_t *__restrict__ pos,
                                                                  uint32_t *d_num_items, uint32_t *__restrict__ n2o,
@@ -228,16 +227,16 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(unsigned long l
       bk[u] = ok[u] ? pos[i] : kNoBucket;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? (uint32_t)table[bk[u]] : FGNN_EMPTY_KEY;
+    for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (ok[u]) {
         const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
-        if (bk[u] != kNoBucket && v[u] == (kPending | (uint32_t)i)) {
+        if (bk[u] != kNoBucket && v[u] == (t.pend | (uint32_t)i)) {
           owner_mask |= 1u << (r0 + u);
           ++cnt;
         } else if (mapped) {
-          mapped[i] = v[u];  // final local id, or PENDING|owner (fixed up later), or EMPTY (no bucket)
+          mapped[i] = v[u];  // final local id, or pend|owner (fixed up later), or EMPTY (no bucket)
         }
       }
     }
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(unsigned long l
     if (owner) {
       const uint32_t local = running + rank;
       if (local < max_items) {
-        reinterpret_cast<uint32_t *>(&table[pos[i]])[0] = local;  // low half of the little-endian bucket = value
+        reinterpret_cast<uint32_t *>(&t.table[pos[i]])[0] = t.gen_base | local;  // low half of the bucket = value
         n2o[local] = items[i];
       }
       if (mapped) mapped[i] = local < max_items ? local : FGNN_EMPTY_KEY;
@@ -275,22 +274,20 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(unsigned long l
 
 // the remap entries ht_count_assign_kernel could not resolve: duplicates inside the fill whose owner had not
 // been numbered yet.  Only those touch the table again.
-__global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(const unsigned long long *__restrict__ table,
-                                                            size_t n_host, const size_t *d_n, size_t cap,
+__global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(HtView t, size_t n_host, const size_t *d_n, size_t cap,
                                                             const uint32_t *__restrict__ pos,
                                                             uint32_t *__restrict__ mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
     const uint32_t m = mapped[i];
-    if ((m & kPending) && m != FGNN_EMPTY_KEY) mapped[i] = (uint32_t)table[pos[i]];
+    if ((m & t.pend) && m != FGNN_EMPTY_KEY) mapped[i] = ht_value(t, t.table[pos[i]]);
   }
 }
 
 // pass 4: mapped[i] = local id of items[i] (bucket known)
 template <int IPT>
-__global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long long *__restrict__ table,
-                                                            size_t n_host, const size_t *d_n, size_t cap,
+__global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(HtView t, size_t n_host, const size_t *d_n, size_t cap,
                                                             const uint32_t *__restrict__ pos,
                                                             uint32_t *__restrict__ mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
@@ -299,17 +296,16 @@ __global__ __launch_bounds__(kBlock) void ht_map_pos_kernel(const unsigned long 
   for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
-      const uint32_t b = pos[i] & ~kPending;
-      mapped[i] = b != kNoBucket ? (uint32_t)table[b] : FGNN_EMPTY_KEY;
+      const uint32_t b = pos[i] & ~kPosOwner;
+      mapped[i] = b != kNoBucket ? ht_value(t, t.table[b]) : FGNN_EMPTY_KEY;
     }
   }
 }
 
 // GPUMapEdges for ids without a remembered bucket
 template <int IPT>
-__global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(const unsigned long long *__restrict__ table,
-                                                              uint32_t shift, uint32_t mask,
-                                                              const uint32_t *__restrict__ items, size_t n_host,
+__global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(HtView t, const uint32_t *__restrict__ items,
+                                                              size_t n_host,
                                                               const size_t *d_n, size_t cap,
                                                               uint32_t *__restrict__ mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
@@ -319,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(const unsigned lon
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
     if (i < n) {
       uint32_t b;
-      mapped[i] = ht_find(table, shift, mask, items[i], &b);
+      mapped[i] = ht_find(t, items[i], &b);
     }
   }
 }
@@ -330,11 +326,16 @@ __global__ __launch_bounds__(kBlock) void ht_map_probe_kernel(const unsigned lon
 using namespace fgnn;
 
 extern "C" fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err) {
+  // fills of any size up to 2^30 items: one generation only, every Reset wipes the table
+  return fgnn_hashtable_create_ex(max_items, (size_t(1) << 30) - 1, h_err);
+}
+
+extern "C" fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max_fill_items, int *h_err) {
   auto fail = [&](int code) -> fgnn_hashtable * {
     if (h_err) *h_err = code;
     return nullptr;
   };
-  if (max_items == 0 || max_items >= 0x7fffffffull) return fail(FGNN_EINVAL);
+  if (max_items == 0 || max_items >= (size_t(1) << 30) || max_fill_items >= (size_t(1) << 30)) return fail(FGNN_EINVAL);
   size_t cap = 1024;
   uint32_t lg = 10;
   while (cap < 2 * max_items) { cap <<= 1; ++lg; }
@@ -346,6 +347,14 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err) {
   ht->n2o = nullptr;
   ht->n2o_owned = nullptr;
   ht->d_num_items = nullptr;
+  // value field: the largest index is a local id (< max_items) or a pending item index (< max_fill_items)
+  const size_t max_index = (max_items > max_fill_items ? max_items : max_fill_items);
+  uint32_t vbits = 1;
+  while ((size_t(1) << vbits) <= max_index) ++vbits;
+  ht->vp1 = vbits + 1;                                 // + the pending flag; <= 31
+  ht->gen_limit = (1u << (32 - ht->vp1)) - 1u;         // >= 1; the all-ones generation is the wiped pattern
+  ht->gen = 0;
+  ht->max_fill_items = max_fill_items;
   ht->scan = new ScanWsHost();
   if (ht->scan->create(4096) != FGNN_OK ||
       hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
@@ -371,10 +380,9 @@ extern "C" int fgnn_hashtable_start_batch(fgnn_hashtable *ht, const uint32_t *it
                                           uint32_t *items_copy, fgnn_batch_meta *d_meta, uint64_t key,
                                           uint32_t num_layers, void *stream) {
   if (!ht || (!items && num_items) || num_items > ht->max_items) return FGNN_EINVAL;
-  const uint32_t mask = (uint32_t)(ht->capacity - 1);
   const size_t nb = num_items ? div_up(num_items, kBlock) : 1;
-  hipLaunchKernelGGL(ht_start_batch_kernel, dim3(nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream), ht->table,
-                     ht->shift, mask, items, num_items, ht->n2o, items_copy, ht->d_num_items, d_meta, key, num_layers);
+  hipLaunchKernelGGL(ht_start_batch_kernel, dim3(nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream), ht_view(ht),
+                     items, num_items, ht->n2o, items_copy, ht->d_num_items, d_meta, key, num_layers);
   return launch_status(__func__);
 }
 
@@ -396,14 +404,27 @@ extern "C" const uint32_t *fgnn_hashtable_d_num_items(const fgnn_hashtable *ht) 
   return ht ? ht->d_num_items : nullptr;
 }
 
-extern "C" int fgnn_hashtable_reset(fgnn_hashtable *ht, void *stream) {
-  if (!ht) return FGNN_EINVAL;
+// Reset: every bucket reads as empty afterwards.  Normally a generation bump (kernels launched from now on carry
+// the new generation); the table is physically wiped when the generations are used up.  zero_counts: also clear the
+// item counts (the batch driver does not need that, its first kernel of a batch sets them).
+int fgnn::hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_counts) {
   auto s = static_cast<hipStream_t>(stream);
+  if (ht->gen + 1 < ht->gen_limit) {
+    ++ht->gen;
+    if (zero_counts) FGNN_HIP_CHECK(hipMemsetAsync(ht->d_num_items, 0, 2 * sizeof(uint32_t), s));
+    return FGNN_OK;
+  }
+  ht->gen = 0;
   size_t blocks = div_up(ht->capacity / 2, (size_t)kBlock * 4);
   const size_t max_blocks = (size_t)device_cu_count() * 8;
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(ht_wipe_kernel, dim3(blocks), dim3(kBlock), 0, s, ht->table, ht->capacity, ht->d_num_items);
   return launch_status(__func__);
+}
+
+extern "C" int fgnn_hashtable_reset(fgnn_hashtable *ht, void *stream) {
+  if (!ht) return FGNN_EINVAL;
+  return fgnn::hashtable_next_generation(ht, stream, true);
 }
 
 extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
@@ -412,9 +433,8 @@ extern "C" int fgnn_hashtable_fill_unique(fgnn_hashtable *ht, const uint32_t *it
   if (num_items == 0) return FGNN_OK;
   if (num_items > ht->max_items) return FGNN_EINVAL;
   auto s = static_cast<hipStream_t>(stream);
-  const uint32_t mask = (uint32_t)(ht->capacity - 1);
-  hipLaunchKernelGGL(ht_fill_unique_kernel, dim3(div_up(num_items, kBlock)), dim3(kBlock), 0, s, ht->table, ht->shift,
-                     mask, items, num_items, ht->n2o, ht->d_num_items, ht->max_items);
+  hipLaunchKernelGGL(ht_fill_unique_kernel, dim3(div_up(num_items, kBlock)), dim3(kBlock), 0, s, ht_view(ht), items,
+                     num_items, ht->n2o, ht->d_num_items, ht->max_items);
   hipLaunchKernelGGL(ht_advance_kernel, dim3(1), dim3(1), 0, s, ht->d_num_items, (uint32_t)num_items);
   return launch_status(__func__);
 }
@@ -433,8 +453,9 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (!ht) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
-  if (!items || cap >= 0x80000000ull) return FGNN_EINVAL;
+  if (!items || cap > ht->max_fill_items) return FGNN_EINVAL;  // pending indices must fit the value field
   auto s = static_cast<hipStream_t>(stream);
+  const HtView tv = ht_view(ht);
   // latency-bound at mini-batch sizes: one item per lane (8x more waves in flight) unless the input is huge
   const int ipt = cap <= (4u << 20) ? 1 : kItemsPerThread;
   const size_t nb = div_up(cap, (size_t)kBlock * ipt);
@@ -443,7 +464,6 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (ws_bytes < need) return FGNN_ENOSPC;
   uint32_t *pos = static_cast<uint32_t *>(ws);
   uint32_t *sums = pos + cap;
-  const uint32_t mask = (uint32_t)(ht->capacity - 1);
 #define FGNN_HT(KERNEL, ...)                                                                  \
   do {                                                                                        \
     if (ipt == 1) hipLaunchKernelGGL((KERNEL<1>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
@@ -451,7 +471,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
   if (!already_inserted)
-    FGNN_HT(ht_insert_kernel, ht->table, ht->shift, mask, items, num_items, d_num_items, cap, pos, ht->d_num_items);
+    FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items);
   if (!scan) scan = ht->scan;
   if (scan) {
     // single-pass path: the grid must be resident at once (ticketless look-back) and a chunk at most 32 rounds
@@ -464,23 +484,23 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
     if (grid > nb1) grid = nb1;
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
-      hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, ht->table, items, num_items,
+      hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
                          scan->next(true, 1));
       if (mapped)
-        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, ht->table, num_items, d_num_items, cap,
+        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
                            pos, mapped);
       return launch_status(__func__);
     }
   }
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
-  FGNN_HT(ht_count_kernel, ht->table, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
+  FGNN_HT(ht_count_kernel, tv, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s, nullptr,
                              (uint32_t)(kBlock * ipt), d_num_items) != FGNN_OK)
     return FGNN_EHIP;
-  FGNN_HT(ht_assign_kernel, ht->table, items, num_items, d_num_items, cap, pos, sums, ht->d_num_items, ht->n2o,
+  FGNN_HT(ht_assign_kernel, tv, items, num_items, d_num_items, cap, pos, sums, ht->d_num_items, ht->n2o,
           ht->max_items, summary);
-  if (mapped) FGNN_HT(ht_map_pos_kernel, ht->table, num_items, d_num_items, cap, pos, mapped);
+  if (mapped) FGNN_HT(ht_map_pos_kernel, tv, num_items, d_num_items, cap, pos, mapped);
 #undef FGNN_HT
   return launch_status(__func__);
 }
@@ -491,9 +511,7 @@ extern "C" int fgnn_hashtable_map(const fgnn_hashtable *ht, const uint32_t *item
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
   if (!items || !mapped) return FGNN_EINVAL;
-  const uint32_t mask = (uint32_t)(ht->capacity - 1);
   hipLaunchKernelGGL((ht_map_probe_kernel<1>), dim3(div_up(cap, kBlock)), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), ht->table, ht->shift, mask, items, num_items, d_num_items, cap,
-                     mapped);
+                     static_cast<hipStream_t>(stream), ht_view(ht), items, num_items, d_num_items, cap, mapped);
   return launch_status(__func__);
 }

@@ -64,8 +64,7 @@ __device__ __forceinline__ int owner_of_slot(const uint32_t *lo, uint32_t p) {
 constexpr uint32_t kWriteBack = 0x80000000u;  // flag on a logged swap position: this step's value survives in the row
 
 struct FuseArgs {               // dedup insert fused into phase B (engine path)
-  unsigned long long *table;    // null = not fused
-  uint32_t shift, mask;
+  HtView t;                     // t.table == null: not fused
   uint32_t *pos;                // bucket of every emitted edge
   uint32_t *d_num_items;        // the table's {count, count before the running fill}
 };
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   const int tid = threadIdx.x;
   const size_t n = resolve_count(num_input, d_num_input, cap);
   // this kernel is pass 1 of the dedup fill: the later passes want the item count from before the fill
-  if (fuse.table && blockIdx.x == 0 && tid == 0) fuse.d_num_items[1] = fuse.d_num_items[0];
+  if (fuse.t.table && blockIdx.x == 0 && tid == 0) fuse.d_num_items[1] = fuse.d_num_items[0];
   // single-pass mode (scan.desc != null): the workgroup's position in the seed list is an ordered ticket and the
   // output offset comes from a look-back over the earlier workgroups' edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
@@ -277,11 +276,11 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
     // FillWithDuplicates pass 1 right here: the neighbour ids are in registers, the edge indices are known
     uint32_t bucket[UB];
-    if (fuse.table && !(ablate & 2u)) {
+    if (fuse.t.table && !(ablate & 2u)) {
       uint32_t ival[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) ival[u] = kPending | (uint32_t)(base + p0 + u * T);
-      ht_insert_min_batch<UB>(fuse.table, fuse.shift, fuse.mask, v, ival, live, bucket);
+      for (int u = 0; u < UB; ++u) ival[u] = fuse.t.pend | (uint32_t)(base + p0 + u * T);
+      ht_insert_min_batch<UB>(fuse.t, v, ival, live, bucket);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         const uint32_t p = p0 + u * T;
         out_dst[base + p] = v[u];
         out_src[base + p] = srcv[u];
-        if (fuse.table) fuse.pos[base + p] = (ablate & 2u) ? kNoBucket : bucket[u];
+        if (fuse.t.table) fuse.pos[base + p] = (ablate & 2u) ? kNoBucket : bucket[u];
         if (KHOP2 && bigv[u]) {
           sh_o[slot[u]] = v[u];   // value that lands in the consumed tail slot len-1-j
           sh_w[slot[u]] = wv[u];  // value that lands in position s_j
@@ -341,14 +340,13 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   const size_t nb = div_up(cap, (size_t)S);
   const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
   const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
-  FuseArgs fuse{nullptr, 0, 0, nullptr, nullptr};
+  FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr};
   uint32_t *sums = static_cast<uint32_t *>(ws);
   if (fuse_ht) {
     // ws = pos[cap*F] (consumed by the dedup passes) | dedup sums | ... ; this kernel's offsets go at the very end
     if (ws_bytes < (cap * fanout + nb + 8) * sizeof(uint32_t) + fgnn_scratch_bytes(cap * fanout)) return FGNN_ENOSPC;
-    fuse.table = fuse_ht->table;
-    fuse.shift = fuse_ht->shift;
-    fuse.mask = (uint32_t)(fuse_ht->capacity - 1);
+    if (cap * fanout > fuse_ht->max_fill_items) return FGNN_EINVAL;  // pending indices must fit the value field
+    fuse.t = ht_view(fuse_ht);
     fuse.pos = static_cast<uint32_t *>(ws);
     fuse.d_num_items = fuse_ht->d_num_items;
     sums = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes) - (nb + 4);

@@ -24,7 +24,7 @@ EXPORTS = [
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
-    "fgnn_hashtable_create", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
+    "fgnn_hashtable_create", "fgnn_hashtable_create_ex", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_get_miss_cache_index", "fgnn_gather_rows",
@@ -183,11 +183,17 @@ def sample_random_walk(indptr, indices, inp, walk_len, restart_prob, num_walks, 
 class HashTable:
     """OrderedHashTable (cuda_hashtable.h:99-149) on the GPU."""
 
-    def __init__(self, max_items, device="cuda:0"):
+    def __init__(self, max_items, device="cuda:0", max_fill_items=None):
+        """max_fill_items: largest fill_duplicates call; when given, reset() is a generation bump (see fgnn_hip.h)."""
         L = load()
         torch.cuda.set_device(device)
         err = C.c_int(0)
-        self.h = C.c_void_p(L.fgnn_hashtable_create(C.c_size_t(max_items), C.byref(err)))
+        L.fgnn_hashtable_create_ex.restype = C.c_void_p
+        if max_fill_items is None:
+            self.h = C.c_void_p(L.fgnn_hashtable_create(C.c_size_t(max_items), C.byref(err)))
+        else:
+            self.h = C.c_void_p(L.fgnn_hashtable_create_ex(C.c_size_t(max_items), C.c_size_t(max_fill_items),
+                                                           C.byref(err)))
         if not self.h:
             raise FgnnError(f"fgnn_hashtable_create failed with code {err.value}")
         self.max_items = max_items

@@ -129,6 +129,11 @@ typedef struct fgnn_hashtable fgnn_hashtable;
 /* max_items = PredictNumNodes(...) (common.cc:330-339).  Buckets are 8 bytes {key,value}; capacity is
  * the next power of two >= 2*max_items.  h_err != NULL receives the failing code. */
 fgnn_hashtable *fgnn_hashtable_create(size_t max_items, int *h_err);
+/* Same, for callers that know the largest fill (number of items of one fill_duplicates call): the spare bits of the
+ * 32-bit bucket value then hold a generation, and fgnn_hashtable_reset becomes a counter bump instead of a wipe of the
+ * whole table (the table is wiped once every 2^(31 - bits(max(max_items, max_fill_items))) - 1 resets).  Fills larger
+ * than max_fill_items are refused (FGNN_EINVAL). */
+fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max_fill_items, int *h_err);
 void fgnn_hashtable_destroy(fgnn_hashtable *ht);
 size_t fgnn_hashtable_capacity(const fgnn_hashtable *ht);
 /* Reset (cuda_hashtable.cu:714-723) */

@@ -134,6 +134,34 @@ def test_hashtable_matches_oracle(hip, oracle):
         np.testing.assert_array_equal(host_u32(ht.unique())[:len(seeds)], seeds)
 
 
+@pytest.mark.parametrize("max_fill", [40000, (1 << 27) - 1])
+def test_hashtable_generations(hip, oracle, max_fill):
+    """Reset as a generation bump: buckets of earlier generations must read as empty, also across the physical wipe
+    when the generation counter wraps (max_fill 2^27 leaves 3 generation bits: the 7th reset wipes) and when the
+    same keys come back generation after generation."""
+    rs = np.random.default_rng(13)
+    num_node = 20000
+    ht = hip.HashTable(30000, max_fill_items=max_fill)
+    oht = oracle.HashTable(num_node, 30000)
+    for rep in range(24):
+        ht.reset()
+        oht.reset()
+        seeds = rs.permutation(num_node)[:500 + 37 * rep].astype(np.uint32)
+        ht.fill_unique(dev(seeds))
+        assert oht.fill_unique(seeds) == 0
+        for n in (9000, 25000):
+            items = np.minimum((num_node * rs.random(n) ** 2).astype(np.uint32), num_node - 1)
+            mapped = ht.fill_duplicates(dev(items))
+            uniq = oht.fill_duplicates(items)
+            _, o_map = oht.map_edges(items, items)
+            assert ht.num_items() == len(uniq)
+            np.testing.assert_array_equal(host_u32(ht.unique()), uniq)
+            np.testing.assert_array_equal(host_u32(mapped, n), o_map)
+            np.testing.assert_array_equal(host_u32(ht.map(dev(items))), o_map)
+    with pytest.raises(hip.FgnnError):  # a fill larger than the table was created for
+        hip.HashTable(1000, max_fill_items=5000).fill_duplicates(dev(np.zeros(6000, dtype=np.uint32)))
+
+
 def test_hashtable_device_side_count(hip, oracle):
     rs = np.random.default_rng(4)
     items = rs.integers(0, 5000, size=10000).astype(np.uint32)
