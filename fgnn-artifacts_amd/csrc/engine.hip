@@ -363,7 +363,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted, nullptr);
+                                      inserted, nullptr, /*final_fill=*/l == 0);
     if (rc != FGNN_OK) return rc;
     in_cap += ecap;
     cur = out->input_nodes;

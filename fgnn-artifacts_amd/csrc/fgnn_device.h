@@ -400,7 +400,7 @@ struct LayerSummary {
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                 ScanWsHost *scan);
+                                 ScanWsHost *scan, bool final_fill = false);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts
 int hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_counts);
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
                                                                  const uint32_t *__restrict__ pos,
                                                                  uint32_t *d_num_items, uint32_t *__restrict__ n2o,
                                                                  size_t max_items, LayerSummary summary,
-                                                                 uint32_t *mapped, ScanWs scan) {
+                                                                 uint32_t *mapped, ScanWs scan, bool final_fill) {
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile;
   const uint32_t n = (uint32_t)resolve_count64(n_host, d_n, cap);  // cap < 2^31 (host check)
@@ -262,7 +262,9 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
     if (owner) {
       const uint32_t local = running + rank;
       if (local < max_items) {
-        reinterpret_cast<uint32_t *>(&t.table[pos[i]])[0] = t.gen_base | local;  // low half of the bucket = value
+        // low half of the bucket = value.  final_fill: nothing looks these keys up again before the table is reset
+        // (last layer of a batch; the fix-up below takes a duplicate's id from its owner's remap entry instead)
+        if (!final_fill) reinterpret_cast<uint32_t *>(&t.table[pos[i]])[0] = t.gen_base | local;
         n2o[local] = items[i];
       }
       if (mapped) mapped[i] = local < max_items ? local : FGNN_EMPTY_KEY;
@@ -273,15 +275,15 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
 }
 
 // the remap entries ht_count_assign_kernel could not resolve: duplicates inside the fill whose owner had not
-// been numbered yet.  Only those touch the table again.
+// been numbered yet.  The unresolved entry holds pend|owner's item index, and the owner's own remap entry (written
+// by the previous kernel) is its local id: one read of a small array instead of a 64 MiB table probe.
 __global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(HtView t, size_t n_host, const size_t *d_n, size_t cap,
-                                                            const uint32_t *__restrict__ pos,
-                                                            uint32_t *__restrict__ mapped) {
+                                                            uint32_t *mapped) {
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
     const uint32_t m = mapped[i];
-    if ((m & t.pend) && m != FGNN_EMPTY_KEY) mapped[i] = ht_value(t, t.table[pos[i]]);
+    if ((m & t.pend) && m != FGNN_EMPTY_KEY) mapped[i] = mapped[m & (t.pend - 1u)];
   }
 }
 
@@ -443,13 +445,13 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
                                               const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped,
                                               void *ws, size_t ws_bytes, void *stream) {
   return fgnn::hashtable_fill_duplicates_ex(ht, items, num_items, d_num_items, num_items_cap, mapped, ws, ws_bytes,
-                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false, nullptr);
+                                            stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false, nullptr, false);
 }
 
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                       ScanWsHost *scan) {
+                                       ScanWsHost *scan, bool final_fill) {
   if (!ht) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
@@ -486,10 +488,10 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(true, 1));
+                         scan->next(true, 1), final_fill && mapped != nullptr);
       if (mapped)
         hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
-                           pos, mapped);
+                           mapped);
       return launch_status(__func__);
     }
   }
