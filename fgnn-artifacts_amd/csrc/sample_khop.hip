@@ -297,15 +297,22 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
   }
 
-  // ---- phase C (khop2): apply the swaps to the CSR row, one lane per long row -------------------
+  // ---- phase C (khop2): apply the swaps to the CSR row -- one lane per (row, step) like phase B, so the F tail
+  // stores of a row are consecutive addresses in consecutive lanes (1-2 lines per row instead of F separate
+  // partial-line stores from one lane) -------------------------------------------------------------------------
   phase_mark(scan, tile, 3);
   if (KHOP2 && !(ablate & 4u)) {
     __syncthreads();  // every read of the old row contents above has been consumed
-    if (big) {
-      for (uint32_t j = 0; j < F; ++j) {
-        indices[off + len - 1 - j] = sh_o[j * S + k];  // the emitted value moves to the consumed tail slot
-        const uint32_t sj = sh_s[j * S + k];
-        if (sj & kWriteBack) indices[off + (sj & ~kWriteBack)] = sh_w[j * S + k];
+    for (uint32_t p = tid; p < total; p += T) {
+      const int kk = owner_of_slot<S>(sh_lo, p);
+      const uint32_t klen = sh_len[kk];
+      if (klen > F) {
+        const uint32_t j = p - sh_lo[kk];
+        const uint32_t koff = sh_off[kk];
+        const uint32_t sl = j * S + kk;
+        indices[koff + klen - 1 - j] = sh_o[sl];  // the emitted value moves to the consumed tail slot
+        const uint32_t sj = sh_s[sl];
+        if (sj & kWriteBack) indices[koff + (sj & ~kWriteBack)] = sh_w[sl];
       }
     }
   }
