@@ -298,11 +298,14 @@ __device__ __forceinline__ uint32_t scan_take_tile(const ScanWs &w, uint32_t *sh
 // tile publishes only its aggregate and sums ALL its predecessors' aggregates itself: thread j polls tiles
 // j, j + blockDim, ... (coalesced 8-byte loads), i.e. ONE memory round trip after the slowest predecessor has
 // published, no dependence between tiles.  O(tiles^2) 8-byte loads in total -- ~1 M for 1500 tiles, noise.
-__device__ __forceinline__ uint32_t scan_lookback(const ScanWs &w, uint32_t tile, uint32_t aggregate, uint32_t *sh) {
-  if (threadIdx.x == 0) {
-    scan_publish(w, tile, kScanAggregate, aggregate);
-    *sh = 0;
-  }
+// the two halves are also usable apart: publish as soon as the aggregate is known, sum the predecessors later
+// (by then they have usually all published: no waiting)
+__device__ __forceinline__ void scan_publish_aggregate(const ScanWs &w, uint32_t tile, uint32_t aggregate) {
+  if (threadIdx.x == 0) scan_publish(w, tile, kScanAggregate, aggregate);
+}
+
+__device__ __forceinline__ uint32_t scan_prefix(const ScanWs &w, uint32_t tile, uint32_t *sh) {
+  if (threadIdx.x == 0) *sh = 0;
   __syncthreads();
   uint32_t part = 0;
   for (uint32_t j = threadIdx.x; j < tile; j += blockDim.x) {
@@ -328,6 +331,11 @@ __device__ __forceinline__ uint32_t scan_lookback(const ScanWs &w, uint32_t tile
   const uint32_t r = *sh;
   __syncthreads();
   return r;
+}
+
+__device__ __forceinline__ uint32_t scan_lookback(const ScanWs &w, uint32_t tile, uint32_t aggregate, uint32_t *sh) {
+  scan_publish_aggregate(w, tile, aggregate);
+  return scan_prefix(w, tile, sh);
 }
 
 __device__ __forceinline__ size_t resolve_count(size_t n_host, const uint32_t *d_n, size_t cap) {

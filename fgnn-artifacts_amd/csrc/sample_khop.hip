@@ -100,7 +100,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   __shared__ uint32_t sh_tile;
   const uint32_t tile = single_pass ? scan_take_tile(scan, &sh_tile) : blockIdx.x;
   const size_t first = (size_t)tile * S;
-  if (!single_pass && first >= n) return;  // whole workgroup exits together
+  const uint32_t last_tile = n ? (uint32_t)((n - 1) / S) : 0u;  // tiles beyond it have no seeds and nobody waits for them
+  if (tile > last_tile) return;  // whole workgroup exits together
   phase_mark(scan, tile, 0);
   // the per-seed phases (0, A, C) run on ONE S-lane group of the workgroup; which one rotates with the tile id so
   // that the ALU-heavy swap simulation of the workgroups sharing a CU does not pile up on the same SIMD
@@ -123,6 +124,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     sh_lo[k] = lo;
   }
   if (tid == 0) sh_lo[S] = total;
+  // single pass: the tile's edge count is known here, long before its offset is needed (after phase A)
+  if (single_pass) scan_publish_aggregate(scan, tile, total);
   const bool big = seed_lane && len > F;
 
   // ---- phase A: which CSR positions does a long row emit? ---------------------------------
@@ -241,9 +244,9 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   size_t base;
   if (single_pass) {
-    base = scan_lookback(scan, tile, total, &sh_tile);
+    base = scan_prefix(scan, tile, &sh_tile);
     phase_mark(scan, tile, 2);
-    if (tile == gridDim.x - 1 && tid == 0 && d_num_out) *d_num_out = base + total;
+    if (tile == last_tile && tid == 0 && d_num_out) *d_num_out = base + total;
   } else {
     base = block_offsets[tile];
   }
@@ -372,19 +375,10 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
       attr_done = true;                                                                                        \
     }                                                                                                          \
-    if (want_scan) {                                                                                           \
-      /* single-pass only when every workgroup of the grid is resident at once (no ticket needed, no        */ \
-      /* possible wait on an undispatched workgroup); 3/4 of the occupancy query as margin                  */ \
-      static size_t occ_lds = ~size_t(0);                                                                      \
-      static int per_cu = 0;                                                                                   \
-      if (occ_lds != lds) {                                                                                    \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, khop_sample_kernel<SS, 256, KHOP2, FM>, 256, \
-                                                         lds) != hipSuccess)                                   \
-          per_cu = 0;                                                                                          \
-        occ_lds = lds;                                                                                         \
-      }                                                                                                        \
-      if (nb <= (size_t)per_cu * 256 * 3 / 4) scan = scan_host->next(true);                                    \
-    }                                                                                                          \
+    /* single pass (no count kernel, no scan kernel) for grids of up to 1536 workgroups: a workgroup waits only   */ \
+    /* for lower-numbered workgroups of its own launch, which each XCD dispatches before it, and 1536 workgroups   */ \
+    /* (192 per XCD) cannot fill an XCD with waiters, so the lowest unfinished tile always gets a slot             */ \
+    if (want_scan && nb <= 1536) scan = scan_host->next(true);                                                 \
     if (!scan.desc) {                                                                                          \
       scan.log = phase_log_base();                                                                             \
       hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,   \

@@ -1,0 +1,8 @@
+#!/bin/bash
+# host threads / streams sweep on one box
+for nt in "$@"; do
+  python3 bench.py --no-cpu-baseline --host-threads $nt 2>/dev/null | python3 -c "
+import sys,json
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('NT=$nt', '%.4f' % j['ms_per_step'], 'stage %.4f' % j['sample_stage']['ms_per_step'], 'enqueue %.3f' % j['host_enqueue_ms_per_step'], 'overflow', j['overflow'], 'gather frac %.3f' % j['roofline']['frac'])"
+done
