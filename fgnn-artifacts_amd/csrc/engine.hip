@@ -314,10 +314,15 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
   int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
   if (rc != FGNN_OK) return rc;
-  // Reset state + FillWithUnique(seeds) + output_nodes copy + summary init: one launch
-  rc = fgnn_hashtable_start_batch(ht, d_seeds, num_seeds, out->output_nodes, out->d_meta, batch_key, (uint32_t)L,
-                                  stream);
-  if (rc != FGNN_OK) return rc;
+  // Reset state + FillWithUnique(seeds) + output_nodes copy + summary header: done by the first sampler launch itself
+  // for the k-hop samplers (BatchStart), by one small launch otherwise
+  const bool khop_fused = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
+  const bool start_in_sampler = khop_fused && num_seeds > 0;
+  if (!start_in_sampler) {
+    rc = fgnn_hashtable_start_batch(ht, d_seeds, num_seeds, out->output_nodes, out->d_meta, batch_key, (uint32_t)L,
+                                    stream);
+    if (rc != FGNN_OK) return rc;
+  }
 
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
@@ -348,11 +353,13 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
                                    s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
                                    d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
                                    stream);
-    else
+    else {
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
+      const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
       rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
                              tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
-                             &sl.scan_sample);
+                             &sl.scan_sample, (start_in_sampler && l == (long)L - 1) ? &start : nullptr);
+    }
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
       FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));

@@ -422,12 +422,23 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
                       size_t num_input_cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out,
                       int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
                       void *stream, ScanWsHost *scan_host);
+// What the FIRST sampler launch of a batch does on top of sampling, so that no separate start-of-batch kernel is
+// needed: FillWithUnique(seeds) (seed i -> local id i), copy of the seeds (the batch's output_nodes), item counts and
+// the batch summary's header.  n2o == null: not the first launch.
+struct BatchStart {
+  uint32_t *n2o;
+  uint32_t *items_copy;
+  fgnn_batch_meta *meta;
+  uint64_t key;
+  uint32_t num_layers;
+  uint32_t layer;  // this launch's layer: its num_edge entry is written by the launch itself, not by the header init
+};
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan);
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr);
 
 }  // namespace fgnn

@@ -67,6 +67,7 @@ struct FuseArgs {               // dedup insert fused into phase B (engine path)
   HtView t;                     // t.table == null: not fused
   uint32_t *pos;                // bucket of every emitted edge
   uint32_t *d_num_items;        // the table's {count, count before the running fill}
+  BatchStart start;             // start.n2o != null: this is the first launch of a batch
 };
 
 // S seeds per workgroup handled by T >= S threads: the per-seed phases (0, A, C) use the first S threads, the
@@ -93,7 +94,29 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   const int tid = threadIdx.x;
   const size_t n = resolve_count(num_input, d_num_input, cap);
   // this kernel is pass 1 of the dedup fill: the later passes want the item count from before the fill
-  if (fuse.t.table && blockIdx.x == 0 && tid == 0) fuse.d_num_items[1] = fuse.d_num_items[0];
+  if (fuse.t.table && blockIdx.x == 0 && tid == 0) {
+    if (fuse.start.n2o) {  // first launch of a batch: the seeds ARE the table's first n items
+      fuse.d_num_items[0] = (uint32_t)n;
+      fuse.d_num_items[1] = (uint32_t)n;
+      fgnn_batch_meta *m = fuse.start.meta;
+      if (m) {  // header of the batch summary; this launch's own num_edge entry is written by its last tile
+        m->key = fuse.start.key;
+        for (uint32_t l = 0; l < FGNN_MAX_LAYERS; ++l) {
+          if (l != fuse.start.layer) m->num_edge[l] = 0;
+          m->num_src[l] = 0;
+          m->num_dst[l] = 0;
+        }
+        m->num_layers = fuse.start.num_layers;
+        m->num_input = (uint32_t)n;
+        m->num_output = (uint32_t)n;
+        m->num_miss = 0;
+        m->num_cache = 0;
+        m->overflow = 0;
+      }
+    } else {
+      fuse.d_num_items[1] = fuse.d_num_items[0];
+    }
+  }
   // single-pass mode (scan.desc != null): the workgroup's position in the seed list is an ordered ticket and the
   // output offset comes from a look-back over the earlier workgroups' edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
@@ -113,6 +136,11 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     rid = input[i];
     off = indptr[rid];
     len = indptr[rid + 1] - off;
+    if (fuse.t.table && fuse.start.n2o) {  // FillWithUnique: seed i gets local id i (min-insert: order does not matter)
+      (void)ht_insert_min(fuse.t, rid, (uint32_t)i);
+      fuse.start.n2o[i] = rid;
+      if (fuse.start.items_copy) fuse.start.items_copy[i] = rid;
+    }
   }
   const uint32_t c = len < F ? len : F;
   uint32_t total;
@@ -327,7 +355,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
                 size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr,
-                ScanWsHost *scan_host = nullptr) {
+                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
   if (cap == 0) {
@@ -350,7 +378,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   const size_t nb = div_up(cap, (size_t)S);
   const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
   const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
-  FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr};
+  FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr, BatchStart{nullptr, nullptr, nullptr, 0, 0, 0}};
   uint32_t *sums = static_cast<uint32_t *>(ws);
   if (fuse_ht) {
     // ws = pos[cap*F] (consumed by the dedup passes) | dedup sums | ... ; this kernel's offsets go at the very end
@@ -359,6 +387,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     fuse.t = ht_view(fuse_ht);
     fuse.pos = static_cast<uint32_t *>(ws);
     fuse.d_num_items = fuse_ht->d_num_items;
+    if (start) fuse.start = *start;
     sums = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes) - (nb + 4);
   } else if (ws_bytes < (nb + 1) * sizeof(uint32_t)) {
     return FGNN_ENOSPC;
@@ -413,13 +442,14 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan) {
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start) {
   if (!ht) return FGNN_EINVAL;
+  if (start && (d_num_input || !start->n2o)) return FGNN_EINVAL;  // the first launch takes the seeds with a host count
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan)
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan);
+                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start);
 }
 
 }  // namespace fgnn
