@@ -17,9 +17,11 @@ for r in csv.DictReader(open(f)):
         continue
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1), r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2] == "ht_start_batch_kernel"]
-b = starts[which]
-e = starts[which + 1]
+# a batch ends with the D2H copy of its summary; the setup copies come before the first sampler kernel
+first = next(i for i, r in enumerate(rows) if r[2].startswith("khop_sample") or r[2].startswith("ht_start_batch"))
+ends = [i for i, r in enumerate(rows) if i > first and r[2] == "__amd_rocclr_copyBuffer"]
+b = ends[which - 1] + 1
+e = ends[which] + 1
 t0 = rows[b][0]
 prev_end = t0
 busy = 0
@@ -28,4 +30,4 @@ for s, en, n, q in rows[b:e]:
     print("%8.1f %7.1f %6.1f  %s  %s" % ((s - t0) / 1e3, (en - s) / 1e3, (s - prev_end) / 1e3, q, n))
     busy += en - s
     prev_end = max(prev_end, en)
-print("total span %.1f us, kernel busy %.1f us, kernels %d" % ((rows[e][0] - t0) / 1e3, busy / 1e3, e - b))
+print("total span %.1f us, kernel busy %.1f us, kernels %d" % ((rows[e - 1][1] - t0) / 1e3, busy / 1e3, e - b))
