@@ -295,7 +295,10 @@ def main():
     ap.add_argument("--cache-ratio", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
-    ap.add_argument("--host-threads", type=int, default=2, help="host threads = HIP streams = batches in flight")
+    ap.add_argument("--host-threads", type=int, default=1, help="host threads enqueueing batches")
+    ap.add_argument("--streams-per-thread", type=int, default=3,
+                    help="HIP streams each host thread rotates over (batches in flight = threads x this); measured on "
+                         "MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
     ap.add_argument("--sample-type", default=None, choices=list(SAMPLE_TYPES),
                     help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
                          "multi_gpu/train_graphsage.py:75)")
@@ -347,15 +350,17 @@ def main():
                           prob_prefix=prefix, walk_len=w.get("walk_len", 3), num_walks=w.get("num_walks", 4),
                           restart_prob=w.get("restart_prob", 0.5))
     NT = 1 if args.no_overlap else args.host_threads
-    NBUF = 2 * NT
+    SPT = 1 if args.no_overlap else max(1, args.streams_per_thread)
+    NBUF = 2 * NT * SPT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
     for bt in batches:
         bt.enable_timing(True)  # HIP events around the feature gather, on the stream it is launched on
-    # NT host threads, each with its own HIP stream, take batches round-robin (batch i -> thread i % NT): whole
+    # Batches go round-robin over NT x SPT HIP streams (batch i -> stream i % (NT*SPT), enqueued by host thread i % NT;
+    # one thread is enough: enqueueing a batch takes ~0.06-0.1 ms): whole
     # batches overlap -- the latency-bound sampling/dedup chain of one with the bandwidth-bound gather of another.
     # fgnn_sampler_run_batch is thread-safe and keeps khop2's in-place CSR swaps in batch order (sequence numbers),
     # so the results are the same as a serial run.  (The reference also overlaps its sample and copy loops.)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(NT)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NT * SPT)]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -384,9 +389,9 @@ def main():
             step, seeds = seeds_of(i)
             t_h = time.perf_counter()
             if extract[0]:
-                sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[t])
+                sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[i % len(streams) if NT > 1 or SPT > 1 else 0])
             else:
-                sampler.run_batch(i, seeds, step, bt, table, None, None, stream=streams[t])
+                sampler.run_batch(i, seeds, step, bt, table, None, None, stream=streams[i % len(streams) if NT > 1 or SPT > 1 else 0])
             host_busy[t] += time.perf_counter() - t_h
         for i in range(max(first, last - NBUF) + ((t - max(first, last - NBUF)) % NT), last, NT):
             m = batches[i % NBUF].wait()
@@ -446,9 +451,9 @@ def main():
     extract[0] = True
     metas.clear()
     gather_ms.clear()
-    if NT > 1:
-        nt_saved = NT
-        NT = 1
+    if NT > 1 or SPT > 1:
+        nt_saved, spt_saved = NT, SPT
+        NT = SPT = 1
         base_seq = next_seq
         run_region(base_seq, base_seq + 24, True)
         torch.cuda.synchronize()
@@ -458,7 +463,7 @@ def main():
             ach = b / (float(np.mean(g)) * 1e-3) / 1e9
             serial = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(g)), "unit": "GB/s",
                       "note": "same launch with no concurrent batch (1 host thread / stream)"}
-        NT = nt_saved
+        NT, SPT = nt_saved, spt_saved
     metas[:] = metas_t
     gather_ms[:] = gather_t
 
@@ -507,7 +512,7 @@ def main():
             "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
             if world == 1 else None,
             "overflow": bool(overflow), "setup_s": t_setup,
-            "host_threads": NT, "host_enqueue_ms_per_step": sum(host_busy) / args.steps * 1e3,
+            "host_threads": NT, "streams": NT * SPT, "host_enqueue_ms_per_step": sum(host_busy) / args.steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:
             if args.sample_type in ("khop2", "khop0"):
