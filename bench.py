@@ -481,6 +481,22 @@ def main():
     elapsed, edges, rows = reduce_over_ranks(elapsed, edges, rows)
 
     ratio = pmc_traffic_ratio()
+    # reference point next to the 8 TB/s spec peak the fraction is quoted against: what torch's plain device-to-device
+    # copy of 2 GiB reaches on this GPU right now (read + write bytes per second; ordinary loads/stores -- the gather's
+    # non-temporal accesses beat it; tools/gather_sweep.py measured 6.5 TB/s for the gather kernel in isolation)
+    copy_gbs = None
+    if world == 1:
+        a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+        bdst = torch.empty_like(a)
+        bdst.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            bdst.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, bdst
     if rank == 0:
         out = {
             "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, full hot "
@@ -501,7 +517,7 @@ def main():
                                            "algorithmic bytes)",
                          "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
                          "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas),
-                         "serial": serial},
+                         "serial": serial, "torch_copy_GBps": copy_gbs},
             "epoch_time_s": {"sample_plus_extract": steps_per_epoch * (elapsed / args.steps) / world,
                              "note": f"{steps_per_epoch} steps/epoch x ms_per_step / n_gpus; no training step -- the "
                                      "reference's Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s)"},
