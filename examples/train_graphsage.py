@@ -42,6 +42,11 @@ def main():
     ap.add_argument("--lr", type=float, default=0.003)
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--sample-type", default="khop2")
+    ap.add_argument("--arch", default=None, choices=["arch1", "arch2", "arch3", "arch4"],
+                    help="default: arch3 (the reference's default, sampler cuda:0 + trainer cuda:1) with two GPUs, "
+                         "arch1 with one")
+    ap.add_argument("--cache-percentage", type=float, default=0.0, help="arch2-4: presample cache on the trainer GPU")
+    ap.add_argument("--pipeline", action="store_true", help="arch2-4: sam.start() background threads")
     args = ap.parse_args()
 
     if args.make_dataset:
@@ -54,14 +59,24 @@ def main():
                             shape["num_train"], 1000, 1000)
         print("dataset written in {:.1f}s".format(time.time() - t0))
 
-    run_config = dict(dataset_path=args.dataset_path, _arch=sam.kArch1, _sample_type=sam.sample_types[args.sample_type],
+    two = th.cuda.device_count() >= 2
+    arch = args.arch or ("arch3" if two else "arch1")
+    trainer_ctx = "cuda:1" if (arch in ("arch3", "arch4") and two) else "cuda:0"
+    sampler_ctx = "cuda:0" if arch != "arch4" or not two else "cuda:1"
+    if arch == "arch4" and two:
+        trainer_ctx = "cuda:0"  # builtin_archs['arch4'] (samgraph/common/__init__.py:118-122)
+    run_config = dict(dataset_path=args.dataset_path, _arch=sam.builtin_archs[arch]["arch"],
+                      _sample_type=sam.sample_types[args.sample_type],
                       batch_size=args.batch_size, num_epoch=args.num_epoch + 1,  # + one warm-up epoch (common_config.py:163)
-                      _cache_policy=sam.kCacheByPreSample, cache_percentage=0.0, max_sampling_jobs=10,
-                      max_copying_jobs=2, omp_thread_num=8, sampler_ctx="cuda:0", trainer_ctx="cuda:0",
+                      _cache_policy=sam.kCacheByPreSample, cache_percentage=args.cache_percentage, max_sampling_jobs=10,
+                      max_copying_jobs=2, omp_thread_num=8, sampler_ctx=sampler_ctx, trainer_ctx=trainer_ctx,
                       num_fanout=len(args.fanout), fanout=args.fanout)
     sam.config(run_config)
     sam.init()
-    dev = th.device("cuda:0")
+    pipeline = args.pipeline and arch != "arch1"  # arch1 doesn't support pipelining (common_config.py:212-214)
+    if pipeline:
+        sam.start()
+    dev = th.device(trainer_ctx)
     num_layer = len(args.fanout)
     model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout).to(dev)
     loss_fcn = nn.CrossEntropyLoss()
@@ -73,7 +88,8 @@ def main():
         t_epoch = time.time()
         t_train = 0.0
         for step in range(num_step):
-            sam.sample_once()
+            if not pipeline:
+                sam.sample_once()
             batch_key = sam.get_next_batch()
             blocks, batch_input, batch_label = sam.get_dgl_blocks(batch_key, num_layer)
             t1 = time.time()

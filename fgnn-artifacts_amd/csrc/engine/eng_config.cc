@@ -63,7 +63,7 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
   max_copying_jobs = std::stoull(need("max_copying_jobs"));
   omp_thread_num = std::stoi(need("omp_thread_num"));
   switch (run_arch) {
-    case kArch0: case kArch1: case kArch2: case kArch3: case kArch4:
+    case kArch1: case kArch2: case kArch3: case kArch4:
       sampler_ctx = Context(need("sampler_ctx"));
       trainer_ctx = Context(need("trainer_ctx"));
       break;
@@ -73,7 +73,8 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
       have_switcher = raw.count("have_switcher") ? std::stoi(raw["have_switcher"]) != 0 : false;
       break;
     default:
-      SAM_FATAL << "run arch " << run_arch << " is not built (supported: arch1, arch5)";
+      SAM_FATAL << "run arch " << run_arch << " is not built (supported: arch1-arch5; arch0 is the reference's CPU "
+                   "sampling mode and arch6/7 its SGNN baseline)";
   }
   if (sample_type != kRandomWalk) {
     const size_t nf = std::stoull(need("num_fanout"));

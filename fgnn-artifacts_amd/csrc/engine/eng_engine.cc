@@ -96,16 +96,13 @@ void Engine::Init() {
   data_initialized_ = true;
   if (RC().run_arch == kArch1) {
     InitArch1();
+  } else if (RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4) {
+    InitInProcess();
   } else {
     SAM_CHECK_EQ(RC().run_arch, (int)kArch5);
     // shared queue + sampler barrier, created BEFORE fork (dist_engine.cc:129-153)
     Timer tq;
-    const bool have_data = RC().sample_type == kRandomWalk;
-    size_t slot = MaxMessageBytes(RC().batch_size, RC().fanout.data(), RC().fanout.size(), have_data);
-    size_t slots = RC().mq_budget_bytes / slot;
-    if (slots > kMaxSlots) slots = kMaxSlots;
-    if (slots < 2) slots = 2;
-    mq_ = new MemoryQueue(slot, slots);
+    CreateQueue();
     void *bp = SharedAnonymous(sizeof(pthread_barrier_t));
     sampler_barrier_ = static_cast<pthread_barrier_t *>(bp);
     pthread_barrierattr_t attr;
@@ -115,6 +112,15 @@ void Engine::Init() {
     Profiler::Get().LogInit(kLogInitL2DistQueue, tq.Passed());
   }
   Profiler::Get().LogInit(kLogInitL1Common, t.Passed());
+}
+
+void Engine::CreateQueue() {
+  const bool have_data = RC().sample_type == kRandomWalk;
+  size_t slot = MaxMessageBytes(RC().batch_size, RC().fanout.data(), RC().fanout.size(), have_data);
+  size_t slots = RC().mq_budget_bytes / slot;
+  if (slots > kMaxSlots) slots = kMaxSlots;
+  if (slots < 2) slots = 2;
+  mq_ = new MemoryQueue(slot, slots);
 }
 
 void Engine::UploadTopology(int device) {
@@ -199,6 +205,56 @@ void Engine::InitArch1() {
     SAM_HIP(hipEventCreate(&s.e2));
   }
   Profiler::Get().LogInit(kLogInitL1Sampler, t.Passed());
+  initialized_ = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// arch2 / arch3 / arch4: one process, sampler on sampler_ctx, copy + extraction + training on trainer_ctx (the same GPU
+// in arch2) -- cuda_engine.cc:64-196, cuda_loops_arch{2,3,4}.cc.  Built from the arch5 halves: the sampler half
+// serialises each batch into an in-process pinned ring, the extractor half rebuilds it on the trainer GPU and
+// gathers the features there (HBM cache rows + miss rows straight from registered host memory).
+void Engine::InitInProcess() {
+  SAM_CHECK(RC().sampler_ctx.IsGPU() && RC().trainer_ctx.IsGPU())
+      << "arch2-4 need cuda contexts: the sampling path has no CPU fallback";
+  SAM_CHECK(RC().cache_policy != kDynamicCache) << "the dynamic cache prototype (arch4) is not built";
+  Timer t;
+  CreateQueue();
+  // sampler half
+  UploadTopology(RC().sampler_ctx.device_id);
+  mq_->PinMemory();
+  CreateSampler();
+  shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
+                               RC().batch_size, 0, 1, stream_));
+  slots_.resize(2);
+  for (auto &s : slots_) {
+    int err = 0;
+    s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
+    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    SAM_HIP(hipEventCreate(&s.e0));
+    SAM_HIP(hipEventCreate(&s.e1));
+    SAM_HIP(hipEventCreate(&s.e2));
+  }
+  if (RC().UseGPUCache()) {
+    Timer tp;
+    if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) PreSample();
+    Profiler::Get().LogInit(kLogInitL2Presample, tp.Passed());
+    Timer tc;
+    BuildCacheTable();
+    Profiler::Get().LogInit(kLogInitL2BuildCache, tc.Passed());
+  }
+  Profiler::Get().LogInit(kLogInitL1Sampler, t.Passed());
+  // extractor / trainer half
+  Timer tt;
+  SAM_HIP(hipSetDevice(RC().trainer_ctx.device_id));
+  tdevice_ = RC().trainer_ctx.device_id;
+  SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
+  SAM_HIP(hipHostRegister(ds_.feat.ptr, ds_.feat.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+  dev_host_feat_ = DeviceVisible(ds_.feat.ptr);
+  SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
+  SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
+  if (RC().UseGPUCache()) BuildTrainerCache();
+  pool_.reset(new GraphPool(RC().max_copying_jobs));
+  Profiler::Get().LogInit(kLogInitL1Trainer, tt.Passed());
   initialized_ = true;
 }
 
@@ -350,6 +406,7 @@ void Engine::BuildCacheTable() {
 
 void Engine::PublishPending() {
   if (pending_slot_ < 0) return;
+  SAM_HIP(hipSetDevice(device_));
   Slot &s = slots_[pending_slot_];
   fgnn_batch_meta m;
   SAM_FGNN(fgnn_batch_wait(s.fb, &m));  // the pack kernel is ordered before the summary copy
@@ -379,6 +436,7 @@ void Engine::PublishPending() {
 }
 
 void Engine::SampleOnceArch5() {
+  SAM_HIP(hipSetDevice(device_));
   const uint32_t *d_batch = nullptr;
   size_t bsize = 0;
   if (!shuffler_->GetBatch(&d_batch, &bsize)) SAM_FATAL << "null task from DoShuffle!";
@@ -434,8 +492,8 @@ void Engine::TrainInit(int worker_id, Context ctx, DistType type) {
   Timer t;
   dist_type_ = type;
   SAM_HIP(hipSetDevice(ctx.device_id));
-  device_ = ctx.device_id;
-  SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  tdevice_ = ctx.device_id;
+  SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
   mq_->PinMemory();
   // the host feature table becomes GPU-readable: miss rows are fetched by the gather kernel itself
   // (replaces the OpenMP ExtractMissData + H2D copy, cuda_cache_manager_host.cc:38-56)
@@ -463,14 +521,15 @@ void Engine::BuildTrainerCache() {
     SAM_HIP(hipMalloc(&d_rank, num_cached_ * sizeof(uint32_t)));
     SAM_HIP(hipMemcpy(d_rank, ds_.ranking_nodes, num_cached_ * sizeof(uint32_t), hipMemcpyHostToDevice));
     SAM_FGNN(fgnn_gather_rows(d_cache_rows_, dev_host_feat_, d_rank, nullptr, num_cached_, nullptr, num_cached_,
-                              ds_.feat_dim, FGNN_F32, stream_));
-    SAM_HIP(hipStreamSynchronize(stream_));
+                              ds_.feat_dim, FGNN_F32, tstream_));
+    SAM_HIP(hipStreamSynchronize(tstream_));
     (void)hipFree(d_rank);
   }
   if (dist_type_ == DistType::Switch) BuildCacheTable();  // the switcher splits hits/misses itself
 }
 
 void Engine::TrainerOnce() {
+  SAM_HIP(hipSetDevice(tdevice_));
   while (pool_->Full()) std::this_thread::sleep_for(std::chrono::microseconds(1));
   Timer t_recv;
   size_t mq_key = 0;
@@ -490,12 +549,12 @@ void Engine::TrainerOnce() {
   b->num_layer = hdr.num_layer;
   b->num_input = hdr.input_size;
   b->num_output = hdr.output_size;
-  b->device = device_;
+  b->device = tdevice_;
 
   auto to_device = [&](const uint32_t *src, size_t n) -> uint32_t * {
     uint32_t *d = static_cast<uint32_t *>(dev_pool_.Alloc(n * sizeof(uint32_t)));
     b->pooled.push_back(d);
-    if (n) SAM_HIP(hipMemcpyAsync(d, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    if (n) SAM_HIP(hipMemcpyAsync(d, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, tstream_));
     return d;
   };
 
@@ -504,12 +563,12 @@ void Engine::TrainerOnce() {
     d_input = to_device(p, hdr.input_size);
     p += hdr.input_size;
     b->input_nodes = d_input;
-    b->input_device = device_;
+    b->input_device = tdevice_;
   }
   uint32_t *d_output = to_device(p, hdr.output_size);
   p += hdr.output_size;
   b->output_nodes = d_output;
-  b->output_device = device_;
+  b->output_device = tdevice_;
 
   const size_t num_miss = hdr.num_miss, num_cache = hdr.input_size - hdr.num_miss;
   uint32_t *d_cidx[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -548,7 +607,7 @@ void Engine::TrainerOnce() {
   size_t miss_rows = num_miss;
   if (!use_cache) {
     SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
-                              ds_.feat_dim, FGNN_F32, stream_));
+                              ds_.feat_dim, FGNN_F32, tstream_));
     miss_rows = hdr.input_size;
   } else if (dist_type_ == DistType::Switch) {
     // own (smaller) cache: split on this GPU with device-side counts
@@ -560,25 +619,25 @@ void Engine::TrainerOnce() {
     b->pooled.push_back(ws);
     uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
     SAM_FGNN(fgnn_get_miss_cache_index(d_cache_table_, d_input, n, nullptr, n, idx[0], idx[1], idx[2], idx[3], d_counts,
-                                       ws, ws_bytes, stream_));
-    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32, stream_));
+                                       ws, ws_bytes, tstream_));
+    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32, tstream_));
     SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
-                              stream_));
+                              tstream_));
   } else {
     if (num_miss)   // CombineMissData with the host fetch fused in
       SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss, ds_.feat_dim,
-                                FGNN_F32, stream_));
+                                FGNN_F32, tstream_));
     if (num_cache)  // CombineCacheData
       SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, d_cidx[2], d_cidx[3], num_cache, nullptr, num_cache,
-                                ds_.feat_dim, FGNN_F32, stream_));
+                                ds_.feat_dim, FGNN_F32, tstream_));
   }
   // labels (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) -- gathered on the GPU from the HBM copy
   void *d_lab = dev_pool_.Alloc(hdr.output_size * 8);
   b->pooled.push_back(d_lab);
   b->label = d_lab;
   SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
-                            stream_));
-  SAM_HIP(hipStreamSynchronize(stream_));
+                            tstream_));
+  SAM_HIP(hipStreamSynchronize(tstream_));
   mq_->Release(mq_key);
   pool_->Submit(b);
 
@@ -600,7 +659,7 @@ void Engine::StartExtract(int count) {
   SAM_CHECK(initialized_ && (dist_type_ == DistType::Extract || dist_type_ == DistType::Switch));
   if (extract_thread_.joinable()) extract_thread_.join();
   extract_thread_ = std::thread([this, count]() {
-    SAM_HIP(hipSetDevice(device_));
+    SAM_HIP(hipSetDevice(tdevice_));
     for (int i = 0; i < count && !shutdown_; ++i) TrainerOnce();
   });
 }
@@ -609,6 +668,12 @@ void Engine::RunSampleOnce() {
   SAM_CHECK(initialized_);
   if (RC().run_arch == kArch1) {
     SampleOnceArch1();
+  } else if (RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4) {
+    // both sub-loops once, like RunArch3LoopsOnce (cuda_loops_arch3.cc:198-205): sample + publish, then copy/extract
+    SAM_CHECK(!sample_thread_.joinable()) << "samgraph_sample_once after samgraph_start";
+    SampleOnceArch5();
+    PublishPending();
+    TrainerOnce();
   } else if (dist_type_ == DistType::Sample) {
     SampleOnceArch5();
   } else {
@@ -628,12 +693,29 @@ uint64_t Engine::GetNextBatch() {
   return b->key;
 }
 
+void Engine::Start() {
+  if (!(RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4)) return;
+  SAM_CHECK(initialized_);
+  if (sample_thread_.joinable()) return;
+  // the sampler thread and the copy/extract thread of cuda_loops_arch3.cc:178-196; each handles every batch of the run
+  const size_t total = RC().num_epoch * num_step_;
+  sample_thread_ = std::thread([this, total]() {
+    for (size_t i = 0; i < total && !shutdown_; ++i) SampleOnceArch5();
+    if (!shutdown_) PublishPending();
+  });
+  extract_thread_ = std::thread([this, total]() {
+    for (size_t i = 0; i < total && !shutdown_; ++i) TrainerOnce();
+  });
+}
+
 void Engine::Shutdown() {
   shutdown_ = true;
   if (pool_) pool_->Stop();
+  if (sample_thread_.joinable()) sample_thread_.join();
   if (extract_thread_.joinable()) extract_thread_.join();
-  if (dist_type_ == DistType::Sample) PublishPending();
+  if (dist_type_ == DistType::Sample || sampler_) PublishPending();
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (tstream_) (void)hipStreamSynchronize(tstream_);
   if (current_) {
     ReleaseBatch(current_.get());
     current_.reset();

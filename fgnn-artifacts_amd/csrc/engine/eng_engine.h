@@ -82,7 +82,7 @@ class Engine {
   void Init();  // samgraph_init (arch1) / samgraph_data_init (arch5)
   void SampleInit(int worker_id, Context ctx);
   void TrainInit(int worker_id, Context ctx, DistType type);
-  void Start() {}
+  void Start();  // samgraph_start: background sampler + extractor threads (arch2-4); nothing to do in arch1 / arch5
   void Shutdown();
   void RunSampleOnce();
   void StartExtract(int count);
@@ -105,6 +105,10 @@ class Engine {
   // arch1
   void InitArch1();
   void SampleOnceArch1();
+  // arch2 / arch3 / arch4: sampler and extractor in ONE process (cuda_loops_arch{2,3,4}.cc), the arch5 halves
+  // joined by an in-process queue
+  void InitInProcess();
+  void CreateQueue();
   // arch5 sampler
   void PreSample();
   void BuildCacheTable();
@@ -118,8 +122,10 @@ class Engine {
   bool initialized_ = false, data_initialized_ = false;
   size_t num_step_ = 0;
   DistType dist_type_ = DistType::Default;
-  int device_ = -1;
+  int device_ = -1;             // sampler-side device (arch1: the only one)
   hipStream_t stream_ = nullptr;
+  int tdevice_ = -1;            // trainer-side device (arch5 trainer process, arch2-4 extractor)
+  hipStream_t tstream_ = nullptr;
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
@@ -156,7 +162,7 @@ class Engine {
   // arch5 shared state (created before fork)
   MemoryQueue *mq_ = nullptr;
   pthread_barrier_t *sampler_barrier_ = nullptr;
-  std::thread extract_thread_;
+  std::thread extract_thread_, sample_thread_;
   std::atomic<bool> shutdown_{false};
   std::atomic<size_t> outer_counter_{0};
 };

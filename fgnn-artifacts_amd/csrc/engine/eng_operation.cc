@@ -25,7 +25,7 @@ void samgraph_config(const char **config_keys, const char **config_values, const
 
 void samgraph_init(void) {
   SAM_CHECK(RC().is_configured);
-  SAM_CHECK_EQ(RC().run_arch, (int)kArch1) << "samgraph_init is the single-process entry (arch1) ";
+  SAM_CHECK(RC().run_arch >= kArch1 && RC().run_arch <= kArch4) << "samgraph_init is the single-process entry (arch1-4)";
   Engine::Get().Init();
 }
 

@@ -10,8 +10,10 @@
  * fallback: a sampler/trainer context that is not "cuda:N" aborts.
  *
  * Supported run architectures (RunArch, common.h:70-79): arch1 (one GPU samples and extracts,
- * cuda/cuda_loops_arch1.cc) and arch5 (FGNN: sampler processes + trainer processes linked by the
- * pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc).  Sample types: all seven (khop0,
+ * cuda/cuda_loops_arch1.cc), arch2 / arch3 / arch4 (one process, sampler context + trainer context, optional
+ * background threads via samgraph_start; arch3 is the default of the reference's single-process scripts;
+ * cuda/cuda_loops_arch{2,3,4}.cc -- without arch4's dynamic-cache prototype) and arch5 (FGNN: sampler processes +
+ * trainer processes linked by the pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc).  Sample types: all seven (khop0,
  * khop1, khop2, weighted_khop, weighted_khop_hash_dedup, weighted_khop_prefix, random_walk).  Cache policies: pre_sample (computed at sample_init,
  * dist/pre_sampler.cc) and the file-backed rankings (cache_by_*.bin, engine.cc:216-256).
  */

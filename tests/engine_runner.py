@@ -157,6 +157,33 @@ def run_arch1(sample_type, workdir):
     print("arch1 %s ok: %d batches" % (sample_type, n))
 
 
+def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
+    """arch2 / arch3 / arch4: one process samples and extracts (the reference's default single-process scripts use
+    arch3); `threaded` = samgraph_start's background threads instead of sample_once per step."""
+    path = dataset(workdir, sample_type)
+    import samgraph.torch as sam
+    cfg = base_config(path, {"arch2": sam.kArch2, "arch3": sam.kArch3, "arch4": sam.kArch4}[arch], sample_type)
+    cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0", cache_percentage=cache_pct)
+    sam.config(cfg)
+    sam.init()
+    rep = OracleReplay(path, sample_type, 0, 1, cache_pct > 0)
+    assert sam.steps_per_epoch() == rep.num_step and sam.num_epoch() == NUM_EPOCH
+    if threaded:
+        sam.start()
+    n = 0
+    for key, seeds, task in rep.epochs():
+        if not threaded:
+            sam.sample_once()
+        got = sam.get_next_batch()
+        assert got == key, (got, key)
+        check_batch(sam, key, seeds, task, rep, "%s key %d" % (arch, key))
+        n += 1
+    assert n == NUM_EPOCH * rep.num_step
+    sam.report_step_average(NUM_EPOCH - 1, rep.num_step - 1)
+    sam.shutdown()
+    print("%s %s cache %.2f %s ok: %d batches" % (arch, sample_type, cache_pct, "threads" if threaded else "inline", n))
+
+
 def _sampler_proc(worker, num_sampler, barrier, err):
     try:
         import samgraph.torch as sam
@@ -326,6 +353,8 @@ if __name__ == "__main__":
         run_arch1(st, wd)
     elif mode == "switcher":
         run_arch5_switcher(st, wd)
+    elif mode in ("arch2", "arch3", "arch4"):
+        run_inproc(mode, st, wd, float(sys.argv[4]), sys.argv[5] == "threads")
     else:
         run_arch5(st, wd, int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]),
                   pipeline=(len(sys.argv) < 8 or sys.argv[7] == "pipeline"))

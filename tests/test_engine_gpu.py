@@ -24,6 +24,18 @@ def test_arch1_single_gpu(tmp_path, sample_type):
     assert "ok" in _run(tmp_path, "arch1", sample_type)
 
 
+@pytest.mark.parametrize("arch,sample_type,cache,mode", [
+    ("arch3", "khop2", 0.25, "inline"),      # the reference's default for its single-process scripts (common_config.py:48)
+    ("arch3", "khop2", 0.25, "threads"),     # samgraph_start: sampler thread + copy/extract thread
+    ("arch3", "random_walk", 0.0, "threads"),
+    ("arch2", "khop0", 0.0, "inline"),
+    ("arch4", "weighted_khop_prefix", 0.3, "threads"),
+])
+def test_single_process_two_role_archs(tmp_path, arch, sample_type, cache, mode):
+    """arch2/3/4: sampler + copy/extract in one process (cuda_loops_arch{2,3,4}.cc), both contexts on cuda:0 here."""
+    assert "ok" in _run(tmp_path, arch, sample_type, cache, mode)
+
+
 @pytest.mark.parametrize("sample_type,ns,nt,cache,mode", [
     ("khop2", 1, 1, 0.25, "pipeline"),       # BASELINE config 3 in miniature: 1S + 1T, presample cache
     ("khop2", 1, 1, 0.0, "inline"),          # no cache: input nodes shipped, all rows fetched from host memory
@@ -45,12 +57,14 @@ def test_arch5_switcher(tmp_path, sample_type):
     assert "ok" in _run(tmp_path, "switcher", sample_type)
 
 
-def test_training_example_runs(tmp_path):
-    """examples/train_graphsage.py = the reference's single-GPU script shape (config -> init -> sample_once ->
-    get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's test_result lines."""
+@pytest.mark.parametrize("extra", [[], ["--arch", "arch3", "--cache-percentage", "0.2", "--pipeline"]])
+def test_training_example_runs(tmp_path, extra):
+    """examples/train_graphsage.py = the reference's single-process script shape (config -> init -> [start] ->
+    sample_once -> get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's
+    test_result lines.  Second case: the reference's default arch3 with its background threads."""
     ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_graphsage.py")
     p = subprocess.run([sys.executable, ex, "--make-dataset", "small", "--dataset-path", str(tmp_path / "small"),
-                        "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"],
+                        "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"] + extra,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch=" in p.stdout

@@ -70,7 +70,7 @@ def test_config_parse(eng):
     assert _probe(eng, rw)[1][:2] == [3, 5]
 
 
-@pytest.mark.parametrize("bad", [dict(drop="batch_size"), dict(_arch=6), dict(_sample_type=7), dict(drop="fanout"),
+@pytest.mark.parametrize("bad", [dict(drop="batch_size"), dict(_arch=6), dict(_arch=0), dict(_sample_type=7), dict(drop="fanout"),
                                  dict(_arch=1), dict(_sample_type=6, fanout="60 5")])
 def test_config_errors_abort(bad):
     """No return codes: a violated check prints file:line and abort()s (logging.h:32-45)."""
