@@ -413,13 +413,18 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    run_region(0, args.warmup, False)
+    # set-up, not warm-up: a few batches so that code objects are loaded, occupancy queries cached and every buffer
+    # touched once even when the caller asks for a very short warm-up (sequence numbers stay consecutive)
+    prime = max(0, 12 - args.warmup)
+    run_region(0, prime, False)
+    torch.cuda.synchronize()
+    run_region(prime, prime + args.warmup, False)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     host_busy = [0.0] * NT
     t0 = time.perf_counter()
-    run_region(args.warmup, args.warmup + args.steps, True)
+    run_region(prime + args.warmup, prime + args.warmup + args.steps, True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -429,7 +434,7 @@ def main():
     # the same kernel with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency
     # from the slowdown it accepts when it shares the chip with the next batch's sampling chain
     serial = None
-    next_seq = args.warmup + args.steps  # sequence numbers must stay consecutive
+    next_seq = prime + args.warmup + args.steps  # sequence numbers must stay consecutive
     metas_t, gather_t = list(metas), list(gather_ms)
     # the sampler-side stage alone (what the reference's kLogEpochSampleTotalTime covers: shuffle slice + sample +
     # dedup + remap + cache-index split, dist_loops_arch5.cc:98-105), same overlap, no feature gather
