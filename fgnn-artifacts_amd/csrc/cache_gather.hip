@@ -303,7 +303,7 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
   uint32_t *sums = slot + cap;
   uint32_t *total = sums + nb;
   if (scan) {
-    // single-pass path: grid resident at once (ticketless look-back), a chunk at most 32 rounds
+    // single-pass path: grid resident at once (prefix over the lower-numbered workgroups), a chunk at most 32 rounds
     static int per_cu = -1;
     if (per_cu < 0 &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cache_split_fused_kernel, kBlock, 0) != hipSuccess)
@@ -318,7 +318,7 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
       if (const char *e_g = getenv("FGNN_SPLIT_GRID")) grid = (size_t)atoi(e_g) < grid ? (size_t)atoi(e_g) : grid;
       hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid), dim3(kBlock), 0, s, table, nodes, num_nodes,
                          d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
-                         scan->next(true, 2), ablate);
+                         scan->next(2), ablate);
       return launch_status(__func__);
     }
   }

@@ -476,7 +476,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items);
   if (!scan) scan = ht->scan;
   if (scan) {
-    // single-pass path: the grid must be resident at once (ticketless look-back) and a chunk at most 32 rounds
+    // single-pass path: the grid must be resident at once (prefix over the lower-numbered workgroups) and a chunk at most 32 rounds
     static int per_cu = -1;
     if (per_cu < 0 &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_count_assign_kernel, kBlock, 0) != hipSuccess)
@@ -488,7 +488,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(true, 1), final_fill && mapped != nullptr);
+                         scan->next(1), final_fill && mapped != nullptr);
       if (mapped)
         hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
                            mapped);

@@ -117,11 +117,11 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
       fuse.d_num_items[1] = fuse.d_num_items[0];
     }
   }
-  // single-pass mode (scan.desc != null): the workgroup's position in the seed list is an ordered ticket and the
-  // output offset comes from a look-back over the earlier workgroups' edge counts -- no count kernel, no scan kernel
+  // single-pass mode (scan.desc != null): the output offset comes from the prefix over the earlier workgroups'
+  // edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
   __shared__ uint32_t sh_tile;
-  const uint32_t tile = single_pass ? scan_take_tile(scan, &sh_tile) : blockIdx.x;
+  const uint32_t tile = blockIdx.x;
   const size_t first = (size_t)tile * S;
   const uint32_t last_tile = n ? (uint32_t)((n - 1) / S) : 0u;  // tiles beyond it have no seeds and nobody waits for them
   if (tile > last_tile) return;  // whole workgroup exits together
@@ -393,7 +393,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     return FGNN_ENOSPC;
   }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
-  ScanWs scan{nullptr, nullptr, nullptr, 0, 0, nullptr};
+  ScanWs scan{nullptr, nullptr, 0, 0, nullptr};
   bool want_scan = scan_host && nb <= scan_host->ws.max_tiles;
 
 #define FGNN_LAUNCH_KHOP2(SS, FM)                                                                              \
@@ -407,7 +407,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     /* single pass (no count kernel, no scan kernel) for grids of up to 1536 workgroups: a workgroup waits only   */ \
     /* for lower-numbered workgroups of its own launch, which each XCD dispatches before it, and 1536 workgroups   */ \
     /* (192 per XCD) cannot fill an XCD with waiters, so the lowest unfinished tile always gets a slot             */ \
-    if (want_scan && nb <= 1536) scan = scan_host->next(true);                                                 \
+    if (want_scan && nb <= 1536) scan = scan_host->next();                                                 \
     if (!scan.desc) {                                                                                          \
       scan.log = phase_log_base();                                                                             \
       hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,   \
