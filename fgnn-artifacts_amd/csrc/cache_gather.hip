@@ -183,7 +183,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
                                                                const chunk16 *__restrict__ src,
                                                                const uint32_t *__restrict__ src_index,
                                                                const uint32_t *__restrict__ dst_index, size_t n_host,
-                                                               const uint32_t *d_n, size_t cap, uint32_t cpr_rt) {
+                                                               const uint32_t *d_n, size_t cap, uint32_t cpr_rt,
+                                                               uint32_t src_mask) {
   const uint32_t cpr = CPR ? (uint32_t)CPR : cpr_rt;
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);
   const uint32_t total = n * cpr;  // host guarantees cap * cpr < 2^32
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
       const uint32_t cc = tile0 + u * kBlock + threadIdx.x;
       const uint32_t row = cc / cpr;
       const uint32_t col = cc - row * cpr;
-      const size_t srow = src_index ? src_index[row] : row;
+      const size_t srow = (src_index ? src_index[row] : row) & src_mask;
       const size_t drow = dst_index ? dst_index[row] : row;
       const chunk16 *sp = src + srow * cpr + col;
       if (NT) {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
       if (cc < total) {
         const uint32_t row = cc / cpr;
         const uint32_t col = cc - row * cpr;
-        const size_t srow = src_index ? src_index[row] : row;
+        const size_t srow = (src_index ? src_index[row] : row) & src_mask;
         const size_t drow = dst_index ? dst_index[row] : row;
         out[drow * cpr + col] = src[srow * cpr + col];
       }
@@ -246,14 +247,14 @@ __global__ __launch_bounds__(kBlock) void gather_rows_elem_kernel(T *__restrict_
                                                                   const uint32_t *__restrict__ src_index,
                                                                   const uint32_t *__restrict__ dst_index,
                                                                   size_t n_host, const uint32_t *d_n, size_t cap,
-                                                                  size_t dim) {
+                                                                  size_t dim, uint32_t src_mask) {
   const size_t n = resolve_count(n_host, d_n, cap);
   const size_t total = n * dim;
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
     const size_t row = e / dim;
     const size_t col = e - row * dim;
-    const size_t srow = src_index ? src_index[row] : row;
+    const size_t srow = (src_index ? src_index[row] : row) & src_mask;
     const size_t drow = dst_index ? dst_index[row] : row;
     out[drow * dim + col] = src[srow * dim + col];
   }
@@ -342,6 +343,12 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
 
 extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
                                 size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, void *stream) {
+  return fgnn_gather_rows_masked(out, src, src_index, dst_index, n, d_n, n_cap, dim, dtype, 0xFFFFFFFFu, stream);
+}
+
+extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_index,
+                                       const uint32_t *dst_index, size_t n, const uint32_t *d_n, size_t n_cap,
+                                       size_t dim, int dtype, uint32_t src_row_mask, void *stream) {
   auto s = static_cast<hipStream_t>(stream);
   const size_t esz = dtype_bytes(dtype);
   size_t cap = d_n ? n_cap : n;
@@ -372,10 +379,10 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
     if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;                                                      \
     if (nts) hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, true>), dim3(blocks), dim3(kBlock), 0, s,          \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
-                       d_n, cap, cpr);                                                                           \
+                       d_n, cap, cpr, src_row_mask);                                                             \
     else hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, false>), dim3(blocks), dim3(kBlock), 0, s,             \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
-                       d_n, cap, cpr);                                                                           \
+                       d_n, cap, cpr, src_row_mask);                                                             \
   } while (0)
 #define FGNN_GATHER2(U, C) do { if (nt) FGNN_GATHER3(U, C, true); else FGNN_GATHER3(U, C, false); } while (0)
 #define FGNN_GATHER(U)                                  \
@@ -397,7 +404,7 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
     if (blocks > 256 * 16) blocks = 256 * 16;
 #define FGNN_ELEM(T)                                                                                              \
   hipLaunchKernelGGL((gather_rows_elem_kernel<T>), dim3(blocks), dim3(kBlock), 0, s, static_cast<T *>(out),       \
-                     static_cast<const T *>(src), src_index, dst_index, n, d_n, cap, dim)
+                     static_cast<const T *>(src), src_index, dst_index, n, d_n, cap, dim, src_row_mask)
     switch (esz) {
       case 1: FGNN_ELEM(uint8_t); break;
       case 2: FGNN_ELEM(uint16_t); break;

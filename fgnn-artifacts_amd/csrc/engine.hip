@@ -63,6 +63,7 @@ struct fgnn_batch {
   hipEvent_t t0, t1;                      // optional: bracket the feature gather (fgnn_batch_enable_timing)
   bool timing, timed;
   fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
+  uint32_t feat_row_mask;                 // SAMGRAPH_EMPTY_FEAT mock extraction (all ones = off)
 };
 
 namespace fgnn {
@@ -217,6 +218,7 @@ extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim,
   b->feat_dim = feat_dim;
   b->feat_dtype = feat_dtype;
   b->label_dtype = label_dtype;
+  b->feat_row_mask = 0xFFFFFFFFu;
   b->feat_rows_cap = feat_rows_cap ? feat_rows_cap : s->max_nodes;
   if (b->feat_rows_cap > s->max_nodes) b->feat_rows_cap = s->max_nodes;
   bool ok = true;
@@ -435,14 +437,20 @@ extern "C" float fgnn_batch_gather_ms(fgnn_batch *b) {
   return ms;
 }
 
+extern "C" int fgnn_batch_set_feat_row_mask(fgnn_batch *b, uint32_t mask) {
+  if (!b) return FGNN_EINVAL;
+  b->feat_row_mask = mask;
+  return FGNN_OK;
+}
+
 extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream) {
   if (!b || !b->feat_dim) return FGNN_EINVAL;
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
   if (feat) {
     if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
-    rc = fgnn_gather_rows(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
-                          b->feat_dim, b->feat_dtype, stream);
+    rc = fgnn_gather_rows_masked(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
+                                 b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
     if (b->timing) {
       FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
       b->timed = true;
@@ -459,8 +467,8 @@ extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, 
   if (!b || !b->feat_dim) return FGNN_EINVAL;
   int rc = FGNN_OK;
   if (full_feat)  // CombineMissData with the row fetch fused in
-    rc = fgnn_gather_rows(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss, b->feat_rows_cap,
-                          b->feat_dim, b->feat_dtype, stream);
+    rc = fgnn_gather_rows_masked(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss,
+                                 b->feat_rows_cap, b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
   if (rc == FGNN_OK && cache_rows)  // CombineCacheData
     rc = fgnn_gather_rows(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,
                           b->feat_dim, b->feat_dtype, stream);

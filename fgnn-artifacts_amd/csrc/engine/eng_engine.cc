@@ -200,6 +200,7 @@ void Engine::InitArch1() {
     int err = 0;
     s.fb = fgnn_batch_create(sampler_, ds_.feat_dim, FGNN_F32, FGNN_I64, 0, &err);
     SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    SAM_FGNN(fgnn_batch_set_feat_row_mask(s.fb, FeatRowMask()));
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
@@ -520,8 +521,8 @@ void Engine::BuildTrainerCache() {
     uint32_t *d_rank = nullptr;
     SAM_HIP(hipMalloc(&d_rank, num_cached_ * sizeof(uint32_t)));
     SAM_HIP(hipMemcpy(d_rank, ds_.ranking_nodes, num_cached_ * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SAM_FGNN(fgnn_gather_rows(d_cache_rows_, dev_host_feat_, d_rank, nullptr, num_cached_, nullptr, num_cached_,
-                              ds_.feat_dim, FGNN_F32, tstream_));
+    SAM_FGNN(fgnn_gather_rows_masked(d_cache_rows_, dev_host_feat_, d_rank, nullptr, num_cached_, nullptr, num_cached_,
+                                     ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
     SAM_HIP(hipStreamSynchronize(tstream_));
     (void)hipFree(d_rank);
   }
@@ -606,8 +607,8 @@ void Engine::TrainerOnce() {
   b->feat_rows = hdr.input_size;
   size_t miss_rows = num_miss;
   if (!use_cache) {
-    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
-                              ds_.feat_dim, FGNN_F32, tstream_));
+    SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
+                                     ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
     miss_rows = hdr.input_size;
   } else if (dist_type_ == DistType::Switch) {
     // own (smaller) cache: split on this GPU with device-side counts
@@ -620,13 +621,14 @@ void Engine::TrainerOnce() {
     uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
     SAM_FGNN(fgnn_get_miss_cache_index(d_cache_table_, d_input, n, nullptr, n, idx[0], idx[1], idx[2], idx[3], d_counts,
                                        ws, ws_bytes, tstream_));
-    SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32, tstream_));
+    SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32,
+                                     FeatRowMask(), tstream_));
     SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
                               tstream_));
   } else {
     if (num_miss)   // CombineMissData with the host fetch fused in
-      SAM_FGNN(fgnn_gather_rows(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss, ds_.feat_dim,
-                                FGNN_F32, tstream_));
+      SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss,
+                                       ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
     if (num_cache)  // CombineCacheData
       SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, d_cidx[2], d_cidx[3], num_cache, nullptr, num_cache,
                                 ds_.feat_dim, FGNN_F32, tstream_));

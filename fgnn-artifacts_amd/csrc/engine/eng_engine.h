@@ -96,6 +96,11 @@ class Engine {
   uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_step_ + step; }
   Dataset &Data() { return ds_; }
   void ForwardBarrier() { outer_counter_++; }
+  // SAMGRAPH_EMPTY_FEAT=k: the feature table holds 2^k rows, node ids are masked before indexing it (the reference's
+  // mock extraction, cpu_extraction.cc:47-62)
+  uint32_t FeatRowMask() const {
+    return RC().option_empty_feat ? (uint32_t)((1ull << RC().option_empty_feat) - 1) : 0xFFFFFFFFu;
+  }
 
  private:
   // shared

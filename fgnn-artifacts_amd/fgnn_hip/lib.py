@@ -27,7 +27,7 @@ EXPORTS = [
     "fgnn_hashtable_create", "fgnn_hashtable_create_ex", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
-    "fgnn_get_miss_cache_index", "fgnn_gather_rows",
+    "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_batch_set_feat_row_mask",
 ]
 
 _lib = None
@@ -277,8 +277,8 @@ def get_miss_cache_index(table, nodes, num_nodes=None, d_num_nodes=None, ws=None
     return outs[0], outs[1], outs[2], outs[3], d_counts
 
 
-def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
-    """out[dst_index[i] or i] = src[src_index[i] or i]; rows are the trailing dims."""
+def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_row_mask=None):
+    """out[dst_index[i] or i] = src[(src_index[i] or i) & src_row_mask]; rows are the trailing dims."""
     _need_gpu(out)
     if n is None:
         n = (src_index if src_index is not None else dst_index if dst_index is not None else src).shape[0]
@@ -286,6 +286,11 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None):
     for s in out.shape[1:]:
         dim *= s
     assert out.dtype == src.dtype and out.is_contiguous() and src.is_contiguous()
+    if src_row_mask is not None:
+        _check(load().fgnn_gather_rows_masked(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), C.c_size_t(n),
+                                              _ptr(d_n), C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]),
+                                              C.c_uint32(src_row_mask), _stream()), "fgnn_gather_rows_masked")
+        return out
     _check(load().fgnn_gather_rows(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), C.c_size_t(n), _ptr(d_n),
                                    C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]), _stream()),
            "fgnn_gather_rows")

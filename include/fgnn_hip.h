@@ -182,6 +182,11 @@ int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size
  * src may be device memory or host memory registered/allocated as device-accessible. */
 int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
                      size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, void *stream);
+/* Same with the SOURCE row index ANDed with src_row_mask: the reference's mock extraction for feature tables that hold
+ * only 2^k rows (SAMGRAPH_EMPTY_FEAT=k; cpu_extraction.cc:47-62, cuda_extraction.cu mock variants). */
+int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
+                            size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
+                            void *stream);
 
 /* ---- batch driver -------------------------------------------------------------------------
  * One object per sampler GPU that enqueues a whole mini-batch without a single host round trip:
@@ -257,6 +262,9 @@ int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seed
 int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream);
 /* DoGPUFeatureExtract: feat_out[i,:] = feat[input_nodes[i],:], label_out[i] = label[output_nodes[i]].
  * Either source may be NULL to skip it. */
+/* Feature tables with 2^k rows (SAMGRAPH_EMPTY_FEAT): node ids are ANDed with `mask` before indexing the feature
+ * source in fgnn_batch_extract / fgnn_batch_extract_cached (labels are not masked).  Default 0xFFFFFFFF. */
+int fgnn_batch_set_feat_row_mask(fgnn_batch *b, uint32_t mask);
 int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream);
 /* Trainer-side DoCacheFeatureCopy (dist_loops.cc:713-846) with the miss rows gathered by the GPU:
  * feat_out[cache_dst] = cache_rows[cache_src]; feat_out[miss_dst] = full_feat[miss_src] where

@@ -123,7 +123,10 @@ def check_batch(sam, key, seeds, task, rep, what=""):
         np.testing.assert_array_equal(u32(blocks[li].col), g["col"], err_msg=what)
         if g["data"] is not None:
             np.testing.assert_array_equal(u32(blocks[li].edata["weights"]), g["data"], err_msg=what)
-    assert feat.cpu().numpy().tobytes() == rep.feat[task["input_nodes"]].tobytes(), what + " feat"
+    if os.environ.get("SAMGRAPH_EMPTY_FEAT", "0") in ("", "0"):
+        assert feat.cpu().numpy().tobytes() == rep.feat[task["input_nodes"]].tobytes(), what + " feat"
+    else:  # mock extraction from an uninitialised 2^k-row table: only the shape is defined
+        assert tuple(feat.shape) == (len(task["input_nodes"]), DIM), what + " feat shape"
     np.testing.assert_array_equal(label.cpu().numpy(), rep.label[seeds], err_msg=what)
     np.testing.assert_array_equal(u32(sam.get_graph_output_nodes(key)), seeds, err_msg=what)
     inp = sam.get_graph_input_nodes(key)

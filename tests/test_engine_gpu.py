@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner.py")
 
 
-def _run(tmp_path, *args):
+def _run(tmp_path, *args, env=None):
     p = subprocess.run([sys.executable, RUNNER, args[0], args[1], str(tmp_path)] + [str(a) for a in args[2:]],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     return p.stdout
 
@@ -22,6 +22,14 @@ def _run(tmp_path, *args):
 def test_arch1_single_gpu(tmp_path, sample_type):
     """BASELINE config 2 in miniature: one GPU samples and extracts (cuda_loops_arch1.cc:44-80)."""
     assert "ok" in _run(tmp_path, "arch1", sample_type)
+
+
+@pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch3", ["khop2", 0.25, "inline"]),
+                                       ("arch5", ["khop2", 1, 1, 0.25, "pipeline"])])
+def test_empty_feat_mock_extraction(tmp_path, mode, args):
+    """SAMGRAPH_EMPTY_FEAT=k (set by the reference's scripts for the *_empty datasets): feat.bin is not read, the
+    table has 2^k rows and every feature gather masks the node id -- no out-of-range row is ever touched."""
+    assert "ok" in _run(tmp_path, mode, *args, env={"SAMGRAPH_EMPTY_FEAT": "9"})
 
 
 @pytest.mark.parametrize("arch,sample_type,cache,mode", [

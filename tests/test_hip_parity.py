@@ -546,3 +546,17 @@ def test_hash_dedup_large_frontier_two_pass(hip, oracle):
     assert ne == len(o_dst) > 1_000_000
     np.testing.assert_array_equal(host_u32(src, ne), o_src)
     np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [128, 7])
+def test_masked_gather_is_the_reference_mock_extraction(hip, oracle, dim):
+    """SAMGRAPH_EMPTY_FEAT=k: the feature table holds 2^k rows and node ids are ANDed with 2^k - 1 before indexing it
+    (cpu_extraction.cc:47-62); both gather kernels (16-byte chunks, element-wise)."""
+    rs = np.random.default_rng(21)
+    k = 10
+    src = rs.standard_normal((1 << k, dim)).astype(np.float32)
+    idx = rs.integers(0, 1 << 30, size=5003).astype(np.uint32)
+    out = torch.empty((len(idx), dim), dtype=torch.float32, device="cuda")
+    hip.gather_rows(out, dev(src), src_index=dev(idx), src_row_mask=(1 << k) - 1)
+    assert out.cpu().numpy().tobytes() == src[idx & ((1 << k) - 1)].tobytes()
