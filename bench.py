@@ -195,7 +195,13 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="kh
     runs = [("omp%d" % t, t) for t in cands] + [("single", 1)]
     budget_s = budget_s / len(runs)
     max_edges = max(bs * int(np.prod([f + 1 for f in fan[i + 1:]])) * fan[i] for i in range(len(fan)))
-    ref = oracle.RefBaseline(num_node, max_edges, cap, 1) if use_ref else None
+    ref = None
+    if use_ref:
+        try:
+            ref = oracle.RefBaseline(num_node, max_edges, cap, 1)
+        except (OSError, MemoryError, RuntimeError) as e:  # built for another libc / not loadable here: time the port
+            print("cpu_baseline: oracle/_ref not usable (%s), timing the oracle's restatement instead" % e, file=sys.stderr)
+            use_ref = False
     for label, T in runs:
         if use_ref:
             ref.set_threads(T)
