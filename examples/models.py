@@ -3,13 +3,25 @@ with DGL installed `get_dgl_blocks` returns DGLBlocks and the dgl.nn layers work
 
 Block convention (samgraph/torch/adapter.py): row[e] = local id of the sampled neighbour (source), col[e] = local id
 of the seed (destination); the first number_of_dst_nodes() source nodes are the destination nodes themselves."""
+import os
+
 import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+try:  # fused gather + segment-sum kernel of this repo (fgnn_hip/nn.py); FGNN_TORCH_AGGREGATE=1 forces the torch ops
+    from fgnn_hip.nn import block_aggregate as _fused_aggregate
+except ImportError:
+    _fused_aggregate = None
+if os.environ.get("FGNN_TORCH_AGGREGATE"):
+    _fused_aggregate = None
+
 
 def _sum_to_dst(block, h, weight=None):
     num_dst = block.number_of_dst_nodes()
+    if (_fused_aggregate is not None and h.is_cuda and h.dtype == th.float32 and getattr(block.row, "dtype", None) == th.int32
+            and block.col.dtype == th.int32):
+        return _fused_aggregate(h, block.row, block.col, num_dst, weight)
     row, col = block.row.long(), block.col.long()
     msg = h[row] if weight is None else h[row] * weight.unsqueeze(1)
     return th.zeros((num_dst, h.shape[1]), dtype=h.dtype, device=h.device).index_add_(0, col, msg)

@@ -27,7 +27,7 @@ EXPORTS = [
     "fgnn_hashtable_create", "fgnn_hashtable_create_ex", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
-    "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_batch_set_feat_row_mask",
+    "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
 ]
 
 _lib = None

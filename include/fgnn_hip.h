@@ -188,6 +188,15 @@ int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_inde
                             size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
                             void *stream);
 
+/* ---- neighbourhood aggregation over a sampled block (consumer side of the path) ----------- */
+
+/* out[dst_index[e], :] += edge_weight[e] * h[src_index[e], :]  for e < num_edge (edge_weight NULL = 1), fp32.
+ * `out` must be initialised by the caller (zeros for a plain aggregation).  Forward of the mean / sum / weighted
+ * aggregators: src_index = block row (neighbour), dst_index = block col (seed); backward: the two swapped with
+ * h = grad_out.  Fastest when equal dst_index values are contiguous (the samplers' seed-major edge order). */
+int fgnn_block_aggregate(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
+                         size_t num_edge, const float *h, size_t dim, float *out, void *stream);
+
 /* ---- batch driver -------------------------------------------------------------------------
  * One object per sampler GPU that enqueues a whole mini-batch without a single host round trip:
  * DoGPUSample (cuda_loops.cc:50-267 == dist/dist_loops.cc:51-269), DoGetCacheMissIndex

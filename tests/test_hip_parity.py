@@ -560,3 +560,34 @@ def test_masked_gather_is_the_reference_mock_extraction(hip, oracle, dim):
     out = torch.empty((len(idx), dim), dtype=torch.float32, device="cuda")
     hip.gather_rows(out, dev(src), src_index=dev(idx), src_row_mask=(1 << k) - 1)
     assert out.cpu().numpy().tobytes() == src[idx & ((1 << k) - 1)].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,weighted,sorted_col", [(128, False, True), (256, True, True), (100, False, True),
+                                                    (7, True, False), (64, False, False)])
+def test_block_aggregate_matches_torch_reference(hip, dim, weighted, sorted_col):
+    """fgnn_block_aggregate (fp32, atomics at segment boundaries) against the plain PyTorch fp32 formulation
+    out.index_add_(0, col, w * h[row]) and its autograd gradient; tolerance rtol 1e-4 / atol 1e-4 (the order of the
+    float additions differs)."""
+    from fgnn_hip.nn import block_aggregate
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    E, nsrc, ndst = 60001, 20000, 3000
+    row = torch.randint(0, nsrc, (E,), device="cuda", generator=g, dtype=torch.int32)
+    col = torch.randint(0, ndst, (E,), device="cuda", generator=g, dtype=torch.int32)
+    if sorted_col:
+        col = torch.sort(col)[0]
+    w = torch.rand(E, device="cuda", generator=g) if weighted else None
+    h1 = torch.randn(nsrc, dim, device="cuda", generator=g, requires_grad=True)
+    h2 = h1.detach().clone().requires_grad_(True)
+    out = block_aggregate(h1, row, col, ndst, w)
+    msg = h2[row.long()] if w is None else h2[row.long()] * w.unsqueeze(1)
+    ref = torch.zeros((ndst, dim), device="cuda").index_add_(0, col.long(), msg)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    gout = torch.randn(ndst, dim, device="cuda", generator=g)
+    out.backward(gout)
+    ref.backward(gout)
+    torch.testing.assert_close(h1.grad, h2.grad, rtol=1e-4, atol=1e-4)
+    # empty block
+    e = torch.empty(0, dtype=torch.int32, device="cuda")
+    assert float(block_aggregate(h1.detach(), e, e, 5).abs().sum()) == 0.0

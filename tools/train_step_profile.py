@@ -10,6 +10,7 @@ from torch.profiler import ProfilerActivity, profile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "examples"))
+sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
 from models import SAGE  # noqa: E402
 
 
@@ -26,8 +27,8 @@ dev = "cuda:0"
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 # layer 0 (outer): 528 K src -> 88 K dst, 490 K edges ; layer 1: 88 K src -> 8000 dst, 80 K edges
-b0 = Block(torch.randint(0, 528000, (490000,), device=dev, generator=g), torch.sort(torch.randint(0, 88000, (490000,), device=dev, generator=g))[0], 528000, 88000)
-b1 = Block(torch.randint(0, 88000, (80000,), device=dev, generator=g), torch.sort(torch.randint(0, 8000, (80000,), device=dev, generator=g))[0], 88000, 8000)
+b0 = Block(torch.randint(0, 528000, (490000,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, 88000, (490000,), device=dev, generator=g, dtype=torch.int32))[0], 528000, 88000)
+b1 = Block(torch.randint(0, 88000, (80000,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, 8000, (80000,), device=dev, generator=g, dtype=torch.int32))[0], 88000, 8000)
 x = torch.randn(528000, 128, device=dev)
 y = torch.randint(0, 172, (8000,), device=dev)
 model = SAGE(128, 256, 172, 2, 0.5).to(dev)
