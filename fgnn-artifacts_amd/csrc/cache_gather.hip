@@ -360,8 +360,22 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
                    (reinterpret_cast<uintptr_t>(src) % 16 == 0) && row_bytes / 16 <= 0xffffffffull;
   if (vec) {
     const uint32_t cpr = (uint32_t)(row_bytes / 16);
+    if (cap * cpr >= 0xffffffffull) {
+      // the kernel indexes 16-byte chunks with 32 bits (64 GiB of rows per launch): larger host-sized gathers (e.g.
+      // filling a whole-table feature cache) go in slices; device-sized ones of that size are not supported
+      if (d_n || (!src_index && src_row_mask != 0xFFFFFFFFu)) return FGNN_EINVAL;
+      const size_t rows_per = (size_t(1) << 31) / cpr;
+      for (size_t r0 = 0; r0 < n; r0 += rows_per) {
+        const size_t m = n - r0 < rows_per ? n - r0 : rows_per;
+        const int rc = fgnn_gather_rows_masked(
+            dst_index ? out : static_cast<char *>(out) + r0 * row_bytes,
+            src_index ? src : static_cast<const char *>(src) + r0 * row_bytes, src_index ? src_index + r0 : nullptr,
+            dst_index ? dst_index + r0 : nullptr, m, nullptr, m, dim, dtype, src_row_mask, stream);
+        if (rc != FGNN_OK) return rc;
+      }
+      return FGNN_OK;
+    }
     const size_t total = cap * cpr;
-    if (total >= 0xffffffffull) return FGNN_EINVAL;  // 32-bit chunk index (64 GiB of rows per call)
     // tuning knobs (read per call: only used by profiles/ sweeps)
     const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
     const int unroll = e_u ? atoi(e_u) : 4;

@@ -117,3 +117,19 @@ def test_full_size_determinism(world):
         assert torch.equal(b1.input_nodes(), b2.input_nodes())
         for l in (0, 1):
             assert torch.equal(b1.graph(l)[0], b2.graph(l)[0]) and torch.equal(b1.graph(l)[1], b2.graph(l)[1])
+
+
+@pytest.mark.gpu
+def test_gather_larger_than_one_launch_is_sliced():
+    from fgnn_hip import lib as hip
+    """A host-sized gather of more than 2^32 16-byte chunks (a whole-table feature cache: 66 GiB of rows here) is cut
+    into several launches; rows are checked at both ends and around the slice boundary."""
+    dim = 256  # 64 chunks per row -> 2^25 rows per slice
+    n = (1 << 26) + 12345
+    src_rows = 1 << 10
+    src = torch.arange(src_rows * dim, dtype=torch.float32, device="cuda").reshape(src_rows, dim)
+    idx = (torch.arange(n, dtype=torch.int64, device="cuda") * 7919 % src_rows).to(torch.int32)
+    out = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    hip.gather_rows(out, src, src_index=idx)
+    for r in (0, 1, (1 << 25) - 1, 1 << 25, (1 << 25) + 1, (1 << 26) - 1, 1 << 26, n - 1):
+        assert torch.equal(out[r], src[int(idx[r])]), r

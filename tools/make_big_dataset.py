@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Writes a papers100M-/products-shaped synthetic dataset in the engine's on-disk layout WITHOUT feat.bin (run the
 engine with SAMGRAPH_EMPTY_FEAT=k, like the reference's papers100M_empty): the CSR comes from bench.py's GPU generator,
-so a 1.6 G-edge graph is written in about a minute.  usage: make_big_dataset.py <dir> [papers100M|products|twitter]"""
+so a 1.6 G-edge graph is written in seconds.
+usage: make_big_dataset.py <dir> [papers100M|products|twitter|uk-2006-05] [--prefix]   (--prefix: also
+prob_prefix_table.bin for the weighted_khop_prefix sampler)"""
 import os
 import sys
 
@@ -34,6 +36,12 @@ n_tr = w["num_train"]
 sets = {"train": perm[:n_tr], "valid": perm[n_tr:n_tr + 1000], "test": perm[n_tr + 1000:n_tr + 2000]}
 for k, v in sets.items():
     v.to(torch.int32).cpu().numpy().view(np.uint32).tofile(os.path.join(out, k + "_set.bin"))
+if "--prefix" in sys.argv:
+    pre = bench.gen_prefix_on_gpu(indptr, ne, 11, dev)
+    with open(os.path.join(out, "prob_prefix_table.bin"), "wb") as f:
+        for a in range(0, ne, chunk):
+            f.write(pre[a:a + chunk].cpu().numpy().tobytes())
+    del pre
 with open(os.path.join(out, "meta.txt"), "w") as f:
     f.write(f"NUM_NODE {w['num_node']}\nNUM_EDGE {ne}\nFEAT_DIM {w['feat_dim']}\nNUM_CLASS {w['num_class']}\n"
             f"NUM_TRAIN_SET {n_tr}\nNUM_VALID_SET 1000\nNUM_TEST_SET 1000\n")
