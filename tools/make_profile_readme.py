@@ -74,7 +74,7 @@ right after a 1 GB streaming write take 21 us: dirty lines in the Infinity Cache
 gather output uses non-temporal stores (whole step 0.228 -> 0.207 ms at the time) and why the dedup table is no longer
 wiped per batch (generation-tagged buckets).
 
-## 7. Other workloads (`r01_c_bench_twitter.json`, `r01_c_bench_uk.json`, two host threads; the serial kernel stats next to
+## 7. Other workloads (`r01_c_bench_twitter.json`, `r01_c_bench_uk.json`; the serial kernel stats next to
 them are from before the last optimisations)
 
 | workload | sampler | ms/step | sampled edges/s (whole path) | sampler-side stage edges/s | gather GB/s alone |
