@@ -6,6 +6,7 @@ and checks every batch bit-for-bit against the oracle.  Run as a subprocess by t
 
 usage: engine_runner.py <arch1|arch5> <sample_type> <workdir> [num_sampler] [num_trainer] [cache_pct]
 """
+import faulthandler
 import multiprocessing as mp
 import os
 import sys
@@ -189,6 +190,7 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
 
 def _sampler_proc(worker, num_sampler, barrier, err):
     try:
+        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         sam.sample_init(worker, "cuda:0")
         barrier.wait()
@@ -207,6 +209,7 @@ def _sampler_proc(worker, num_sampler, barrier, err):
 
 def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample, pipeline, barrier, err):
     try:
+        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         barrier.wait()  # samplers (and the presample) are done initialising
         sam.train_init(worker, "cuda:0")
@@ -259,12 +262,15 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     for p in procs:
         p.start()
     bad = 0
-    for p in procs:
-        p.join(timeout=300)
+    for i, p in enumerate(procs):
+        p.join(timeout=200)
         if p.is_alive():
+            print("process %d (%s) did not finish" % (i, "sampler" if i < num_sampler else "trainer"), file=sys.stderr)
             p.terminate()
             bad = 1
         elif p.exitcode != 0:
+            print("process %d (%s) exited with %s" % (i, "sampler" if i < num_sampler else "trainer", p.exitcode),
+                  file=sys.stderr)
             bad = 1
     if bad or err.value:
         sys.exit(1)
@@ -273,6 +279,7 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
 
 def _switch_sampler_proc(barrier, sem, stop, err):
     try:
+        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         sam.sample_init(0, "cuda:0")
         barrier.wait()
@@ -290,6 +297,7 @@ def _switch_sampler_proc(barrier, sem, stop, err):
 
 def _switch_consumer_proc(is_switcher, path, sample_type, barrier, sem, stop, seen_keys, err):
     try:
+        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         barrier.wait()
         if is_switcher:

@@ -12,7 +12,7 @@ RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner
 
 def _run(tmp_path, *args, env=None):
     p = subprocess.run([sys.executable, RUNNER, args[0], args[1], str(tmp_path)] + [str(a) for a in args[2:]],
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+                       capture_output=True, text=True, timeout=420, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     return p.stdout
 
