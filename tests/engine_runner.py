@@ -188,6 +188,32 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
     print("%s %s cache %.2f %s ok: %d batches" % (arch, sample_type, cache_pct, "threads" if threaded else "inline", n))
 
 
+def _join_all(procs, roles, limit=240.0):
+    """Waits for all children; as soon as one dies with an error (or the time is up) the rest are terminated, so a
+    failure is reported at once instead of after the survivors' time-outs."""
+    import time
+    t0 = time.time()
+    bad = 0
+    while any(p.is_alive() for p in procs):
+        for i, p in enumerate(procs):
+            if not p.is_alive() and p.exitcode not in (0, None):
+                bad = 1
+        if bad or time.time() - t0 > limit:
+            bad = 1
+            break
+        time.sleep(0.05)
+    for i, p in enumerate(procs):
+        if p.is_alive():
+            print("process %d (%s) did not finish" % (i, roles[i]), file=sys.stderr)
+            p.terminate()
+        elif p.exitcode != 0:
+            print("process %d (%s) exited with %s" % (i, roles[i], p.exitcode), file=sys.stderr)
+            bad = 1
+    for p in procs:
+        p.join(timeout=10)
+    return bad
+
+
 def _sampler_proc(worker, num_sampler, barrier, err):
     try:
         faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
@@ -261,17 +287,7 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
               for w in range(num_trainer)]
     for p in procs:
         p.start()
-    bad = 0
-    for i, p in enumerate(procs):
-        p.join(timeout=200)
-        if p.is_alive():
-            print("process %d (%s) did not finish" % (i, "sampler" if i < num_sampler else "trainer"), file=sys.stderr)
-            p.terminate()
-            bad = 1
-        elif p.exitcode != 0:
-            print("process %d (%s) exited with %s" % (i, "sampler" if i < num_sampler else "trainer", p.exitcode),
-                  file=sys.stderr)
-            bad = 1
+    bad = _join_all(procs, ["sampler"] * num_sampler + ["trainer"] * num_trainer)
     if bad or err.value:
         sys.exit(1)
     print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
@@ -344,14 +360,7 @@ def run_arch5_switcher(sample_type, workdir):
              ctx.Process(target=_switch_consumer_proc, args=(True, path, sample_type, barrier, sem, stop, seen, err))]
     for p in procs:
         p.start()
-    bad = 0
-    for p in procs:
-        p.join(timeout=300)
-        if p.is_alive():
-            p.terminate()
-            bad = 1
-        elif p.exitcode != 0:
-            bad = 1
+    bad = _join_all(procs, ["sampler", "trainer", "switcher"])
     if bad or err.value or list(seen) != [1] * total:
         print("seen", list(seen))
         sys.exit(1)
