@@ -17,6 +17,41 @@ if os.environ.get("FGNN_TORCH_AGGREGATE"):
     _fused_aggregate = None
 
 
+class _TallLinearFn(th.autograd.Function):
+    """y = x W^T + b for x with very many rows (10^5 nodes x 10^2 features).  The weight gradient gy^T x reduces over
+    the rows; the library GEMM picked for that shape is slow (0.26 ms for 88 K x 128 x 256 on MI355X), a batched GEMM
+    over 32 row slices followed by a sum takes 0.06 ms."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        y = x.mm(weight.t())
+        return y + bias if bias is not None else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy.mm(weight) if ctx.needs_input_grad[0] else None
+        m, s = x.shape[0], 32
+        mp = (m // s) * s
+        if mp >= 8192 and x.is_contiguous():
+            gw = th.bmm(gy[:mp].view(s, mp // s, -1).transpose(1, 2), x[:mp].view(s, mp // s, -1)).sum(0)
+            if mp < m:
+                gw = gw + gy[mp:].t().mm(x[mp:])
+        else:
+            gw = gy.t().mm(x)
+        gb = gy.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class TallLinear(nn.Linear):
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.dtype == th.float32:
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _sum_to_dst(block, h, weight=None):
     num_dst = block.number_of_dst_nodes()
     if (_fused_aggregate is not None and h.is_cuda and h.dtype == th.float32 and getattr(block.row, "dtype", None) == th.int32
@@ -39,8 +74,8 @@ class SAGEConvMean(nn.Module):
 
     def __init__(self, in_feats, out_feats):
         super().__init__()
-        self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
-        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=True)
+        self.fc_self = TallLinear(in_feats, out_feats, bias=False)
+        self.fc_neigh = TallLinear(in_feats, out_feats, bias=True)
 
     def forward(self, block, h):
         num_dst = block.number_of_dst_nodes()
@@ -54,7 +89,7 @@ class GraphConv(nn.Module):
 
     def __init__(self, in_feats, out_feats, activation=None):
         super().__init__()
-        self.fc = nn.Linear(in_feats, out_feats, bias=True)
+        self.fc = TallLinear(in_feats, out_feats, bias=True)
         self.activation = activation
 
     def forward(self, block, h):
@@ -73,8 +108,8 @@ class WeightedSAGEConv(nn.Module):
 
     def __init__(self, in_feats, hidden, out_feats, dropout):
         super().__init__()
-        self.Q = nn.Linear(in_feats, hidden)
-        self.W = nn.Linear(in_feats + hidden, out_feats)
+        self.Q = TallLinear(in_feats, hidden)
+        self.W = TallLinear(in_feats + hidden, out_feats)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, block, h):

@@ -637,3 +637,25 @@ def test_example_layers_same_with_fused_and_torch_aggregation(hip, layer):
         models._fused_aggregate = saved
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_tall_linear_matches_nn_linear():
+    """examples/models.py TallLinear (weight gradient as a batched GEMM over row slices) against nn.Linear, fp32,
+    rtol 1e-4."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import models
+    torch.manual_seed(1)
+    a, b = models.TallLinear(96, 40).cuda(), torch.nn.Linear(96, 40).cuda()
+    b.load_state_dict(a.state_dict())
+    x1 = torch.randn(20011, 96, device="cuda", requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(20011, 40, device="cuda")
+    a(x1).backward(g)
+    b(x2).backward(g)
+    torch.testing.assert_close(a(x1), b(x2), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
