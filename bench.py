@@ -41,7 +41,22 @@ WORKLOADS = {
                   fanout=[25, 10], batch_size=8000, sample_type="khop2"),
 }
 SAMPLE_TYPES = {"khop0": lib.KHOP0, "khop1": lib.KHOP1, "khop2": lib.KHOP2, "weighted_khop_prefix": lib.WEIGHTED_KHOP_PREFIX,
-                "random_walk": lib.RANDOM_WALK}
+                "random_walk": lib.RANDOM_WALK, "weighted_khop": lib.WEIGHTED_KHOP,
+                "weighted_khop_hash_dedup": lib.WEIGHTED_KHOP_HASH_DEDUP}
+
+
+def gen_alias_on_gpu(indices, total, seed, device):
+    """prob_table f32[E] / alias_table u32[E] (node ids) for the alias-method samplers: random acceptance
+    probabilities, alias = the row neighbour one position further (any node id is a valid table entry) -- same memory
+    behaviour as a real table; bit-exact parity with the oracle is covered by the tests, not by the bench."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    prob = torch.empty(total, dtype=torch.float32, device=device)
+    chunk = 1 << 27
+    for a in range(0, total, chunk):
+        prob[a:a + chunk] = torch.rand(min(chunk, total - a), generator=g, device=device)
+    alias = torch.roll(indices, 1)
+    return prob, alias
 
 
 def gen_prefix_on_gpu(indptr, total, seed, device):
@@ -353,9 +368,12 @@ def main():
     local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
     prefix = gen_prefix_on_gpu(indptr, num_edge, 11, dev) if args.sample_type == "weighted_khop_prefix" else None
+    prob_t = alias_t = None
+    if args.sample_type in ("weighted_khop", "weighted_khop_hash_dedup"):
+        prob_t, alias_t = gen_alias_on_gpu(indices, num_edge, 12, dev)
     sampler = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=SAMPLE_TYPES[args.sample_type], seed=args.seed,
                           prob_prefix=prefix, walk_len=w.get("walk_len", 3), num_walks=w.get("num_walks", 4),
-                          restart_prob=w.get("restart_prob", 0.5))
+                          restart_prob=w.get("restart_prob", 0.5), prob_table=prob_t, alias_table=alias_t)
     NT = 1 if args.no_overlap else args.host_threads
     SPT = 1 if args.no_overlap else max(1, args.streams_per_thread)
     NBUF = 2 * NT * SPT
