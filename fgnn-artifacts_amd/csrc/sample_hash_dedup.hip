@@ -18,7 +18,7 @@
 namespace fgnn {
 namespace {
 
-constexpr uint32_t kMaxScanTiles = 2048;  // all-predecessor prefix: O(tiles^2) descriptor loads
+constexpr uint32_t kMaxScanTiles = 1536;  // cap of every waiting grid (fgnn_device.h): 192 workgroups per XCD
 constexpr uint32_t kMaxFanout = 50;  // the reference's per-thread table has 50 slots (hash_dedup.cu:43,72)
 __host__ __device__ constexpr uint32_t max_attempts(uint32_t fanout) { return 64u * fanout; }
 
