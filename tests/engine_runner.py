@@ -188,7 +188,7 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
     print("%s %s cache %.2f %s ok: %d batches" % (arch, sample_type, cache_pct, "threads" if threaded else "inline", n))
 
 
-def _join_all(procs, roles, limit=240.0):
+def _join_all(procs, roles, limit=600.0):
     """Waits for all children; as soon as one dies with an error (or the time is up) the rest are terminated, so a
     failure is reported at once instead of after the survivors' time-outs."""
     import time
@@ -216,7 +216,7 @@ def _join_all(procs, roles, limit=240.0):
 
 def _sampler_proc(worker, num_sampler, barrier, err):
     try:
-        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
+        faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         sam.sample_init(worker, "cuda:0")
         barrier.wait()
@@ -235,7 +235,7 @@ def _sampler_proc(worker, num_sampler, barrier, err):
 
 def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample, pipeline, barrier, err):
     try:
-        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
+        faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         barrier.wait()  # samplers (and the presample) are done initialising
         sam.train_init(worker, "cuda:0")
@@ -295,7 +295,7 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
 
 def _switch_sampler_proc(barrier, sem, stop, err):
     try:
-        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
+        faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         sam.sample_init(0, "cuda:0")
         barrier.wait()
@@ -313,7 +313,7 @@ def _switch_sampler_proc(barrier, sem, stop, err):
 
 def _switch_consumer_proc(is_switcher, path, sample_type, barrier, sem, stop, seen_keys, err):
     try:
-        faulthandler.dump_traceback_later(150, exit=True)  # a stuck child shows where it is stuck
+        faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         barrier.wait()
         if is_switcher:

@@ -12,7 +12,7 @@ RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner
 
 def _run(tmp_path, *args, env=None):
     p = subprocess.run([sys.executable, RUNNER, args[0], args[1], str(tmp_path)] + [str(a) for a in args[2:]],
-                       capture_output=True, text=True, timeout=420, env=dict(os.environ, **(env or {})))
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     return p.stdout
 
@@ -73,7 +73,7 @@ def test_training_example_runs(tmp_path, extra):
     ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_graphsage.py")
     p = subprocess.run([sys.executable, ex, "--make-dataset", "small", "--dataset-path", str(tmp_path / "small"),
                         "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"] + extra,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch=" in p.stdout
 
@@ -90,6 +90,6 @@ def test_fgnn_training_example_runs(tmp_path, model, extra):
                       "train_fgnn.py")
     p = subprocess.run([sys.executable, ex, "--model", model, "--make-dataset", "small", "--dataset-path",
                         str(tmp_path / "small"), "--num-epoch", "2", "--batch-size", "2000", "--single-gpu"] + extra,
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:pipeline_train_epoch_time=" in p.stdout and "test_result:sample_time=" in p.stdout
