@@ -415,6 +415,15 @@ struct BatchStart {
   uint32_t num_layers;
   uint32_t layer;  // this launch's layer: its num_edge entry is written by the launch itself, not by the header init
 };
+// the three with-replacement samplers (khop1 / weighted_khop / weighted_khop_prefix by sample_type; table_f = prob or
+// prefix table) for callers that know the number of graph nodes and guarantee unique seeds: the seed order then comes
+// from a bitmap over the id space instead of a radix sort.  Scratch: weighted_scratch_bytes_ex.
+size_t weighted_scratch_bytes_ex(size_t num_input_cap, size_t fanout, size_t num_node);
+int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const uint32_t *indices, const float *table_f,
+                               const uint32_t *alias, const uint32_t *input, size_t num_input,
+                               const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
+                               uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
+                               uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node);
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).
