@@ -72,9 +72,20 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
       num_train_worker = std::stoull(need("num_train_worker"));
       have_switcher = raw.count("have_switcher") ? std::stoi(raw["have_switcher"]) != 0 : false;
       break;
+    case kArch6:  // operation.cc:104-108
+      num_worker = std::stoull(need("num_worker"));
+      num_sample_worker = num_train_worker = num_worker;
+      break;
+    case kArch7:  // operation.cc:109-118
+      worker_id = std::stoull(need("worker_id"));
+      num_worker = std::stoull(need("num_worker"));
+      sampler_ctx = Context(need("sampler_ctx"));
+      trainer_ctx = Context(need("trainer_ctx"));
+      SAM_CHECK(num_worker > 0 && worker_id < num_worker) << "bad worker_id / num_worker";
+      break;
     default:
-      SAM_FATAL << "run arch " << run_arch << " is not built (supported: arch1-arch5; arch0 is the reference's CPU "
-                   "sampling mode and arch6/7 its SGNN baseline)";
+      SAM_FATAL << "run arch " << run_arch << " is not built (supported: arch1-arch7; arch0 is the reference's CPU "
+                   "sampling mode)";
   }
   if (sample_type != kRandomWalk) {
     const size_t nf = std::stoull(need("num_fanout"));

@@ -29,6 +29,7 @@ struct RunConfig {
   size_t random_walk_length = 0, num_random_walk = 0, num_neighbor = 0, num_layer = 0;
   double random_walk_restart_prob = 0.0;
   size_t num_sample_worker = 1, num_train_worker = 1;
+  size_t worker_id = 0, num_worker = 1;  // arch6 (num_worker), arch7 (both)
   bool have_switcher = false;
   int barriered_epoch = 0, presample_epoch = 0;
   int omp_thread_num = 1;

@@ -91,18 +91,23 @@ void Engine::Init() {
   Timer t;
   ds_.Load(RC());
   Profiler::Get().LogInit(kLogInitL2LoadDataset, t.Passed());
-  num_step_ = RoundUpDiv(ds_.num_train, RC().batch_size);
+  const bool aligned = RC().run_arch == kArch6 || RC().run_arch == kArch7;
+  num_step_ = aligned ? Shuffler::AlignedNumStep(ds_.num_train, RC().batch_size, RC().num_worker)
+                      : RoundUpDiv(ds_.num_train, RC().batch_size);
   Profiler::Get().Resize(RC().num_epoch, num_step_);
   data_initialized_ = true;
   if (RC().run_arch == kArch1) {
     InitArch1();
   } else if (RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4) {
     InitInProcess();
+  } else if (RC().run_arch == kArch7) {
+    InitArch7();
   } else {
-    SAM_CHECK_EQ(RC().run_arch, (int)kArch5);
-    // shared queue + sampler barrier, created BEFORE fork (dist_engine.cc:129-153)
+    SAM_CHECK(RC().run_arch == kArch5 || RC().run_arch == kArch6);
+    // shared queue + sampler barrier, created BEFORE fork (dist_engine.cc:129-153); an arch6 worker's queue only joins
+    // the two halves of that worker, so each creates its own after the fork
     Timer tq;
-    CreateQueue();
+    if (RC().run_arch == kArch5) CreateQueue();
     void *bp = SharedAnonymous(sizeof(pthread_barrier_t));
     sampler_barrier_ = static_cast<pthread_barrier_t *>(bp);
     pthread_barrierattr_t attr;
@@ -181,26 +186,40 @@ void Engine::ReleaseBatch(GraphBatch *b) {
 // ------------------------------------------------------------------------------------------------
 // arch1: one GPU samples and extracts (cuda_engine.cc:64-196, cuda_loops_arch1.cc:44-80)
 
-void Engine::InitArch1() {
+void Engine::InitArch1() { InitSingleGPU(true); }
+
+// arch7 (the reference's "SGNN-DGL" baseline, cuda_engine.cc:102-112,329-332, cuda_loops_arch7.cc:54-84): every worker
+// process runs its own engine on its own GPU over an equal share of the train set and only SAMPLES; the script
+// gathers features itself (samgraph.torch.load_subtensor), so batches carry neither features nor labels.
+void Engine::InitArch7() {
+  SAM_CHECK(!RC().UseGPUCache()) << "arch7 has no feature cache (cuda_engine.cc:331)";
+  InitSingleGPU(false);
+}
+
+void Engine::InitSingleGPU(bool extract) {
   SAM_CHECK(RC().sampler_ctx.IsGPU() && RC().trainer_ctx.IsGPU())
-      << "arch1 needs cuda contexts: the sampling path has no CPU fallback";
+      << "arch1 / arch7 need cuda contexts: the sampling path has no CPU fallback";
   SAM_CHECK_EQ(RC().sampler_ctx.device_id, RC().trainer_ctx.device_id);
   Timer t;
   UploadTopology(RC().sampler_ctx.device_id);
-  SAM_HIP(hipMalloc(&d_feat_, ds_.feat.bytes));
-  SAM_HIP(hipMemcpy(d_feat_, ds_.feat.ptr, ds_.feat.bytes, hipMemcpyHostToDevice));
-  SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
-  SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
+  if (extract) {
+    SAM_HIP(hipMalloc(&d_feat_, ds_.feat.bytes));
+    SAM_HIP(hipMemcpy(d_feat_, ds_.feat.ptr, ds_.feat.bytes, hipMemcpyHostToDevice));
+    SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
+    SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
+  }
   CreateSampler();
+  const bool aligned = RC().run_arch == kArch7;
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
-                               RC().batch_size, 0, 1, stream_));
+                               RC().batch_size, aligned ? (int)RC().worker_id : 0, aligned ? (int)RC().num_worker : 1,
+                               stream_, aligned));
   pool_.reset(new GraphPool(RC().max_copying_jobs));
   slots_.resize(RC().max_copying_jobs + 2);
   for (auto &s : slots_) {
     int err = 0;
-    s.fb = fgnn_batch_create(sampler_, ds_.feat_dim, FGNN_F32, FGNN_I64, 0, &err);
+    s.fb = fgnn_batch_create(sampler_, extract ? ds_.feat_dim : 0, FGNN_F32, FGNN_I64, 0, &err);
     SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
-    SAM_FGNN(fgnn_batch_set_feat_row_mask(s.fb, FeatRowMask()));
+    if (extract) SAM_FGNN(fgnn_batch_set_feat_row_mask(s.fb, FeatRowMask()));
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
@@ -285,7 +304,8 @@ void Engine::SampleOnceArch1() {
   SAM_HIP(hipEventRecord(s->e0, stream_));
   SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s->fb, stream_));
   SAM_HIP(hipEventRecord(s->e1, stream_));
-  SAM_FGNN(fgnn_batch_extract(s->fb, d_feat_, d_label_, stream_));
+  const bool extract = d_feat_ != nullptr;  // arch7 hands the sampled blocks over without features
+  if (extract) SAM_FGNN(fgnn_batch_extract(s->fb, d_feat_, d_label_, stream_));
   SAM_HIP(hipEventRecord(s->e2, stream_));
   SAM_FGNN(fgnn_batch_finish(s->fb, stream_));
   fgnn_batch_meta m;
@@ -304,9 +324,11 @@ void Engine::SampleOnceArch1() {
     b->graphs[l].num_dst = m.num_dst[l];
     b->graphs[l].num_edge = m.num_edge[l];
   }
-  b->feat = fgnn_batch_feat(s->fb);
-  b->feat_rows = m.num_input;
-  b->label = fgnn_batch_label(s->fb);
+  if (extract) {
+    b->feat = fgnn_batch_feat(s->fb);
+    b->feat_rows = m.num_input;
+    b->label = fgnn_batch_label(s->fb);
+  }
   b->input_nodes = fgnn_batch_input_nodes(s->fb);
   b->output_nodes = fgnn_batch_output_nodes(s->fb);
   b->num_input = m.num_input;
@@ -328,8 +350,10 @@ void Engine::SampleOnceArch1() {
   P.LogStep(key, kLogL2ShuffleTime, shuffle_time);
   P.LogStep(key, kLogL2CoreSampleTime, ms_sample * 1e-3);
   P.LogStep(key, kLogL2ExtractTime, ms_extract * 1e-3);
-  P.LogStep(key, kLogL1FeatureBytes, (double)m.num_input * ds_.feat_dim * 4);
-  P.LogStep(key, kLogL1LabelBytes, (double)m.num_output * 8);
+  if (extract) {
+    P.LogStep(key, kLogL1FeatureBytes, (double)m.num_input * ds_.feat_dim * 4);
+    P.LogStep(key, kLogL1LabelBytes, (double)m.num_output * 8);
+  }
   P.LogEpochAdd(key, kLogEpochSampleTime, shuffle_time + ms_sample * 1e-3);
   P.LogEpochAdd(key, kLogEpochCopyTime, ms_extract * 1e-3);
   P.LogEpochAdd(key, kLogEpochSampleTotalTime, t0.Passed());
@@ -344,11 +368,14 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   SAM_CHECK(ctx.IsGPU()) << "sampler context must be cuda:N (no CPU sampling path in this build)";
   Timer t;
   dist_type_ = DistType::Sample;
+  const bool arch6 = RC().run_arch == kArch6;
+  if (arch6) CreateQueue();  // joins this worker's sampler half and extractor half only
   UploadTopology(ctx.device_id);
   mq_->PinMemory();
   CreateSampler();
+  // arch6: equal shares of the padded train set (DistAlignedShuffler, dist_engine.cc:276-281)
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
-                               RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_));
+                               RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_, arch6));
   pool_.reset(new GraphPool(RC().max_copying_jobs));
   slots_.resize(2);
   for (auto &s : slots_) {
@@ -487,15 +514,23 @@ void Engine::SampleOnceArch5() {
 
 void Engine::TrainInit(int worker_id, Context ctx, DistType type) {
   (void)worker_id;
-  if (initialized_) return;
+  // arch6 ("SGNN", dist_engine.cc:231-482 with kArch6): a worker calls sample_init AND train_init in the same process
+  // on the same GPU; the second call adds the extractor half
+  const bool second_half = RC().run_arch == kArch6 && dist_type_ == DistType::Sample && !tstream_;
+  if (initialized_ && !second_half) return;
   SAM_CHECK(data_initialized_) << "samgraph_data_init must run before fork";
   SAM_CHECK(ctx.IsGPU()) << "trainer context must be cuda:N";
+  if (RC().run_arch == kArch6) {
+    SAM_CHECK(second_half) << "arch6: samgraph_sample_init must precede samgraph_train_init in each worker";
+    SAM_CHECK_EQ(ctx.device_id, device_) << "arch6 samples and trains on the same GPU";
+    SAM_CHECK(type == DistType::Extract);
+  }
   Timer t;
-  dist_type_ = type;
+  if (!second_half) dist_type_ = type;
   SAM_HIP(hipSetDevice(ctx.device_id));
   tdevice_ = ctx.device_id;
   SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
-  mq_->PinMemory();
+  if (!second_half) mq_->PinMemory();
   // the host feature table becomes GPU-readable: miss rows are fetched by the gather kernel itself
   // (replaces the OpenMP ExtractMissData + H2D copy, cuda_cache_manager_host.cc:38-56)
   SAM_HIP(hipHostRegister(ds_.feat.ptr, ds_.feat.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
@@ -658,6 +693,21 @@ void Engine::TrainerOnce() {
 }
 
 void Engine::StartExtract(int count) {
+  if (RC().run_arch == kArch6) {
+    // one background thread running both halves per batch (SampleCopySubSloop, dist_loops_arch6.cc:196-207,218-227);
+    // the reference loops until shutdown, here `count` bounds it when positive
+    SAM_CHECK(initialized_ && tstream_);
+    if (extract_thread_.joinable()) extract_thread_.join();
+    const size_t total = count > 0 ? (size_t)count : RC().num_epoch * shuffler_->NumLocalStep();
+    extract_thread_ = std::thread([this, total]() {
+      for (size_t i = 0; i < total && !shutdown_; ++i) {
+        SampleOnceArch5();
+        PublishPending();
+        TrainerOnce();
+      }
+    });
+    return;
+  }
   SAM_CHECK(initialized_ && (dist_type_ == DistType::Extract || dist_type_ == DistType::Switch));
   if (extract_thread_.joinable()) extract_thread_.join();
   extract_thread_ = std::thread([this, count]() {
@@ -668,11 +718,14 @@ void Engine::StartExtract(int count) {
 
 void Engine::RunSampleOnce() {
   SAM_CHECK(initialized_);
-  if (RC().run_arch == kArch1) {
+  if (RC().run_arch == kArch1 || RC().run_arch == kArch7) {
     SampleOnceArch1();
-  } else if (RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4) {
-    // both sub-loops once, like RunArch3LoopsOnce (cuda_loops_arch3.cc:198-205): sample + publish, then copy/extract
+  } else if (RC().run_arch == kArch2 || RC().run_arch == kArch3 || RC().run_arch == kArch4 ||
+             RC().run_arch == kArch6) {
+    // both sub-loops once, like RunArch3LoopsOnce (cuda_loops_arch3.cc:198-205) / RunArch6LoopsOnce
+    // (dist_loops_arch6.cc:209-216): sample + publish, then copy/extract
     SAM_CHECK(!sample_thread_.joinable()) << "samgraph_sample_once after samgraph_start";
+    SAM_CHECK(tstream_) << "arch6: samgraph_train_init has not run in this worker";
     SampleOnceArch5();
     PublishPending();
     TrainerOnce();

@@ -1,6 +1,7 @@
 // eng_engine.h -- the process-wide engine singleton behind the samgraph_* C ABI.
 // Reference: engine.{h,cc} (base), cuda/cuda_engine.cc + cuda/cuda_loops_arch1.cc (arch1),
-// dist/dist_engine.cc + dist/dist_loops.cc + dist/dist_loops_arch5.cc (arch5, FGNN),
+// dist/dist_engine.cc + dist/dist_loops.cc + dist/dist_loops_arch5.cc (arch5, FGNN), dist/dist_loops_arch6.cc (arch6),
+// cuda/cuda_loops_arch7.cc (arch7),
 // graph_pool.cc, workspace_pool.cc.
 #pragma once
 #include <pthread.h>
@@ -109,6 +110,8 @@ class Engine {
   void ReleaseBatch(GraphBatch *b);
   // arch1
   void InitArch1();
+  void InitArch7();
+  void InitSingleGPU(bool extract);
   void SampleOnceArch1();
   // arch2 / arch3 / arch4: sampler and extractor in ONE process (cuda_loops_arch{2,3,4}.cc), the arch5 halves
   // joined by an in-process queue

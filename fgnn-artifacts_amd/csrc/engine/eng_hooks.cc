@@ -15,6 +15,18 @@ using namespace sam;
 
 extern "C" void fgnn_host_shuffle_minstd0(uint32_t *data, size_t n, uint64_t seed) { ShuffleMinstd0(data, n, seed); }
 
+extern "C" void fgnn_host_shuffler_partition(size_t num_data, size_t batch_size, int sampler_id, int num_sampler,
+                                             int aligned, size_t out[7]) {
+  const ShufflePartition p = Shuffler::Partition(num_data, batch_size, sampler_id, num_sampler, aligned != 0);
+  out[0] = p.padded_size;
+  out[1] = p.local_size;
+  out[2] = p.num_local_step;
+  out[3] = p.epoch_step;
+  out[4] = p.step_offset;
+  out[5] = p.dataset_offset;
+  out[6] = p.last_batch_size;
+}
+
 extern "C" void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_layers, int have_data,
                                      size_t out[3]) {
   out[0] = sizeof(TransData);

@@ -25,7 +25,8 @@ void samgraph_config(const char **config_keys, const char **config_values, const
 
 void samgraph_init(void) {
   SAM_CHECK(RC().is_configured);
-  SAM_CHECK(RC().run_arch >= kArch1 && RC().run_arch <= kArch4) << "samgraph_init is the single-process entry (arch1-4)";
+  SAM_CHECK((RC().run_arch >= kArch1 && RC().run_arch <= kArch4) || RC().run_arch == kArch7)
+      << "samgraph_init is the single-process entry (arch1-4, arch7)";
   Engine::Get().Init();
 }
 
@@ -92,7 +93,8 @@ void samgraph_forward_barrier(void) { Engine::Get().ForwardBarrier(); }
 
 void samgraph_data_init(void) {
   SAM_CHECK(RC().is_configured);
-  SAM_CHECK_EQ(RC().run_arch, (int)kArch5) << "samgraph_data_init is the multi-process entry (arch5) ";
+  SAM_CHECK(RC().run_arch == kArch5 || RC().run_arch == kArch6)
+      << "samgraph_data_init is the multi-process entry (arch5, arch6)";
   Engine::Get().Init();
 }
 void samgraph_sample_init(int worker_id, const char *ctx) {

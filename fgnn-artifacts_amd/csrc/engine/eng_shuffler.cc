@@ -28,25 +28,57 @@ void ShuffleMinstd0(uint32_t *data, size_t n, uint64_t seed) {
   }
 }
 
+size_t Shuffler::AlignedNumStep(size_t num_data, size_t batch_size, size_t num_worker) {
+  return Partition(num_data, batch_size, 0, (int)num_worker, true).epoch_step;
+}
+
+ShufflePartition Shuffler::Partition(size_t num_data, size_t batch_size, int sampler_id, int num_sampler,
+                                     bool aligned) {
+  SAM_CHECK(batch_size > 0 && num_sampler > 0 && sampler_id >= 0 && sampler_id < num_sampler);
+  ShufflePartition p;
+  const size_t ns = (size_t)num_sampler, id = (size_t)sampler_id;
+  if (aligned) {
+    p.padded_size = RoundUpDiv(num_data, ns) * ns;
+    p.local_size = p.padded_size / ns;
+    p.num_local_step = RoundUpDiv(p.local_size, batch_size);
+    p.epoch_step = p.num_local_step * ns;
+    p.step_offset = p.num_local_step * id;
+    p.dataset_offset = p.local_size * id;
+    p.last_batch_size = p.local_size % batch_size == 0 ? batch_size : p.local_size % batch_size;
+  } else {
+    const size_t total_step = RoundUpDiv(num_data, batch_size);  // drop_last == false
+    p.padded_size = num_data;
+    p.epoch_step = total_step;
+    p.step_offset = total_step / ns * id;
+    p.dataset_offset = p.step_offset * batch_size;
+    p.last_batch_size = num_data % batch_size == 0 ? batch_size : num_data % batch_size;
+    if (id + 1 < ns) {
+      p.last_batch_size = batch_size;
+      p.num_local_step = total_step / ns;
+      p.local_size = p.num_local_step * batch_size;
+    } else {
+      p.num_local_step = total_step - p.step_offset;
+      p.local_size = num_data - p.step_offset * batch_size;
+    }
+  }
+  return p;
+}
+
 Shuffler::Shuffler(const uint32_t *train_set, size_t num_data, size_t num_epoch, size_t batch_size, int sampler_id,
-                   int num_sampler, hipStream_t stream)
+                   int num_sampler, hipStream_t stream, bool aligned)
     : data_(train_set, train_set + num_data), num_data_(num_data), num_epoch_(num_epoch), batch_size_(batch_size),
       stream_(stream) {
-  SAM_CHECK(batch_size > 0 && num_sampler > 0 && sampler_id >= 0 && sampler_id < num_sampler);
-  // drop_last == false path of dist_shuffler.cc:47-79
-  size_t total_step = (num_data + batch_size - 1) / batch_size;
-  last_batch_size_ = num_data % batch_size == 0 ? batch_size : num_data % batch_size;
-  if (sampler_id < num_sampler - 1) last_batch_size_ = batch_size;
-  epoch_step_ = total_step;
-  dataset_offset_ = (total_step / num_sampler * sampler_id) * batch_size;
-  if (sampler_id == num_sampler - 1) {
-    const size_t previous = total_step / num_sampler * sampler_id;
-    num_step_ = total_step - previous;
-    local_size_ = num_data - previous * batch_size;
-  } else {
-    num_step_ = total_step / num_sampler;
-    local_size_ = num_step_ * batch_size;
-  }
+  const ShufflePartition p = Partition(num_data, batch_size, sampler_id, num_sampler, aligned);
+  // aligned: pad with the first ids of the set (dist_shuffler_aligned.cc:50-59)
+  SAM_CHECK(p.padded_size - num_data <= num_data);
+  for (size_t i = 0; i < p.padded_size - num_data; ++i) data_.push_back(train_set[i]);
+  num_data_ = p.padded_size;
+  local_size_ = p.local_size;
+  num_step_ = p.num_local_step;
+  epoch_step_ = p.epoch_step;
+  step_offset_ = p.step_offset;
+  dataset_offset_ = p.dataset_offset;
+  last_batch_size_ = p.last_batch_size;
   cur_step_ = num_step_;
   SAM_HIP(hipMalloc(&d_data_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
 }

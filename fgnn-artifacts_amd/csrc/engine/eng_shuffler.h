@@ -1,7 +1,9 @@
 // eng_shuffler.h -- per-epoch shuffle of the train set and its split into batches.
 // Reference: dist/dist_shuffler.cc:36-179 (arch5: every sampler shuffles the WHOLE train set on the
 // host with std::default_random_engine(epoch) and takes a contiguous step range),
-// cuda/cuda_shuffler.cc:40-154 (single process; wall-clock seed there, epoch seed here).
+// cuda/cuda_shuffler.cc:40-154 (single process; wall-clock seed there, epoch seed here),
+// dist/dist_shuffler_aligned.cc:36-146 (arch6 / arch7: the train set is padded to a multiple of the worker count with
+// its own first ids, every worker takes an equal contiguous share of the shuffled array).
 // The permutation is bit-identical to the reference's for the same seed (oracle
 // fgnn_oracle_shuffle_minstd0, pinned against libstdc++ in tests/golden/shuffle.npz).
 #pragma once
@@ -15,16 +17,25 @@ namespace sam {
 // std::minstd_rand0 + libstdc++ uniform_int_distribution<size_t>(0,i): in place, cumulative
 void ShuffleMinstd0(uint32_t *data, size_t n, uint64_t seed);
 
+struct ShufflePartition {  // one sampler's share of an epoch
+  size_t padded_size, local_size, num_local_step, epoch_step, step_offset, dataset_offset, last_batch_size;
+};
+
 class Shuffler {
  public:
+  // dist_shuffler.cc:47-79 (contiguous step ranges, the last sampler takes the remainder) or, aligned,
+  // dist_shuffler_aligned.cc:45-71 (equal shares of the set padded to a multiple of the sampler count)
+  static ShufflePartition Partition(size_t num_data, size_t batch_size, int sampler_id, int num_sampler, bool aligned);
   // sampler_id/num_sampler = 0/1 for the single-process engines
   Shuffler(const uint32_t *train_set, size_t num_data, size_t num_epoch, size_t batch_size, int sampler_id,
-           int num_sampler, hipStream_t stream);
+           int num_sampler, hipStream_t stream, bool aligned = false);
+  // steps per epoch over all workers of the aligned split (known before any worker exists)
+  static size_t AlignedNumStep(size_t num_data, size_t batch_size, size_t num_worker);
   ~Shuffler();
   // next batch of this sampler: device pointer into the epoch's slice + size; false when all epochs are done
   bool GetBatch(const uint32_t **d_batch, size_t *size);
   uint64_t Epoch() const { return cur_epoch_; }
-  uint64_t Step() const { return cur_step_ + dataset_offset_ / batch_size_; }  // global step (dist_shuffler.h:38-41)
+  uint64_t Step() const { return cur_step_ + step_offset_; }  // global step (dist_shuffler.h:38-41, dist_shuffler_aligned.h:41)
   size_t NumStep() const { return epoch_step_; }      // steps per epoch over all samplers
   size_t NumLocalStep() const { return num_step_; }   // steps of this sampler
   bool IsLastBatch() const { return cur_step_ == num_step_ - 1; }
@@ -35,7 +46,7 @@ class Shuffler {
   std::vector<uint32_t> data_;
   uint32_t *d_data_ = nullptr;
   size_t num_data_, num_epoch_, batch_size_;
-  size_t num_step_, epoch_step_, last_batch_size_, dataset_offset_, local_size_;
+  size_t num_step_, epoch_step_, last_batch_size_, dataset_offset_, local_size_, step_offset_;
   uint64_t cur_epoch_ = 0;
   size_t cur_step_;
   bool initialized_ = false;

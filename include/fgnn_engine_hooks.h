@@ -16,6 +16,13 @@ extern "C" {
 /* the shufflers' per-epoch Fisher-Yates (dist/dist_shuffler.cc:108-131), in place */
 void fgnn_host_shuffle_minstd0(uint32_t *data, size_t n, uint64_t seed);
 
+/* one sampler's share of an epoch: aligned == 0 is DistShuffler (dist/dist_shuffler.cc:47-79), aligned != 0 is
+ * DistAlignedShuffler (dist/dist_shuffler_aligned.cc:45-71, arch6 / arch7).  out = {padded train-set size, ids of this
+ * sampler, its steps per epoch, steps per epoch over all samplers, its first global step, its first id's offset in
+ * the shuffled array, size of its last batch} */
+void fgnn_host_shuffler_partition(size_t num_data, size_t batch_size, int sampler_id, int num_sampler, int aligned,
+                                  size_t out[7]);
+
 /* sizes the wire format was compiled with: out[0] = sizeof(TransData) (40), out[1] = sizeof(GraphData) (24),
  * out[2] = worst-case message bytes for (batch_size, fanout[num_layers], have_data) (task_queue.cc:349-371) */
 void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_layers, int have_data, size_t out[3]);

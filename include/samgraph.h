@@ -12,8 +12,12 @@
  * Supported run architectures (RunArch, common.h:70-79): arch1 (one GPU samples and extracts,
  * cuda/cuda_loops_arch1.cc), arch2 / arch3 / arch4 (one process, sampler context + trainer context, optional
  * background threads via samgraph_start; arch3 is the default of the reference's single-process scripts;
- * cuda/cuda_loops_arch{2,3,4}.cc -- without arch4's dynamic-cache prototype) and arch5 (FGNN: sampler processes +
- * trainer processes linked by the pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc).  Sample types: all seven (khop0,
+ * cuda/cuda_loops_arch{2,3,4}.cc -- without arch4's dynamic-cache prototype), arch5 (FGNN: sampler processes +
+ * trainer processes linked by the pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc), arch6 (the
+ * reference's SGNN baseline: samgraph_data_init in the parent, samgraph_sample_init + samgraph_train_init in every
+ * worker process, each worker samples and extracts its equal share of the train set, dist/dist_loops_arch6.cc,
+ * dist/dist_shuffler_aligned.cc) and arch7 (a sample-only engine per worker: samgraph_config with worker_id /
+ * num_worker + samgraph_init in every worker, cuda/cuda_loops_arch7.cc).  Sample types: all seven (khop0,
  * khop1, khop2, weighted_khop, weighted_khop_hash_dedup, weighted_khop_prefix, random_walk).  Cache policies: pre_sample (computed at sample_init,
  * dist/pre_sampler.cc) and the file-backed rankings (cache_by_*.bin, engine.cc:216-256).
  */
@@ -29,14 +33,14 @@ extern "C" {
 
 /* operation.h:29-31, operation.cc:45-169.  Required keys: dataset_path, _arch, _sample_type,
  * batch_size, num_epoch, _cache_policy, cache_percentage, max_sampling_jobs, max_copying_jobs,
- * omp_thread_num; arch1: sampler_ctx, trainer_ctx; arch5: num_sample_worker, num_train_worker,
- * [have_switcher]; k-hop: num_fanout, fanout; random walk: random_walk_length,
+ * omp_thread_num; arch1-4: sampler_ctx, trainer_ctx; arch5: num_sample_worker, num_train_worker,
+ * [have_switcher]; arch6: num_worker; arch7: worker_id, num_worker, sampler_ctx, trainer_ctx; k-hop: num_fanout, fanout; random walk: random_walk_length,
  * random_walk_restart_prob, num_random_walk, num_neighbor, num_layer; optional barriered_epoch,
  * presample_epoch.  Unknown keys are ignored.  Extension keys of this build (ignored by the
  * reference): seed (Philox seed, default 0x5A4D47). */
 void samgraph_config(const char **config_keys, const char **config_values, const size_t num_config_items);
 
-void samgraph_init(void);     /* operation.h:32, single-process archs */
+void samgraph_init(void);     /* operation.h:32, single-process archs (arch1-4) and every arch7 worker */
 void samgraph_start(void);    /* operation.h:34 */
 void samgraph_shutdown(void); /* operation.h:36 */
 

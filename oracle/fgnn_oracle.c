@@ -713,6 +713,26 @@ void fgnn_oracle_dist_shuffler_partition(size_t num_data, size_t batch_size, int
   *last_batch_size = last;
 }
 
+void fgnn_oracle_aligned_shuffler_partition(size_t num_data, size_t batch_size, size_t worker_id,
+                                            size_t num_worker, size_t *padded_size,
+                                            size_t *data_per_worker, size_t *num_local_step,
+                                            size_t *num_global_step, size_t *global_step_offset,
+                                            size_t *global_data_offset, size_t *last_batch_size) {
+  /* DistAlignedShuffler's constructor, dist_shuffler_aligned.cc:45-71: the set is rounded up to a
+   * multiple of num_worker (the pad repeats its first ids, :50-59), every worker owns
+   * padded / num_worker consecutive ids of the shuffled array and ceil(that / batch) steps */
+  size_t padded = (num_data + num_worker - 1) / num_worker * num_worker;
+  size_t per = padded / num_worker;
+  size_t local = (per + batch_size - 1) / batch_size;
+  *padded_size = padded;
+  *data_per_worker = per;
+  *num_local_step = local;
+  *num_global_step = local * num_worker;
+  *global_step_offset = local * worker_id;
+  *global_data_offset = per * worker_id;
+  *last_batch_size = per % batch_size == 0 ? batch_size : per % batch_size;
+}
+
 /* ------------------------------------------------------------------ OpenMP CPU baseline -----
  * The reference's CPU sampling path as it actually runs with omp_thread_num > 1
  * (cpu/cpu_sampling_khop2.cc:29-76 with a thread_local default-seeded mt19937 per thread,

@@ -236,6 +236,13 @@ void fgnn_oracle_dist_shuffler_partition(size_t num_data, size_t batch_size, int
                                          size_t *num_local_step, size_t *local_data_size,
                                          size_t *last_batch_size, size_t *epoch_step);
 
+/* DistAlignedShuffler (dist/dist_shuffler_aligned.cc:36-146): the arch6 / arch7 split */
+void fgnn_oracle_aligned_shuffler_partition(size_t num_data, size_t batch_size, size_t worker_id,
+                                            size_t num_worker, size_t *padded_size,
+                                            size_t *data_per_worker, size_t *num_local_step,
+                                            size_t *num_global_step, size_t *global_step_offset,
+                                            size_t *global_data_offset, size_t *last_batch_size);
+
 size_t fgnn_dtype_bytes(int dtype);
 
 /* ---------------------------------------------------------------- OpenMP CPU baseline -------

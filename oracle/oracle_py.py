@@ -312,6 +312,29 @@ def dist_shuffler_partition(num_data, batch_size, sampler_id, num_sampler):
                 last_batch_size=v[3].value, epoch_step=v[4].value)
 
 
+def aligned_shuffler_partition(num_data, batch_size, worker_id, num_worker):
+    """DistAlignedShuffler's split (dist/dist_shuffler_aligned.cc:45-71)."""
+    v = [C.c_size_t(0) for _ in range(7)]
+    lib().fgnn_oracle_aligned_shuffler_partition(C.c_size_t(num_data), C.c_size_t(batch_size), C.c_size_t(worker_id),
+                                                 C.c_size_t(num_worker), *[C.byref(x) for x in v])
+    return dict(padded_size=v[0].value, local_data_size=v[1].value, num_local_step=v[2].value,
+                epoch_step=v[3].value, step_offset=v[4].value, dataset_offset=v[5].value,
+                last_batch_size=v[6].value)
+
+
+def aligned_shuffler_batches(train_set, batch_size, worker_id, num_worker, num_epoch):
+    """The batches one worker's DistAlignedShuffler hands out, in order: (epoch, global step, ids)
+    (dist_shuffler_aligned.cc:80-146: cumulative Fisher-Yates over the padded set, seed = epoch)."""
+    train_set = np.ascontiguousarray(train_set, dtype=np.uint32)
+    p = aligned_shuffler_partition(len(train_set), batch_size, worker_id, num_worker)
+    data = np.concatenate([train_set, train_set[:p["padded_size"] - len(train_set)]])
+    for epoch in range(num_epoch):
+        data = shuffle_minstd0(data, epoch)
+        mine = data[p["dataset_offset"]:p["dataset_offset"] + p["local_data_size"]]
+        for ls in range(p["num_local_step"]):
+            yield epoch, p["step_offset"] + ls, mine[ls * batch_size:(ls + 1) * batch_size]
+
+
 class OmpBaseline:
     """The reference's OpenMP CPU path (see fgnn_oracle.c, 'OpenMP CPU baseline'); timing only."""
 

@@ -46,9 +46,10 @@ def base_config(path, arch, sample_type):
 class OracleReplay:
     """Replays what sampler `worker` of `num_sampler` does, batch by batch, with the oracle."""
 
-    def __init__(self, path, sample_type, worker=0, num_sampler=1, presample=False):
+    def __init__(self, path, sample_type, worker=0, num_sampler=1, presample=False, aligned=False):
         import oracle_py as oracle
         self.o = oracle
+        self.worker, self.num_sampler, self.aligned = worker, num_sampler, aligned
         self.indptr = np.fromfile(os.path.join(path, "indptr.bin"), dtype=np.uint32)
         self.indices = np.fromfile(os.path.join(path, "indices.bin"), dtype=np.uint32)
         self.feat = np.fromfile(os.path.join(path, "feat.bin"), dtype=np.float32).reshape(NUM_NODE, DIM)
@@ -74,8 +75,13 @@ class OracleReplay:
             self.fan = [5, 3]
         self.rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
         self.ht = oracle.HashTable(NUM_NODE, oracle.predict_num_nodes(BATCH, self.fan))
-        self.num_step = (NUM_TRAIN + BATCH - 1) // BATCH
-        self.part = oracle.dist_shuffler_partition(NUM_TRAIN, BATCH, worker, num_sampler)
+        self.plain_step = (NUM_TRAIN + BATCH - 1) // BATCH  # the presampler always walks the whole set
+        if aligned:  # arch6 / arch7: DistAlignedShuffler
+            self.part = oracle.aligned_shuffler_partition(NUM_TRAIN, BATCH, worker, num_sampler)
+            self.num_step = self.part["epoch_step"]
+        else:
+            self.part = oracle.dist_shuffler_partition(NUM_TRAIN, BATCH, worker, num_sampler)
+            self.num_step = self.plain_step
         self.rank = None
         if presample and worker == 0:
             self._presample()
@@ -87,7 +93,7 @@ class OracleReplay:
         data = self.train0.copy()
         freq = np.zeros(NUM_NODE, dtype=np.uint32)
         data = self.o.shuffle_minstd0(data, 0)
-        for step in range(self.num_step):
+        for step in range(self.plain_step):
             seeds = data[step * BATCH:(step + 1) * BATCH]
             t = self._sample(seeds, (1 << 63) | step)
             np.add.at(freq, t["input_nodes"], 1)
@@ -95,6 +101,12 @@ class OracleReplay:
 
     def epochs(self):
         """yields (key, seeds, task) for this sampler's batches in order"""
+        if self.aligned:
+            for epoch, step, seeds in self.o.aligned_shuffler_batches(self.train0, BATCH, self.worker,
+                                                                      self.num_sampler, NUM_EPOCH):
+                key = epoch * self.num_step + step
+                yield key, seeds, self._sample(seeds, key)
+            return
         data = self.train0.copy()
         for epoch in range(NUM_EPOCH):
             data = self.o.shuffle_minstd0(data, epoch)
@@ -106,11 +118,11 @@ class OracleReplay:
                 yield key, seeds, self._sample(seeds, key)
 
 
-def check_batch(sam, key, seeds, task, rep, what=""):
+def check_batch(sam, key, seeds, task, rep, what="", with_feat=True):
     import torch  # noqa: F401
     nl = len(task["graphs"])
     blocks, feat, label = (sam.get_dgl_blocks_with_weights if rep.st == rep.o.RANDOM_WALK else sam.get_dgl_blocks)(
-        key, nl)
+        key, nl, with_feat)
 
     def u32(t):
         return t.cpu().numpy().view(np.uint32)
@@ -124,6 +136,10 @@ def check_batch(sam, key, seeds, task, rep, what=""):
         np.testing.assert_array_equal(u32(blocks[li].col), g["col"], err_msg=what)
         if g["data"] is not None:
             np.testing.assert_array_equal(u32(blocks[li].edata["weights"]), g["data"], err_msg=what)
+    if not with_feat:
+        # arch7: the script gathers features itself from the host tensors (sgnn_dgl/train_graphsage.py:165-167)
+        assert feat is None and label is None
+        feat, label = sam.load_subtensor(key, sam.get_dataset_feat(), sam.get_dataset_label(), "cuda:0")
     if os.environ.get("SAMGRAPH_EMPTY_FEAT", "0") in ("", "0"):
         assert feat.cpu().numpy().tobytes() == rep.feat[task["input_nodes"]].tobytes(), what + " feat"
     else:  # mock extraction from an uninitialised 2^k-row table: only the shape is defined
@@ -293,6 +309,68 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
 
 
+def _sgnn_worker(arch, worker, num_worker, path, sample_type, cache_pct, background, barrier, err):
+    """One worker of the reference's SGNN baselines: arch6 = example/samgraph/sgnn/train_graphsage.py:115-190
+    (sample_init + train_init in the same process, sample_once / get_next_batch per step), arch7 =
+    example/samgraph/sgnn_dgl/train_graphsage.py:95-170 (config + init per worker, blocks without features)."""
+    try:
+        faulthandler.dump_traceback_later(400, exit=True)
+        import samgraph.torch as sam
+        if arch == "arch6":
+            sam.sample_init(worker, "cuda:0")
+            sam.train_init(worker, "cuda:0")
+        else:
+            cfg = base_config(path, sam.kArch7, sample_type)
+            cfg.update(worker_id=worker, num_worker=num_worker, sampler_ctx="cuda:0", trainer_ctx="cuda:0")
+            sam.config(cfg)
+            sam.init()
+        rep = OracleReplay(path, sample_type, worker, num_worker, cache_pct > 0, aligned=True)
+        assert sam.steps_per_epoch() == rep.num_step and sam.num_local_step() == rep.part["num_local_step"]
+        assert sam.num_epoch() == NUM_EPOCH
+        barrier.wait()
+        if background:
+            sam.extract_start(0)
+        n = 0
+        for key, seeds, task in rep.epochs():
+            if not background:
+                sam.sample_once()
+            got = sam.get_next_batch()
+            assert got == key, (got, key)
+            check_batch(sam, key, seeds, task, rep, "%s worker %d key %d" % (arch, worker, key),
+                        with_feat=(arch == "arch6"))
+            n += 1
+        assert n == NUM_EPOCH * rep.part["num_local_step"]
+        barrier.wait()
+        sam.shutdown()
+        print("%s worker %d/%d checked %d batches" % (arch, worker, num_worker, n))
+    except BaseException:
+        traceback.print_exc()
+        err.value = 1
+        os._exit(1)
+
+
+def run_sgnn(arch, sample_type, workdir, num_worker, cache_pct, background):
+    path = dataset(workdir, sample_type)
+    if arch == "arch6":
+        import samgraph.torch as sam
+        cfg = base_config(path, sam.kArch6, sample_type)
+        cfg.update(num_worker=num_worker, cache_percentage=cache_pct)
+        sam.config(cfg)
+        sam.data_init()  # before fork, no GPU touched (sgnn/train_graphsage.py: run_init)
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(num_worker)
+    err = ctx.Value("i", 0)
+    procs = [ctx.Process(target=_sgnn_worker,
+                         args=(arch, w, num_worker, path, sample_type, cache_pct, background, barrier, err))
+             for w in range(num_worker)]
+    for p in procs:
+        p.start()
+    bad = _join_all(procs, ["worker"] * num_worker)
+    if bad or err.value:
+        sys.exit(1)
+    print("%s %s %d workers cache %.2f ok" % (arch, sample_type, num_worker, cache_pct))
+
+
 def _switch_sampler_proc(barrier, sem, stop, err):
     try:
         faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
@@ -373,6 +451,8 @@ if __name__ == "__main__":
         run_arch1(st, wd)
     elif mode == "switcher":
         run_arch5_switcher(st, wd)
+    elif mode in ("arch6", "arch7"):
+        run_sgnn(mode, st, wd, int(sys.argv[4]), float(sys.argv[5]), len(sys.argv) > 6 and sys.argv[6] == "background")
     elif mode in ("arch2", "arch3", "arch4"):
         run_inproc(mode, st, wd, float(sys.argv[4]), sys.argv[5] == "threads")
     else:

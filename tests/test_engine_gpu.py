@@ -58,6 +58,20 @@ def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)
 
 
+@pytest.mark.parametrize("arch,sample_type,workers,cache,mode", [
+    ("arch6", "khop2", 2, 0.25, "inline"),       # 2 workers, each samples + extracts its own aligned share
+    ("arch6", "khop2", 3, 0.0, "background"),    # train set padded to a multiple of 3; samgraph_extract_start thread
+    ("arch6", "random_walk", 1, 0.2, "inline"),
+    ("arch7", "khop2", 2, 0.0, "inline"),        # sample only; features through samgraph.torch.load_subtensor
+    ("arch7", "weighted_khop_prefix", 3, 0.0, "inline"),
+])
+def test_sgnn_baseline_archs(tmp_path, arch, sample_type, workers, cache, mode):
+    """The reference's SGNN baselines behind the same API: arch6 (dist_loops_arch6.cc: every worker process samples,
+    extracts and trains on its GPU) and arch7 (cuda_loops_arch7.cc: every worker runs its own sample-only engine),
+    both over DistAlignedShuffler's equal shares (dist_shuffler_aligned.cc); all workers on cuda:0 here."""
+    assert "ok" in _run(tmp_path, arch, sample_type, workers, cache, mode)
+
+
 @pytest.mark.parametrize("sample_type", ["random_walk", "khop2"])
 def test_arch5_switcher(tmp_path, sample_type):
     """BASELINE config 5's switcher flow: with `have_switcher` the sampler ships input nodes, the trainer and the
@@ -93,3 +107,16 @@ def test_fgnn_training_example_runs(tmp_path, model, extra):
                        capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:pipeline_train_epoch_time=" in p.stdout and "test_result:sample_time=" in p.stdout
+
+
+@pytest.mark.parametrize("extra", [["--arch", "arch6", "--num-worker", "2", "--single-gpu", "--cache-percentage", "0.2"],
+                                   ["--arch", "arch7", "--num-worker", "1"]])
+def test_sgnn_example_runs(tmp_path, extra):
+    """examples/sgnn/train_sgnn.py = the reference's sgnn/ (arch6) and sgnn_dgl/ (arch7) script shape: one process per
+    worker doing sample + extract + train, gradients synchronised across workers."""
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "sgnn", "train_sgnn.py")
+    p = subprocess.run([sys.executable, ex, "--make-dataset", "small", "--dataset-path", str(tmp_path / "small"),
+                        "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"] + extra,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch_per_worker=" in p.stdout

@@ -68,9 +68,14 @@ def test_config_parse(eng):
               num_layer=3)
     del rw["fanout"], rw["num_fanout"]
     assert _probe(eng, rw)[1][:2] == [3, 5]
+    # the SGNN baselines' keys (operation.cc:104-118)
+    a6 = _cfg(_arch=6, num_worker=4)
+    assert _probe(eng, a6)[1] == [2, 25, 6, 1]
+    a7 = _cfg(_arch=7, num_worker=4, worker_id=3, sampler_ctx="cuda:3", trainer_ctx="cuda:3", cache_percentage=0.0)
+    assert _probe(eng, a7)[1] == [2, 25, 7, 0]
 
 
-@pytest.mark.parametrize("bad", [dict(drop="batch_size"), dict(_arch=6), dict(_arch=0), dict(_sample_type=7), dict(drop="fanout"),
+@pytest.mark.parametrize("bad", [dict(drop="batch_size"), dict(_arch=6), dict(_arch=8), dict(_arch=0), dict(_arch=7, num_worker=2, worker_id=2, sampler_ctx='cuda:0', trainer_ctx='cuda:0'), dict(_sample_type=7), dict(drop="fanout"),
                                  dict(_arch=1), dict(_sample_type=6, fanout="60 5")])
 def test_config_errors_abort(bad):
     """No return codes: a violated check prints file:line and abort()s (logging.h:32-45)."""
@@ -98,6 +103,23 @@ def test_shuffle_matches_reference_permutation(eng, oracle, golden_dir):
     data = np.arange(100003, dtype=np.uint32)
     eng.fgnn_host_shuffle_minstd0(data.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), C.c_uint64(7))
     np.testing.assert_array_equal(data, oracle.shuffle_minstd0(np.arange(100003, dtype=np.uint32), 7))
+
+
+def test_shuffler_partitions_match_oracle(eng, oracle):
+    """Both shufflers' splits (dist_shuffler.cc:47-79, dist_shuffler_aligned.cc:45-71) against the oracle's restatement."""
+    out = (C.c_size_t * 7)()
+    for n, b, ns in [(1207179, 8000, 1), (1207179, 8000, 2), (1207179, 8000, 8), (196615, 8000, 3), (1003, 100, 4),
+                     (16000, 8000, 2), (7, 3, 2), (64, 8, 8)]:
+        for sid in range(ns):
+            eng.fgnn_host_shuffler_partition(C.c_size_t(n), C.c_size_t(b), sid, ns, 0, out)
+            want = oracle.dist_shuffler_partition(n, b, sid, ns)
+            assert (out[0], out[1], out[2], out[3], out[4], out[5], out[6]) == (
+                n, want["local_data_size"], want["num_local_step"], want["epoch_step"], want["dataset_offset"] // b,
+                want["dataset_offset"], want["last_batch_size"])
+            eng.fgnn_host_shuffler_partition(C.c_size_t(n), C.c_size_t(b), sid, ns, 1, out)
+            want = oracle.aligned_shuffler_partition(n, b, sid, ns)
+            assert list(out) == [want[k] for k in ("padded_size", "local_data_size", "num_local_step", "epoch_step",
+                                                   "step_offset", "dataset_offset", "last_batch_size")]
 
 
 def test_wire_sizes(eng):

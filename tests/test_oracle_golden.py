@@ -139,6 +139,28 @@ def test_formulas(oracle):
     assert p0["dataset_offset"] == 0 and p1["dataset_offset"] == 75 * 8000
     assert p0["last_batch_size"] == 8000 and p1["last_batch_size"] == 1207179 % 8000
     assert p0["local_data_size"] == 75 * 8000 and p1["local_data_size"] == 1207179 - 75 * 8000
+    # DistAlignedShuffler (dist_shuffler_aligned.cc:45-71), papers100M on 8 workers: 1 207 179 -> 1 207 184 ids,
+    # 150 898 per worker, 19 steps each (152 per epoch), last batch 150 898 - 18 * 8000 = 6898
+    for w in range(8):
+        a = oracle.aligned_shuffler_partition(1207179, 8000, w, 8)
+        assert a == dict(padded_size=1207184, local_data_size=150898, num_local_step=19, epoch_step=152,
+                         step_offset=19 * w, dataset_offset=150898 * w, last_batch_size=6898)
+    a = oracle.aligned_shuffler_partition(16000, 8000, 1, 2)
+    assert a["padded_size"] == 16000 and a["num_local_step"] == 1 and a["last_batch_size"] == 8000
+    # the batches of all workers of an epoch are the shuffled padded set, cut per worker
+    train = np.arange(100, 1103, dtype=np.uint32)  # 1003 ids, 4 workers -> padded with the first id
+    got = {}
+    for w in range(4):
+        for epoch, step, ids in oracle.aligned_shuffler_batches(train, 100, w, 4, 2):
+            got[(epoch, step)] = ids
+    assert sorted(got) == [(e, s) for e in range(2) for s in range(12)]
+    data = np.concatenate([train, train[:1]])
+    for e in range(2):
+        data = oracle.shuffle_minstd0(data, e)
+        for w in range(4):
+            mine = np.concatenate([got[(e, 3 * w + k)] for k in range(3)])
+            np.testing.assert_array_equal(mine, data[251 * w:251 * (w + 1)])
+            assert [len(got[(e, 3 * w + k)]) for k in range(3)] == [100, 100, 51]
 
 
 def test_cache_split_and_rank(oracle):
