@@ -288,7 +288,10 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
   const size_t L = s->cfg.num_layers;
+  // FGNN_KHOP2_UNORDERED=1 (profiling only; results then depend on the overlap): drop khop2's batch-order chain
+  static const bool unordered = [] { const char *e = getenv("FGNN_KHOP2_UNORDERED"); return e && atoi(e) != 0; }();
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
+  const bool ordered = mutates && !unordered;
   {
     // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
     std::unique_lock<std::mutex> lk(s->mu);
@@ -305,7 +308,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   out->num_output = num_seeds;
   // the slot's scratch was last used kSlots batches ago, possibly on another stream
   if (sl.was_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
-  if (mutates && seq > 0) {
+  if (ordered && seq > 0) {
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
     {
       std::unique_lock<std::mutex> lk(s->mu);
