@@ -242,6 +242,7 @@ void Engine::InitInProcess() {
   // sampler half
   UploadTopology(RC().sampler_ctx.device_id);
   mq_->PinMemory();
+  if (mq_->CreateDeviceRing(0, (uint32_t)RC().device_ring_slots)) ring_id_ = 0;
   CreateSampler();
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, 0, 1, stream_));
@@ -372,6 +373,10 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   if (arch6) CreateQueue();  // joins this worker's sampler half and extractor half only
   UploadTopology(ctx.device_id);
   mq_->PinMemory();
+  {
+    const int ring = arch6 ? 0 : worker_id;  // an arch6 queue is private to its worker
+    if (ring < kMaxRings && mq_->CreateDeviceRing(ring, (uint32_t)RC().device_ring_slots)) ring_id_ = ring;
+  }
   CreateSampler();
   // arch6: equal shares of the padded train set (DistAlignedShuffler, dist_engine.cc:276-281)
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
@@ -497,6 +502,7 @@ void Engine::SampleOnceArch5() {
   a.ship_cache_index = use_cache ? 1 : 0;
   a.have_data = RC().sample_type == kRandomWalk ? 1 : 0;
   a.slot = DeviceVisible(slot);
+  a.payload = mq_->ClaimDeviceSlot(ring_id_, s.mq_key);  // null: no device ring, or none of its slots is free
   a.slot_bytes = mq_->SlotBytes();
   SAM_FGNN(LaunchPack(a, stream_));
   SAM_FGNN(fgnn_batch_finish(s.fb, stream_));
@@ -579,7 +585,12 @@ void Engine::TrainerOnce() {
   SAM_CHECK_LE((size_t)hdr.num_layer, (size_t)FGNN_MAX_LAYERS);
   const bool use_cache = RC().UseGPUCache();
   const bool ship_input = !use_cache || RC().have_switcher;
+  // headers are parsed from the host slot (`p`); the arrays are copied from the payload slot (`q`), which is the host
+  // slot itself or a slot of the sampler's HBM ring at the same offsets
+  bool payload_on_device = false;
+  const char *payload = static_cast<const char *>(mq_->Payload(mq_key, msg, &payload_on_device));
   const uint32_t *p = reinterpret_cast<const uint32_t *>(msg + sizeof(TransData));
+  const ptrdiff_t to_payload = payload - msg;
   auto b = std::make_shared<GraphBatch>();
   b->key = hdr.key;
   b->num_layer = hdr.num_layer;
@@ -590,7 +601,8 @@ void Engine::TrainerOnce() {
   auto to_device = [&](const uint32_t *src, size_t n) -> uint32_t * {
     uint32_t *d = static_cast<uint32_t *>(dev_pool_.Alloc(n * sizeof(uint32_t)));
     b->pooled.push_back(d);
-    if (n) SAM_HIP(hipMemcpyAsync(d, src, n * sizeof(uint32_t), hipMemcpyHostToDevice, tstream_));
+    const void *from = reinterpret_cast<const char *>(src) + to_payload;
+    if (n) SAM_HIP(hipMemcpyAsync(d, from, n * sizeof(uint32_t), hipMemcpyDefault, tstream_));
     return d;
   };
 
@@ -771,6 +783,12 @@ void Engine::Shutdown() {
   if (dist_type_ == DistType::Sample || sampler_) PublishPending();
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
+  if (mq_ && ring_id_ >= 0) {
+    // messages published into this sampler's HBM ring must stay readable until their receivers have copied them
+    // (the in-process engines read their own ring and their threads have been joined: nothing to wait for)
+    mq_->DrainDeviceRing(ring_id_, RC().run_arch == kArch5 ? 120.0 : 0.0);
+    ring_id_ = -1;
+  }
   if (current_) {
     ReleaseBatch(current_.get());
     current_.reset();

@@ -169,6 +169,7 @@ class Engine {
 
   // arch5 shared state (created before fork)
   MemoryQueue *mq_ = nullptr;
+  int ring_id_ = -1;  // this sampler's HBM message ring (eng_queue.h), -1: none
   pthread_barrier_t *sampler_barrier_ = nullptr;
   std::thread extract_thread_, sample_thread_;
   std::atomic<bool> shutdown_{false};

@@ -1,6 +1,9 @@
 #include "eng_queue.h"
 
 #include <sys/mman.h>
+#include <unistd.h>
+
+#include <cstring>
 
 #include <chrono>
 #include <thread>
@@ -21,7 +24,98 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
   for (size_t i = 0; i < num_slots; ++i) {
     sem_init(meta_->sem_list + i, 1, 0);
     sem_init(meta_->release_list + i, 1, 1);
+    meta_->payload_loc[i] = 0;
   }
+  memset(meta_->rings, 0, sizeof(meta_->rings));
+}
+
+bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {
+  SAM_CHECK(ring >= 0 && ring < kMaxRings && !local_ring_[ring]);
+  if (slots == 0) return false;
+  if (slots > (uint32_t)kMaxRingSlots) slots = kMaxRingSlots;
+  RingInfo &r = meta_->rings[ring];
+  void *p = nullptr;
+  if (hipMalloc(&p, (size_t)slots * meta_->mq_nbytes) != hipSuccess) {
+    (void)hipGetLastError();
+    SAM_LOG(kWarning) << "device ring: no HBM for " << slots << " slots; messages use the host ring";
+    return false;
+  }
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    SAM_LOG(kWarning) << "device ring: hipIpcGetMemHandle refused; messages use the host ring";
+    return false;
+  }
+  local_ring_[ring] = p;
+  int dev = 0;
+  SAM_HIP(hipGetDevice(&dev));
+  r.device = dev;
+  r.pid = (int)getpid();
+  r.slots = slots;
+  r.handle = h;
+  for (auto &b : r.busy) b = 0;
+  __sync_synchronize();
+  r.ready = 1;
+  return true;
+}
+
+void *MemoryQueue::ClaimDeviceSlot(int ring, size_t key) {
+  if (ring < 0 || ring >= kMaxRings || !local_ring_[ring]) return nullptr;
+  RingInfo &r = meta_->rings[ring];
+  for (uint32_t i = 0; i < r.slots; ++i) {
+    if (__atomic_load_n(&r.busy[i], __ATOMIC_ACQUIRE) == 0) {  // single claimer per ring: no CAS needed
+      __atomic_store_n(&r.busy[i], 1u, __ATOMIC_RELAXED);
+      meta_->payload_loc[key % meta_->max_size] = ((uint32_t)(ring + 1) << 8) | i;
+      ++r.sent_device;
+      return static_cast<char *>(local_ring_[ring]) + (size_t)i * meta_->mq_nbytes;
+    }
+  }
+  meta_->payload_loc[key % meta_->max_size] = 0;
+  ++r.sent_host;
+  return nullptr;
+}
+
+const void *MemoryQueue::Payload(size_t key, const void *host_msg, bool *on_device) {
+  const uint32_t loc = meta_->payload_loc[key % meta_->max_size];
+  *on_device = loc != 0;
+  if (!loc) return host_msg;
+  const int ring = (int)(loc >> 8) - 1;
+  const uint32_t slot = loc & 0xffu;
+  SAM_CHECK(ring >= 0 && ring < kMaxRings);
+  RingInfo &r = meta_->rings[ring];
+  SAM_CHECK(r.ready && slot < r.slots);
+  void *base = nullptr;
+  if (r.pid == (int)getpid()) {
+    base = local_ring_[ring];
+  } else {
+    if (!mapped_ring_[ring])
+      SAM_HIP(hipIpcOpenMemHandle(&mapped_ring_[ring], r.handle, hipIpcMemLazyEnablePeerAccess));
+    base = mapped_ring_[ring];
+  }
+  SAM_CHECK(base);
+  return static_cast<const char *>(base) + (size_t)slot * meta_->mq_nbytes;
+}
+
+void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {
+  if (ring < 0 || ring >= kMaxRings || !local_ring_[ring]) return;
+  RingInfo &r = meta_->rings[ring];
+  Timer t;
+  for (;;) {
+    bool busy = false;
+    for (uint32_t i = 0; i < r.slots; ++i) busy |= __atomic_load_n(&r.busy[i], __ATOMIC_ACQUIRE) != 0;
+    if (!busy) break;
+    if (t.Passed() >= timeout_s) {
+      if (timeout_s > 0)
+        SAM_LOG(kWarning) << "device ring " << ring << ": messages still unread after " << timeout_s << " s";
+      break;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  SAM_LOG(kInfo) << "device ring " << ring << ": " << r.sent_device << " messages through HBM, " << r.sent_host
+                 << " through the host ring";
+  (void)hipFree(local_ring_[ring]);
+  local_ring_[ring] = nullptr;
 }
 
 void MemoryQueue::PinMemory() {
@@ -54,7 +148,15 @@ bool MemoryQueue::TryRecv(const void **data, size_t *key) {
   return true;
 }
 
-void MemoryQueue::Release(size_t key) { SAM_CHECK(sem_post(meta_->release_list + (key % meta_->max_size)) == 0); }
+void MemoryQueue::Release(size_t key) {
+  uint32_t &loc = meta_->payload_loc[key % meta_->max_size];
+  if (loc) {  // hand the device slot back to its sampler
+    RingInfo &r = meta_->rings[(loc >> 8) - 1];
+    __atomic_store_n(&r.busy[loc & 0xffu], 0u, __ATOMIC_RELEASE);
+    loc = 0;
+  }
+  SAM_CHECK(sem_post(meta_->release_list + (key % meta_->max_size)) == 0);
+}
 
 size_t MaxMessageBytes(size_t batch_size, const size_t *fanout, size_t num_layers, bool have_data) {
   size_t layer_cnt = batch_size, ret = sizeof(TransData);

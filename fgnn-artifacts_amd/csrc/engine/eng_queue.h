@@ -33,11 +33,31 @@ static_assert(sizeof(TransData) == 40, "wire format");
 static_assert(sizeof(GraphData) == 24, "wire format");
 
 constexpr size_t kMaxSlots = 170;  // mq_size, memory_queue.h:46
+constexpr int kMaxRings = 16;      // sampler processes that may own a device ring
+constexpr int kMaxRingSlots = 32;
+
+// Optional HBM hand-off: each sampler owns a small ring of message slots in ITS OWN HBM and exports it
+// with hipIpcGetMemHandle; the payload arrays of a message are packed there, only the headers go to the host slot.
+// A trainer maps the ring once and pulls the arrays device-to-device (over xGMI when it sits on another GPU) instead
+// of the reference's D2H + H2D pair over the host link.  MPMC semantics are unchanged: any trainer takes any message,
+// the host ring still orders and counts them, and a message whose sampler finds no free device slot simply travels
+// through the host slot as before.
+struct RingInfo {
+  int ready;                 // 1 once the handle below is valid
+  int device;
+  int pid;                   // owner process: the same process uses the pointer directly (IPC cannot self-open)
+  uint32_t slots;
+  hipIpcMemHandle_t handle;
+  uint32_t busy[kMaxRingSlots];  // 1 while a published message lives in the slot
+  size_t sent_device, sent_host;  // messages of this sampler by payload location
+};
 
 struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   size_t send_cnt, recv_cnt, max_size, mq_nbytes;
   sem_t sem_list[kMaxSlots];
   sem_t release_list[kMaxSlots];
+  uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
+  RingInfo rings[kMaxRings];
   alignas(256) char data[0];
 };
 
@@ -54,9 +74,23 @@ class MemoryQueue {
   size_t NumSlots() const { return meta_->max_size; }
   size_t Pending() const { return meta_->send_cnt - meta_->recv_cnt; }
 
+  // ---- device ring (see RingInfo) ----
+  // sampler process, after fork, current device = the sampler's: allocates `slots` message slots in HBM and exports
+  // them; false (with a warning) when the platform refuses the IPC handle -- payloads then stay on the host path
+  bool CreateDeviceRing(int ring, uint32_t slots);
+  // sampler: a free slot of its ring for message `key` (nullptr: none free, use the host slot)
+  void *ClaimDeviceSlot(int ring, size_t key);
+  // receiver: where the payload arrays of message `key` live -- the host slot itself (`host_msg`) or the ring slot,
+  // mapped into this process on first use; *on_device tells which
+  const void *Payload(size_t key, const void *host_msg, bool *on_device);
+  // sampler, at shutdown: waits until every published device slot has been released, then frees the ring
+  void DrainDeviceRing(int ring, double timeout_s);
+
  private:
   QueueMeta *meta_;
   size_t total_bytes_;
+  void *local_ring_[kMaxRings] = {};   // rings this process owns
+  void *mapped_ring_[kMaxRings] = {};  // rings of other processes, opened through IPC
 };
 
 // worst-case message size for a config (GetMaxMQSize, task_queue.cc:349-371)
@@ -71,7 +105,8 @@ struct PackArgs {
   int ship_input;        // !UseGPUCache || have_switcher (task_queue.cc:174)
   int ship_cache_index;  // UseGPUCache (task_queue.cc:184)
   int have_data;
-  void *slot;
+  void *slot;            // host slot: headers (and the arrays too when `payload` is null)
+  void *payload;         // device-ring slot for the arrays (same layout and offsets as the host slot), or null
   size_t slot_bytes;
 };
 // enqueues the serialisation of one batch into `slot` (device-visible host memory)

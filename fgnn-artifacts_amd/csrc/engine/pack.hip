@@ -5,6 +5,9 @@
 //   { GraphData{num_src,num_dst,num_edge} row col [data] } x num_layer
 // All sizes are read from the device-side batch summary; the slot is host memory mapped into the
 // GPU's address space, so the stores travel over the host link while the sampler keeps going.
+// With a device-ring slot (eng_queue.h) the arrays are written there instead -- same layout, same
+// offsets -- and only the headers (TransData, GraphData) go to the host slot, where the receiver's
+// CPU parses them.
 #include "eng_queue.h"
 
 namespace sam {
@@ -38,7 +41,11 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
     hdr->num_miss = m.num_miss;
   }
   if (!fits) return;
-  uint32_t *p = hdr->data;
+  // arrays go to the payload slot; `hp` walks the host slot in step for the GraphData headers
+  const bool split = a.payload != nullptr;
+  uint32_t *p = split ? static_cast<TransData *>(a.payload)->data : hdr->data;
+  uint32_t *hp = hdr->data;
+  const uint32_t *p_begin = p;
   if (a.ship_input) { copy_words(p, a.input_nodes, m.num_input); p += m.num_input; }
   copy_words(p, a.output_nodes, m.num_output);
   p += m.num_output;
@@ -58,9 +65,10 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
     const size_t ne = m.num_edge[l];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const uint64_t v[3] = {m.num_src[l], m.num_dst[l], ne};
+      uint32_t *h = hp + (p - p_begin);  // the same offset in the host slot
       for (int k = 0; k < 3; ++k) {
-        p[2 * k] = (uint32_t)v[k];
-        p[2 * k + 1] = (uint32_t)(v[k] >> 32);
+        h[2 * k] = (uint32_t)v[k];
+        h[2 * k + 1] = (uint32_t)(v[k] >> 32);
       }
     }
     p += sizeof(GraphData) / sizeof(uint32_t);

@@ -14,7 +14,7 @@ def _run(tmp_path, *args, env=None):
     p = subprocess.run([sys.executable, RUNNER, args[0], args[1], str(tmp_path)] + [str(a) for a in args[2:]],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
-    return p.stdout
+    return p.stdout + ("\n" + p.stderr if env and "SAMGRAPH_LOG_LEVEL" in env else "")
 
 
 @pytest.mark.parametrize("sample_type", ["khop2", "khop0", "weighted_khop_prefix", "random_walk", "khop1",
@@ -70,6 +70,24 @@ def test_sgnn_baseline_archs(tmp_path, arch, sample_type, workers, cache, mode):
     extracts and trains on its GPU) and arch7 (cuda_loops_arch7.cc: every worker runs its own sample-only engine),
     both over DistAlignedShuffler's equal shares (dist_shuffler_aligned.cc); all workers on cuda:0 here."""
     assert "ok" in _run(tmp_path, arch, sample_type, workers, cache, mode)
+
+
+@pytest.mark.parametrize("slots,mode,args", [
+    (8, "arch5", ["khop2", 1, 1, 0.25, "pipeline"]),
+    (2, "arch5", ["random_walk", 2, 2, 0.2, "inline"]),   # 2 slots per sampler: some messages spill to the host ring
+    (1, "arch5", ["khop2", 2, 1, 0.0, "pipeline"]),
+    (4, "arch3", ["khop2", 0.25, "threads"]),
+    (4, "arch6", ["khop2", 2, 0.25, "inline"]),
+    (4, "switcher", ["khop2"]),
+])
+def test_device_ring_handoff(tmp_path, slots, mode, args):
+    """SAMGRAPH_DEVICE_RING_SLOTS: the message arrays travel through a ring in the sampler's HBM that the receiver maps
+    with hipIpcOpenMemHandle (headers still through the host ring); same batches, bit for bit."""
+    import re
+    out = _run(tmp_path, mode, *args, env={"SAMGRAPH_DEVICE_RING_SLOTS": str(slots), "SAMGRAPH_LOG_LEVEL": "info"})
+    assert "ok" in out
+    used = [(int(a), int(b)) for a, b in re.findall(r"device ring \d+: (\d+) messages through HBM, (\d+) through", out)]
+    assert used and all(a > 0 for a, _ in used), out[-2000:]   # the HBM path really carried messages
 
 
 @pytest.mark.parametrize("sample_type", ["random_walk", "khop2"])
