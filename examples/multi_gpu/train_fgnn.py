@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cache-policy", default="pre_sample", choices=list(sam.cache_policies))
     ap.add_argument("--cache-percentage", type=float, default=0.0)
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="trainers only consume batches: measures sample + hand-off "
+                    "+ extract throughput")
     # PinSAGE (multi_gpu/train_pinsage.py:130-134)
     ap.add_argument("--random-walk-length", type=int, default=3)
     ap.add_argument("--random-walk-restart-prob", type=float, default=0.5)
@@ -82,7 +84,7 @@ def get_run_config(args):
         rc["sample_workers"] = ["cuda:%d" % i for i in range(ns)]
         rc["train_workers"] = ["cuda:%d" % (ns + i) for i in range(nt)]
     rc.update(model=args.model, num_hidden=args.num_hidden, lr=args.lr, dropout=args.dropout,
-              pipeline=not args.no_pipeline)
+              pipeline=not args.no_pipeline, no_train=args.no_train)
     return rc
 
 
@@ -128,7 +130,7 @@ def run_train(worker_id, rc):
     if nt > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev)
     loss_fcn = nn.CrossEntropyLoss().to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=rc["lr"])
+    opt = torch.optim.Adam(model.parameters(), lr=rc["lr"], fused=True)
     num_epoch, num_step = sam.num_epoch(), sam.steps_per_epoch()
     my_step = num_step // nt + (1 if worker_id < num_step % nt else 0)  # multi_gpu/train_graphsage.py:293-298
     get_blocks = sam.get_dgl_blocks_with_weights if rc["model"] == "pinsage" else sam.get_dgl_blocks
@@ -148,11 +150,16 @@ def run_train(worker_id, rc):
             key = sam.get_next_batch()
             blocks, batch_input, batch_label = get_blocks(key, num_layer)
             t1 = time.time()
-            loss = loss_fcn(model(blocks, batch_input), batch_label)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            torch.cuda.synchronize(dev)  # the batch's buffers go back to the pool at the next get_next_batch
+            if not rc["no_train"]:
+                loss = loss_fcn(model(blocks, batch_input), batch_label)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            else:
+                loss = 0.0
+            # the batch's buffers go back to the pool at the next get_next_batch: wait for THIS stream's work only
+            # (event_sync of the reference's scripts), not for the extractor thread's copies of the next batches
+            torch.cuda.current_stream().synchronize()
             t_copy += t1 - t0
             t_train += time.time() - t1
         totals.append(time.time() - tic)
@@ -185,7 +192,7 @@ def main():
     rc = get_run_config(args)
     ns, nt = rc["num_sample_worker"], rc["num_train_worker"]
     sam.config({k: v for k, v in rc.items() if isinstance(v, (int, float, str, list)) and k not in
-                ("sample_workers", "train_workers", "model")})
+                ("sample_workers", "train_workers", "model", "no_train")})
     sam.data_init()  # before fork: nothing here touches the GPU
     ctx = mp.get_context("fork")
     rc["global_barrier"] = ctx.Barrier(ns + nt)

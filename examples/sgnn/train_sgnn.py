@@ -106,7 +106,7 @@ def run_worker(worker_id, rc):
     if nw > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev)
     loss_fcn = nn.CrossEntropyLoss().to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=rc["lr"])
+    opt = torch.optim.Adam(model.parameters(), lr=rc["lr"], fused=True)
     num_epoch, num_step = sam.num_epoch(), sam.num_local_step()
     get_blocks = sam.get_dgl_blocks_with_weights if rc["model"] == "pinsage" else sam.get_dgl_blocks
     model.train()
@@ -131,7 +131,9 @@ def run_worker(worker_id, rc):
             opt.zero_grad()
             loss.backward()
             opt.step()
-            torch.cuda.synchronize(dev)  # the batch's buffers go back to the pool at the next get_next_batch
+            # the batch's buffers go back to the pool at the next get_next_batch: wait for THIS stream's work only
+            # (event_sync of the reference's scripts), not for the extractor thread's copies of the next batches
+            torch.cuda.current_stream().synchronize()
             t_sample += t1 - t0
             t_copy += t2 - t1
             t_train += time.time() - t2

@@ -80,7 +80,7 @@ def main():
     num_layer = len(args.fanout)
     model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout).to(dev)
     loss_fcn = nn.CrossEntropyLoss()
-    opt = th.optim.Adam(model.parameters(), lr=args.lr)
+    opt = th.optim.Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel per step instead of one per tensor and op
     num_epoch, num_step = sam.num_epoch(), sam.steps_per_epoch()
     model.train()
     epoch_total, epoch_sample, epoch_copy, epoch_train, edges = [], [], [], [], 0
@@ -97,7 +97,9 @@ def main():
             opt.zero_grad()
             loss.backward()
             opt.step()
-            th.cuda.synchronize()  # the batch's buffers are released at the next get_next_batch
+            # the batch's buffers go back to the pool at the next get_next_batch: wait for THIS stream's work only
+            # (event_sync of the reference's scripts), not for the extractor thread's copies of the next batches
+            th.cuda.current_stream().synchronize()
             t_train += time.time() - t1
             if epoch == num_epoch - 1:
                 edges += sam.get_log_step_value(epoch, step, sam.kLogL1NumSample)

@@ -251,6 +251,9 @@ void Engine::InitInProcess() {
     int err = 0;
     s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
     SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    // a stream per slot: the chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to
+    // stay ordered with events); one batch alone cannot fill the chip
+    SAM_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
@@ -387,6 +390,9 @@ void Engine::SampleInit(int worker_id, Context ctx) {
     int err = 0;
     s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
     SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    // a stream per slot: the chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to
+    // stay ordered with events); one batch alone cannot fill the chip
+    SAM_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
@@ -479,12 +485,12 @@ void Engine::SampleOnceArch5() {
   SAM_CHECK(!s.pending);
   s.started = Timer();
   s.key = key;
-  SAM_HIP(hipEventRecord(s.e0, stream_));
-  SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, stream_));
-  SAM_HIP(hipEventRecord(s.e1, stream_));
+  SAM_HIP(hipEventRecord(s.e0, s.st));
+  SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, s.st));
+  SAM_HIP(hipEventRecord(s.e1, s.st));
   const bool use_cache = RC().UseGPUCache();
-  if (use_cache) SAM_FGNN(fgnn_batch_cache_index(s.fb, d_cache_table_, stream_));
-  SAM_HIP(hipEventRecord(s.e2, stream_));
+  if (use_cache) SAM_FGNN(fgnn_batch_cache_index(s.fb, d_cache_table_, s.st));
+  SAM_HIP(hipEventRecord(s.e2, s.st));
   // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
   void *slot = mq_->GetPtr(&s.mq_key);
   PackArgs a;
@@ -504,8 +510,8 @@ void Engine::SampleOnceArch5() {
   a.slot = DeviceVisible(slot);
   a.payload = mq_->ClaimDeviceSlot(ring_id_, s.mq_key);  // null: no device ring, or none of its slots is free
   a.slot_bytes = mq_->SlotBytes();
-  SAM_FGNN(LaunchPack(a, stream_));
-  SAM_FGNN(fgnn_batch_finish(s.fb, stream_));
+  SAM_FGNN(LaunchPack(a, s.st));
+  SAM_FGNN(fgnn_batch_finish(s.fb, s.st));
   s.pending = true;
   // publish the PREVIOUS batch now that this one is in flight (the reference's PIPELINE branch,
   // dist_loops_arch5.cc:108-146); the last batch of an epoch is flushed immediately
@@ -782,6 +788,8 @@ void Engine::Shutdown() {
   if (extract_thread_.joinable()) extract_thread_.join();
   if (dist_type_ == DistType::Sample || sampler_) PublishPending();
   if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto &sl : slots_)
+    if (sl.st) (void)hipStreamSynchronize(sl.st);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
   if (mq_ && ring_id_ >= 0) {
     // messages published into this sampler's HBM ring must stay readable until their receivers have copied them
@@ -798,6 +806,7 @@ void Engine::Shutdown() {
     if (s.e0) (void)hipEventDestroy(s.e0);
     if (s.e1) (void)hipEventDestroy(s.e1);
     if (s.e2) (void)hipEventDestroy(s.e2);
+    if (s.st) (void)hipStreamDestroy(s.st);
   }
   slots_.clear();
   if (sampler_) {

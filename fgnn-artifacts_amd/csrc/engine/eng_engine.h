@@ -157,6 +157,7 @@ class Engine {
     fgnn_batch *fb = nullptr;
     bool busy = false;           // arch1: handed to the trainer
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    hipStream_t st = nullptr;    // arch2-6: the slot's own stream
     // arch5: message being written
     bool pending = false;
     size_t mq_key = 0;

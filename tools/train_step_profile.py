@@ -32,7 +32,7 @@ b1 = Block(torch.randint(0, 88000, (80000,), device=dev, generator=g, dtype=torc
 x = torch.randn(528000, 128, device=dev)
 y = torch.randint(0, 172, (8000,), device=dev)
 model = SAGE(128, 256, 172, 2, 0.5).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=0.003)
+opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=os.environ.get('ADAM_FUSED', '1') == '1')
 lossf = nn.CrossEntropyLoss()
 
 
@@ -57,4 +57,4 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get('ROWS', '30')), max_name_column_width=70))
