@@ -114,7 +114,7 @@ void RunConfig::Parse(const char **keys, const char **vals, size_t n) {
   option_sanity_check = EnvOn("SAMGRAPH_SANITY_CHECK");
   if (const char *e = getenv("SAMGRAPH_EMPTY_FEAT")) option_empty_feat = strtoull(e, nullptr, 10);
   if (const char *e = getenv("SAMGRAPH_MQ_BYTES")) mq_budget_bytes = strtoull(e, nullptr, 10);
-  if (const char *e = getenv("SAMGRAPH_DEVICE_RING_SLOTS")) device_ring_slots = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("SAMGRAPH_DEVICE_RING_SLOTS")) device_ring_slots = strtol(e, nullptr, 10);
   switch (sample_type) {
     case kKHop0: case kKHop1: case kKHop2: case kWeightedKHop: case kWeightedKHopPrefix: case kRandomWalk: break;
     case kWeightedKHopHashDedup:

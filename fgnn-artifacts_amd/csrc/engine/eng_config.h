@@ -40,7 +40,13 @@ struct RunConfig {
   bool option_dump_trace = false, option_sanity_check = false;
   size_t option_empty_feat = 0;
   size_t mq_budget_bytes = 8ull << 30;  // SAMGRAPH_MQ_BYTES: total size of the shared queue
-  size_t device_ring_slots = 0;         // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h)
+  // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h).  Unset: 4 where sampler and
+  // extractor share a process (arch2-4, arch6: a plain device pointer), 0 for arch5 (needs hipIpc between processes)
+  long device_ring_slots = -1;
+  size_t DeviceRingSlots() const {
+    if (device_ring_slots >= 0) return (size_t)device_ring_slots;
+    return run_arch == kArch5 ? 0 : 4;
+  }
 
   bool UseGPUCache() const { return cache_percentage > 0 && run_arch != kArch1; }  // run_config.h:84-86
   void Parse(const char **keys, const char **vals, size_t n);

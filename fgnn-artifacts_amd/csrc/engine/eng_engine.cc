@@ -242,7 +242,7 @@ void Engine::InitInProcess() {
   // sampler half
   UploadTopology(RC().sampler_ctx.device_id);
   mq_->PinMemory();
-  if (mq_->CreateDeviceRing(0, (uint32_t)RC().device_ring_slots)) ring_id_ = 0;
+  if (mq_->CreateDeviceRing(0, (uint32_t)RC().DeviceRingSlots())) ring_id_ = 0;
   CreateSampler();
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, 0, 1, stream_));
@@ -378,7 +378,7 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   mq_->PinMemory();
   {
     const int ring = arch6 ? 0 : worker_id;  // an arch6 queue is private to its worker
-    if (ring < kMaxRings && mq_->CreateDeviceRing(ring, (uint32_t)RC().device_ring_slots)) ring_id_ = ring;
+    if (ring < kMaxRings && mq_->CreateDeviceRing(ring, (uint32_t)RC().DeviceRingSlots())) ring_id_ = ring;
   }
   CreateSampler();
   // arch6: equal shares of the padded train set (DistAlignedShuffler, dist_engine.cc:276-281)
