@@ -41,11 +41,12 @@ struct RunConfig {
   size_t option_empty_feat = 0;
   size_t mq_budget_bytes = 8ull << 30;  // SAMGRAPH_MQ_BYTES: total size of the shared queue
   // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h).  Unset: 4 where sampler and
-  // extractor share a process (arch2-4, arch6: a plain device pointer), 0 for arch5 (needs hipIpc between processes)
+  // extractor share a process (arch2-4, arch6: a plain device pointer), 16 for arch5 (mapped by the trainers with
+  // hipIpc; a trainer that cannot map it makes the whole job fall back to the host ring)
   long device_ring_slots = -1;
   size_t DeviceRingSlots() const {
     if (device_ring_slots >= 0) return (size_t)device_ring_slots;
-    return run_arch == kArch5 ? 0 : 4;
+    return run_arch == kArch5 ? 16 : 4;
   }
 
   bool UseGPUCache() const { return cache_percentage > 0 && run_arch != kArch1; }  // run_config.h:84-86

@@ -27,6 +27,7 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
     meta_->payload_loc[i] = 0;
   }
   memset(meta_->rings, 0, sizeof(meta_->rings));
+  meta_->ipc_broken = 0;
 }
 
 bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {
@@ -55,17 +56,46 @@ bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {
   r.slots = slots;
   r.handle = h;
   for (auto &b : r.busy) b = 0;
+  for (auto &b : r.spill) b = 0;
+  r.sent_device = r.sent_host = r.spilled = 0;
   __sync_synchronize();
   r.ready = 1;
+  svc_stop_ = false;
+  svc_ = std::thread([this, ring, dev] {
+    (void)hipSetDevice(dev);
+    while (!svc_stop_) {
+      // requests only ever appear after a receiver has flagged the mapping as broken
+      if (*(volatile int *)&meta_->ipc_broken) {
+        ServiceSpills(ring);
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+      } else {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+    }
+  });
   return true;
+}
+
+void MemoryQueue::ServiceSpills(int ring) {
+  RingInfo &r = meta_->rings[ring];
+  for (uint32_t i = 0; i < r.slots; ++i) {
+    if (__atomic_load_n(&r.spill[i], __ATOMIC_ACQUIRE) != 1) continue;
+    // the device slot holds the complete message (headers included): overwrite the host slot with it
+    char *host = meta_->data + (r.slot_key[i] % meta_->max_size) * meta_->mq_nbytes;
+    const char *dev = static_cast<const char *>(local_ring_[ring]) + (size_t)i * meta_->mq_nbytes;
+    SAM_HIP(hipMemcpy(host, dev, meta_->mq_nbytes, hipMemcpyDeviceToHost));
+    ++r.spilled;
+    __atomic_store_n(&r.spill[i], 2u, __ATOMIC_RELEASE);
+  }
 }
 
 void *MemoryQueue::ClaimDeviceSlot(int ring, size_t key) {
   if (ring < 0 || ring >= kMaxRings || !local_ring_[ring]) return nullptr;
   RingInfo &r = meta_->rings[ring];
-  for (uint32_t i = 0; i < r.slots; ++i) {
+  for (uint32_t i = 0; i < r.slots && !*(volatile int *)&meta_->ipc_broken; ++i) {
     if (__atomic_load_n(&r.busy[i], __ATOMIC_ACQUIRE) == 0) {  // single claimer per ring: no CAS needed
       __atomic_store_n(&r.busy[i], 1u, __ATOMIC_RELAXED);
+      r.slot_key[i] = key;
       meta_->payload_loc[key % meta_->max_size] = ((uint32_t)(ring + 1) << 8) | i;
       ++r.sent_device;
       return static_cast<char *>(local_ring_[ring]) + (size_t)i * meta_->mq_nbytes;
@@ -89,8 +119,31 @@ const void *MemoryQueue::Payload(size_t key, const void *host_msg, bool *on_devi
   if (r.pid == (int)getpid()) {
     base = local_ring_[ring];
   } else {
-    if (!mapped_ring_[ring])
-      SAM_HIP(hipIpcOpenMemHandle(&mapped_ring_[ring], r.handle, hipIpcMemLazyEnablePeerAccess));
+    if (!mapped_ring_[ring] && !*(volatile int *)&meta_->ipc_broken) {
+      // SAMGRAPH_DEVICE_RING_FORCE_SPILL=1 (tests): behave as if the mapping had been refused
+      const char *force = getenv("SAMGRAPH_DEVICE_RING_FORCE_SPILL");
+      hipError_t e = (force && atoi(force)) ? hipErrorInvalidValue
+                                            : hipIpcOpenMemHandle(&mapped_ring_[ring], r.handle,
+                                                                  hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        mapped_ring_[ring] = nullptr;
+        SAM_LOG(kWarning) << "device ring " << ring << ": cannot map the sampler's HBM ring (" << hipGetErrorString(e)
+                          << "); messages go through the host ring from now on";
+        __atomic_store_n(&meta_->ipc_broken, 1, __ATOMIC_RELEASE);
+      }
+    }
+    if (!mapped_ring_[ring]) {
+      // ask the owner to copy this message into its host slot, then read it there
+      __atomic_store_n(&r.spill[slot], 1u, __ATOMIC_RELEASE);
+      Timer t;
+      while (__atomic_load_n(&r.spill[slot], __ATOMIC_ACQUIRE) != 2) {
+        SAM_CHECK(t.Passed() < 120.0) << "device ring " << ring << ": the sampler does not answer the spill request";
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+      *on_device = false;
+      return host_msg;
+    }
     base = mapped_ring_[ring];
   }
   SAM_CHECK(base);
@@ -112,8 +165,10 @@ void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {
     }
     std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
+  svc_stop_ = true;
+  if (svc_.joinable()) svc_.join();
   SAM_LOG(kInfo) << "device ring " << ring << ": " << r.sent_device << " messages through HBM, " << r.sent_host
-                 << " through the host ring";
+                 << " through the host ring, " << r.spilled << " copied back on request";
   (void)hipFree(local_ring_[ring]);
   local_ring_[ring] = nullptr;
 }
@@ -152,6 +207,7 @@ void MemoryQueue::Release(size_t key) {
   uint32_t &loc = meta_->payload_loc[key % meta_->max_size];
   if (loc) {  // hand the device slot back to its sampler
     RingInfo &r = meta_->rings[(loc >> 8) - 1];
+    __atomic_store_n(&r.spill[loc & 0xffu], 0u, __ATOMIC_RELAXED);
     __atomic_store_n(&r.busy[loc & 0xffu], 0u, __ATOMIC_RELEASE);
     loc = 0;
   }

@@ -9,6 +9,9 @@
 #pragma once
 #include <semaphore.h>
 
+#include <atomic>
+#include <thread>
+
 #include <cstddef>
 #include <cstdint>
 
@@ -34,7 +37,7 @@ static_assert(sizeof(GraphData) == 24, "wire format");
 
 constexpr size_t kMaxSlots = 170;  // mq_size, memory_queue.h:46
 constexpr int kMaxRings = 16;      // sampler processes that may own a device ring
-constexpr int kMaxRingSlots = 32;
+constexpr int kMaxRingSlots = (int)kMaxSlots;  // slot index travels in 8 bits (payload_loc)
 
 // Optional HBM hand-off: each sampler owns a small ring of message slots in ITS OWN HBM and exports it
 // with hipIpcGetMemHandle; the payload arrays of a message are packed there, only the headers go to the host slot.
@@ -50,6 +53,11 @@ struct RingInfo {
   hipIpcMemHandle_t handle;
   uint32_t busy[kMaxRingSlots];  // 1 while a published message lives in the slot
   size_t sent_device, sent_host;  // messages of this sampler by payload location
+  // fallback when a receiver cannot map the ring (hipIpcOpenMemHandle refused): it asks the owner to copy the slot
+  // into the message's host slot -- 0 none, 1 requested, 2 done; the owner's service thread answers
+  uint32_t spill[kMaxRingSlots];
+  size_t slot_key[kMaxRingSlots];  // queue key of the message in the slot
+  size_t spilled;
 };
 
 struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
@@ -57,6 +65,7 @@ struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   sem_t sem_list[kMaxSlots];
   sem_t release_list[kMaxSlots];
   uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
+  int ipc_broken;                   // set by the first receiver that could not map a ring: samplers stop using theirs
   RingInfo rings[kMaxRings];
   alignas(256) char data[0];
 };
@@ -89,8 +98,11 @@ class MemoryQueue {
  private:
   QueueMeta *meta_;
   size_t total_bytes_;
+  void ServiceSpills(int ring);
   void *local_ring_[kMaxRings] = {};   // rings this process owns
   void *mapped_ring_[kMaxRings] = {};  // rings of other processes, opened through IPC
+  std::thread svc_;                    // answers spill requests for the ring this process owns
+  std::atomic<bool> svc_stop_{false};
 };
 
 // worst-case message size for a config (GetMaxMQSize, task_queue.cc:349-371)

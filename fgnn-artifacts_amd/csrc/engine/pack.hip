@@ -33,12 +33,17 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
     bytes += sizeof(GraphData) + m.num_edge[l] * (a.have_data ? 3 : 2) * sizeof(uint32_t);
   const bool fits = bytes <= a.slot_bytes && m.overflow == 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    hdr->have_data = a.have_data != 0;
-    hdr->num_layer = fits ? (int)m.num_layers : -1;  // -1: the receiver aborts (CHECK_LE at task_queue.cc:162)
-    hdr->key = m.key;
-    hdr->input_size = m.num_input;
-    hdr->output_size = m.num_output;
-    hdr->num_miss = m.num_miss;
+    // the device-ring slot gets the headers too: it is a complete message (copied back to the host slot as it is
+    // when a receiver cannot map the ring)
+    for (TransData *h : {hdr, static_cast<TransData *>(a.payload)}) {
+      if (!h) continue;
+      h->have_data = a.have_data != 0;
+      h->num_layer = fits ? (int)m.num_layers : -1;  // -1: the receiver aborts (CHECK_LE at task_queue.cc:162)
+      h->key = m.key;
+      h->input_size = m.num_input;
+      h->output_size = m.num_output;
+      h->num_miss = m.num_miss;
+    }
   }
   if (!fits) return;
   // arrays go to the payload slot; `hp` walks the host slot in step for the GraphData headers
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
       const uint64_t v[3] = {m.num_src[l], m.num_dst[l], ne};
       uint32_t *h = hp + (p - p_begin);  // the same offset in the host slot
       for (int k = 0; k < 3; ++k) {
-        h[2 * k] = (uint32_t)v[k];
-        h[2 * k + 1] = (uint32_t)(v[k] >> 32);
+        h[2 * k] = p[2 * k] = (uint32_t)v[k];
+        h[2 * k + 1] = p[2 * k + 1] = (uint32_t)(v[k] >> 32);
       }
     }
     p += sizeof(GraphData) / sizeof(uint32_t);

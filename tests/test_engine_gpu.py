@@ -79,15 +79,29 @@ def test_sgnn_baseline_archs(tmp_path, arch, sample_type, workers, cache, mode):
     (4, "arch3", ["khop2", 0.25, "threads"]),
     (4, "arch6", ["khop2", 2, 0.25, "inline"]),
     (4, "switcher", ["khop2"]),
+    (0, "arch5", ["khop2", 2, 1, 0.25, "pipeline"]),      # the reference's path: everything through the host ring
+    (-1, "arch5", ["khop2", 2, 2, 0.25, "pipeline"]),     # a receiver that cannot map the ring: copied back on request
 ])
 def test_device_ring_handoff(tmp_path, slots, mode, args):
-    """SAMGRAPH_DEVICE_RING_SLOTS: the message arrays travel through a ring in the sampler's HBM that the receiver maps
-    with hipIpcOpenMemHandle (headers still through the host ring); same batches, bit for bit."""
+    """SAMGRAPH_DEVICE_RING_SLOTS (default: 16 for arch5, 4 in-process): the message arrays travel through a ring in the
+    sampler's HBM that the receiver maps with hipIpcOpenMemHandle (headers still through the host ring); same batches,
+    bit for bit.  slots == -1 here: default slots, but the receivers pretend the mapping was refused."""
     import re
-    out = _run(tmp_path, mode, *args, env={"SAMGRAPH_DEVICE_RING_SLOTS": str(slots), "SAMGRAPH_LOG_LEVEL": "info"})
+    env = {"SAMGRAPH_LOG_LEVEL": "info"}
+    if slots >= 0:
+        env["SAMGRAPH_DEVICE_RING_SLOTS"] = str(slots)
+    else:
+        env["SAMGRAPH_DEVICE_RING_FORCE_SPILL"] = "1"
+    out = _run(tmp_path, mode, *args, env=env)
     assert "ok" in out
-    used = [(int(a), int(b)) for a, b in re.findall(r"device ring \d+: (\d+) messages through HBM, (\d+) through", out)]
-    assert used and all(a > 0 for a, _ in used), out[-2000:]   # the HBM path really carried messages
+    used = [tuple(int(x) for x in m) for m in
+            re.findall(r"device ring \d+: (\d+) messages through HBM, (\d+) through the host ring, (\d+) copied", out)]
+    if slots == 0:
+        assert not used
+    elif slots > 0:
+        assert used and all(a > 0 and c == 0 for a, _, c in used), out[-2000:]  # the HBM path really carried messages
+    else:
+        assert used and sum(c for _, _, c in used) > 0 and "cannot map the sampler's HBM ring" in out, out[-2000:]
 
 
 @pytest.mark.parametrize("sample_type", ["random_walk", "khop2"])
