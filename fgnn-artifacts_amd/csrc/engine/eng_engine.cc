@@ -400,6 +400,9 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   if (RC().UseGPUCache()) {
     Timer tp;
     if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) {
+      // every worker stops here, not only the one that would have pre-sampled (dist/pre_sampler.cc:87-88)
+      SAM_CHECK(RC().cache_policy != kCacheByPreSampleStatic)
+          << "kCacheByPreSampleStatic is not implemented in DistEngine now!";
       if (worker_id == 0) PreSample();
       int rc = pthread_barrier_wait(sampler_barrier_);
       SAM_CHECK(rc == 0 || rc == PTHREAD_BARRIER_SERIAL_THREAD);
@@ -414,6 +417,13 @@ void Engine::SampleInit(int worker_id, Context ctx) {
 }
 
 void Engine::PreSample() {
+  if (RC().cache_policy == kCacheByPreSampleStatic) {
+    // the multi-process engine has none (dist/pre_sampler.cc:87-88)
+    SAM_CHECK(RC().run_arch != kArch5 && RC().run_arch != kArch6)
+        << "kCacheByPreSampleStatic is not implemented in DistEngine now!";
+    PreSampleStatic();
+    return;
+  }
   // frequency ranking over presample_epoch epochs of the sampling path (dist/pre_sampler.cc:75-162)
   const int epochs = RC().presample_epoch > 0 ? RC().presample_epoch : 1;
   Shuffler sh(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, epochs, RC().batch_size, 0, 1, stream_);
@@ -432,6 +442,44 @@ void Engine::PreSample() {
   }
   PresampleRank(d_freq, ds_.num_node, ds_.ranking_nodes, stream_);
   (void)hipFree(d_freq);
+}
+
+void Engine::PreSampleStatic() {
+  // cuda/pre_sampler.cc:57-109 with DoGPUSampleAllNeighbour (cuda_loops.cc:500-571) as the "sampler": the access
+  // frequency of a node = the number of batches whose closed L-hop neighbourhood holds it -- no random draw anywhere.
+  // The neighbourhoods are grown level by level against a stamp array over the node ids (fgnn_neighbourhood_expand);
+  // batch b stamps with b, so nothing is reset between batches and no size is read back by the host.
+  const int epochs = RC().presample_epoch > 0 ? RC().presample_epoch : 1;
+  const size_t layers = RC().fanout.size();  // GetFanout().size(): num_layer copies of num_neighbor for random walks
+  Shuffler sh(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, epochs, RC().batch_size, 0, 1, stream_);
+  const size_t n = ds_.num_node;
+  uint32_t *d_freq = nullptr, *d_stamp = nullptr, *d_front[2] = {nullptr, nullptr}, *d_count = nullptr;
+  SAM_HIP(hipMalloc(&d_freq, n * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_stamp, n * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_front[0], n * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_front[1], n * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_count, (layers + 1) * sizeof(uint32_t)));
+  SAM_HIP(hipMemsetAsync(d_freq, 0, n * sizeof(uint32_t), stream_));
+  SAM_HIP(hipMemsetAsync(d_stamp, 0, n * sizeof(uint32_t), stream_));
+  const uint32_t *d_batch;
+  size_t bsize;
+  uint32_t mark = 0;
+  while (sh.GetBatch(&d_batch, &bsize)) {
+    ++mark;  // < 2^32 batches: stamps never repeat
+    SAM_HIP(hipMemsetAsync(d_count, 0, (layers + 1) * sizeof(uint32_t), stream_));
+    for (size_t l = 0; l < layers; ++l) {
+      const uint32_t *front = l == 0 ? d_batch : d_front[(l - 1) & 1];
+      SAM_FGNN(fgnn_neighbourhood_expand(d_indptr_, d_indices_, front, l == 0 ? bsize : 0, l == 0 ? nullptr : d_count + l,
+                                         l == 0 ? bsize : n, d_stamp, mark, d_freq, d_front[l & 1], n, d_count + l + 1,
+                                         l == 0 ? 1 : 0, stream_));
+    }
+  }
+  PresampleRank(d_freq, n, ds_.ranking_nodes, stream_);
+  (void)hipFree(d_freq);
+  (void)hipFree(d_stamp);
+  (void)hipFree(d_front[0]);
+  (void)hipFree(d_front[1]);
+  (void)hipFree(d_count);
 }
 
 void Engine::BuildCacheTable() {

@@ -119,6 +119,7 @@ class Engine {
   void CreateQueue();
   // arch5 sampler
   void PreSample();
+  void PreSampleStatic();
   void BuildCacheTable();
   void SampleOnceArch5();
   void PublishPending();

@@ -27,6 +27,7 @@ EXPORTS = [
     "fgnn_hashtable_create", "fgnn_hashtable_create_ex", "fgnn_hashtable_destroy", "fgnn_hashtable_capacity", "fgnn_hashtable_reset",
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
+    "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
     "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
 ]
 
@@ -52,6 +53,8 @@ def load():
         L.fgnn_debug_phase_log.argtypes = [C.c_void_p]
         L.fgnn_scratch_bytes.restype = C.c_size_t
         L.fgnn_scratch_bytes.argtypes = [C.c_size_t]
+        L.fgnn_extract_neighbour_scratch_bytes.restype = C.c_size_t
+        L.fgnn_extract_neighbour_scratch_bytes.argtypes = [C.c_size_t]
         L.fgnn_hashtable_create.restype = C.c_void_p
         L.fgnn_hashtable_create.argtypes = [C.c_size_t, C.POINTER(C.c_int)]
         L.fgnn_hashtable_destroy.argtypes = [C.c_void_p]
@@ -258,6 +261,34 @@ def _wrap_device_u32(ptr, n, device):
     if n == 0:
         return torch.empty(0, dtype=torch.int32, device=device)
     return torch.as_tensor(_DevArray(ptr, n, "<i4"), device=device)
+
+
+def extract_neighbour(indptr, indices, inp, out_cap, num_input=None, d_num_input=None):
+    """GPUExtractNeighbour: returns (out[out_cap], d_num_out int64[1]) device tensors.  Asynchronous."""
+    L = load()
+    _need_gpu(indptr, indices, inp)
+    cap = inp.numel()
+    n = cap if num_input is None else num_input
+    dev = inp.device
+    out = torch.empty(max(out_cap, 1), dtype=torch.int32, device=dev)
+    d_num_out = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.fgnn_extract_neighbour_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+    _check(L.fgnn_extract_neighbour(_ptr(indptr), _ptr(indices), _ptr(inp), C.c_size_t(n), _ptr(d_num_input),
+                                    C.c_size_t(cap), _ptr(out), C.c_size_t(out_cap), _ptr(d_num_out), _ptr(ws),
+                                    C.c_size_t(ws.numel()), _stream()), "fgnn_extract_neighbour")
+    return out, d_num_out
+
+
+def neighbourhood_expand(indptr, indices, frontier, stamp, mark, freq, nxt, d_num_next, mark_frontier=False,
+                         num_frontier=None, d_num_frontier=None):
+    """One level of the closed-neighbourhood search (fgnn_neighbourhood_expand); d_num_next (int32[1]) is added to."""
+    _need_gpu(indptr, indices, frontier, stamp, nxt, d_num_next)
+    cap = frontier.numel()
+    n = cap if num_frontier is None else num_frontier
+    _check(load().fgnn_neighbourhood_expand(_ptr(indptr), _ptr(indices), _ptr(frontier), C.c_size_t(n),
+                                            _ptr(d_num_frontier), C.c_size_t(cap), _ptr(stamp), C.c_uint32(mark),
+                                            _ptr(freq), _ptr(nxt), C.c_size_t(nxt.numel()), _ptr(d_num_next),
+                                            C.c_int(1 if mark_frontier else 0), _stream()), "fgnn_neighbourhood_expand")
 
 
 def get_miss_cache_index(table, nodes, num_nodes=None, d_num_nodes=None, ws=None):

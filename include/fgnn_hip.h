@@ -122,6 +122,28 @@ int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *indices, con
                             uint32_t *out_data, size_t *d_num_out, int src_mode, uint64_t seed,
                             uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- whole neighbourhoods (no sampling) ----------------------------------------------------- */
+
+/* GPUExtractNeighbour (cuda_function.h:93-97, cuda_extract_neighbour.cu:111-169): every neighbour of every input node,
+ * input order, CSR order inside a row (the reference emits in a tile-internal order; its consumers only dedup the list).
+ * *d_num_out (size_t, device) = number of neighbours (exact below 2^32); at most out_cap ids are written (out_cap = 0:
+ * count only).  Scratch: fgnn_extract_neighbour_scratch_bytes(num_input_cap). */
+size_t fgnn_extract_neighbour_scratch_bytes(size_t num_input_cap);
+int fgnn_extract_neighbour(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,
+                           const uint32_t *d_num_input, size_t num_input_cap, uint32_t *out, size_t out_cap,
+                           size_t *d_num_out, void *ws, size_t ws_bytes, void *stream);
+/* One layer of DoGPUSampleAllNeighbour (cuda_loops.cc:526-565: GPUExtractNeighbour + FillWithDupMutable), the "sampler"
+ * of the static pre-sampling policy, with the dedup done by a direct-map stamp array over the node ids: every neighbour
+ * u of frontier[0 .. n) with stamp[u] != mark gets stamp[u] = mark, freq[u] += 1 (freq may be NULL) and is appended to
+ * next[] (order unspecified; ids beyond next_cap are counted but not stored).  *d_num_next (uint32, device) is ADDED to:
+ * zero it before the call.  mark_frontier != 0: the frontier nodes themselves are stamped and counted first (the seeds,
+ * FillWithUnique).  Levels are expanded from the previous level's `next` only, which reaches the same closed
+ * neighbourhood as the reference's re-expansion of everything seen so far. */
+int fgnn_neighbourhood_expand(const uint32_t *indptr, const uint32_t *indices, const uint32_t *frontier,
+                              size_t num_frontier, const uint32_t *d_num_frontier, size_t frontier_cap, uint32_t *stamp,
+                              uint32_t mark, uint32_t *freq, uint32_t *next, size_t next_cap, uint32_t *d_num_next,
+                              int mark_frontier, void *stream);
+
 /* ---- dedup / remap: OrderedHashTable (cuda_hashtable.h:99-149) ---------------------------- */
 
 typedef struct fgnn_hashtable fgnn_hashtable;

@@ -658,6 +658,42 @@ void fgnn_oracle_presample_rank(const uint32_t *freq, size_t num_node, uint32_t 
   free(t);
 }
 
+size_t fgnn_oracle_extract_neighbour(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                                     size_t num_input, uint32_t *out) {
+  size_t n = 0;
+  for (size_t i = 0; i < num_input; ++i) {
+    const uint32_t off = indptr[input[i]], len = indptr[input[i] + 1] - off; /* count_edge, :53-58 */
+    if (out) memcpy(out + n, indices + off, sizeof(uint32_t) * len);          /* compact_edge, :86-105 */
+    n += len;
+  }
+  return n;
+}
+
+size_t fgnn_oracle_sample_all_neighbour(const uint32_t *indptr, const uint32_t *indices, const uint32_t *seeds,
+                                        size_t num_seeds, size_t num_layers, size_t num_node, uint32_t *input_nodes) {
+  uint8_t *seen = (uint8_t *)calloc(num_node ? num_node : 1, 1);
+  size_t n = 0;
+  for (size_t i = 0; i < num_seeds; ++i) { /* FillWithUnique, cuda_loops.cc:512-517 */
+    seen[seeds[i]] = 1;
+    input_nodes[n++] = seeds[i];
+  }
+  for (size_t l = 0; l < num_layers; ++l) { /* :526-565: input = unique = everything seen so far */
+    const size_t num_input = n;
+    for (size_t i = 0; i < num_input; ++i) {
+      const uint32_t v = input_nodes[i];
+      for (uint32_t e = indptr[v]; e < indptr[v + 1]; ++e) { /* GPUExtractNeighbour + FillWithDupMutable */
+        const uint32_t u = indices[e];
+        if (!seen[u]) {
+          seen[u] = 1;
+          input_nodes[n++] = u;
+        }
+      }
+    }
+  }
+  free(seen);
+  return n;
+}
+
 /* ------------------------------------------------------------------ shufflers -------------- */
 
 /* std::minstd_rand0: x <- 16807 x mod (2^31 - 1); seed 0 maps to 1; min 1, max 2^31-2. */

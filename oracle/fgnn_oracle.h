@@ -219,6 +219,19 @@ void fgnn_oracle_combine(void *out, const void *rows, const uint32_t *src_index 
 /* Presample ranking, dist/pre_sampler.cc:131-162: sort desc of (freq << 32 | node). */
 void fgnn_oracle_presample_rank(const uint32_t *freq, size_t num_node, uint32_t *ranking_nodes);
 
+/* GPUExtractNeighbour, cuda/cuda_extract_neighbour.cu:41-169: every neighbour of every input node (count_edge ->
+ * ExclusiveSum -> compact_edge).  The reference emits in a tile-internal order (thread t of a 1024-item tile writes the
+ * rows of items t, t+256, ... back to back); its only consumers feed the list to a dedup, so the restatement uses input
+ * order, CSR order within a row.  out == NULL: count only.  Returns the number of neighbours. */
+size_t fgnn_oracle_extract_neighbour(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
+                                     size_t num_input, uint32_t *out);
+/* DoGPUSampleAllNeighbour, cuda/cuda_loops.cc:500-571 (the kCacheByPreSampleStatic pre-sampler's "sampler",
+ * cuda/pre_sampler.cc:69-71): FillWithUnique(seeds); per layer GPUExtractNeighbour of ALL nodes seen so far ->
+ * FillWithDupMutable; input_nodes = every node seen (the closed num_layers-hop neighbourhood of the seeds), here in
+ * first-occurrence order.  input_nodes holds up to num_node ids.  Returns their number. */
+size_t fgnn_oracle_sample_all_neighbour(const uint32_t *indptr, const uint32_t *indices, const uint32_t *seeds,
+                                        size_t num_seeds, size_t num_layers, size_t num_node, uint32_t *input_nodes);
+
 /* ---------------------------------------------------------------- shufflers ---------------- */
 
 /* The shufflers' explicit Fisher-Yates: for i = n-1..1: swap(data[i], data[d(0,i)(g)]) with

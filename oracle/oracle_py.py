@@ -297,6 +297,32 @@ def presample_rank(freq):
     return out
 
 
+def extract_neighbour(indptr, indices, inp):
+    indptr, pp = _u32(indptr)
+    indices, pi = _u32(indices)
+    inp, pn = _u32(inp)
+    fn = lib().fgnn_oracle_extract_neighbour
+    fn.restype = C.c_size_t
+    n = fn(pp, pi, pn, C.c_size_t(len(inp)), None)
+    out = np.empty(n, dtype=np.uint32)
+    fn(pp, pi, pn, C.c_size_t(len(inp)), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def sample_all_neighbour(indptr, indices, seeds, num_layers):
+    """input_nodes of DoGPUSampleAllNeighbour (first-occurrence order)"""
+    indptr, pp = _u32(indptr)
+    indices, pi = _u32(indices)
+    seeds, ps = _u32(seeds)
+    num_node = len(indptr) - 1
+    out = np.empty(num_node, dtype=np.uint32)
+    fn = lib().fgnn_oracle_sample_all_neighbour
+    fn.restype = C.c_size_t
+    n = fn(pp, pi, ps, C.c_size_t(len(seeds)), C.c_size_t(num_layers), C.c_size_t(num_node),
+           out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out[:n].copy()
+
+
 def shuffle_minstd0(data, seed):
     data = np.ascontiguousarray(data, dtype=np.uint32).copy()
     lib().fgnn_oracle_shuffle_minstd0(data.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(len(data)),

@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 SEED = 0x5A4D47
 NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, 2000
 BATCH, NUM_EPOCH = 256, 2
+# FGNN_TEST_CACHE_POLICY=static: the kCacheByPreSampleStatic policy (whole neighbourhoods instead of sampled ones)
+STATIC_PRESAMPLE = os.environ.get("FGNN_TEST_CACHE_POLICY", "") == "static"
 
 
 def dataset(workdir, sample_type):
@@ -32,8 +34,9 @@ def dataset(workdir, sample_type):
 
 def base_config(path, arch, sample_type):
     import samgraph.common as sc
+    policy = sc.kCacheByPreSampleStatic if STATIC_PRESAMPLE else sc.kCacheByPreSample
     cfg = dict(dataset_path=path, _arch=arch, _sample_type=sc.sample_types[sample_type], batch_size=BATCH,
-               num_epoch=NUM_EPOCH, _cache_policy=sc.kCacheByPreSample, cache_percentage=0.0, max_sampling_jobs=10,
+               num_epoch=NUM_EPOCH, _cache_policy=policy, cache_percentage=0.0, max_sampling_jobs=10,
                max_copying_jobs=2, omp_thread_num=8, seed=SEED, presample_epoch=1, barriered_epoch=0)
     if sample_type == "random_walk":
         cfg.update(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4, num_neighbor=5, num_layer=3)
@@ -95,8 +98,11 @@ class OracleReplay:
         data = self.o.shuffle_minstd0(data, 0)
         for step in range(self.plain_step):
             seeds = data[step * BATCH:(step + 1) * BATCH]
-            t = self._sample(seeds, (1 << 63) | step)
-            np.add.at(freq, t["input_nodes"], 1)
+            if STATIC_PRESAMPLE:  # DoGPUSampleAllNeighbour: no draw, no khop2 row mutation
+                nodes = self.o.sample_all_neighbour(self.indptr, self.indices, seeds, len(self.fan))
+            else:
+                nodes = self._sample(seeds, (1 << 63) | step)["input_nodes"]
+            np.add.at(freq, nodes, 1)
         self.rank = self.o.presample_rank(freq)
 
     def epochs(self):
@@ -190,18 +196,30 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
     assert sam.steps_per_epoch() == rep.num_step and sam.num_epoch() == NUM_EPOCH
     if threaded:
         sam.start()
-    n = 0
+    n = miss_total = 0
     for key, seeds, task in rep.epochs():
         if not threaded:
             sam.sample_once()
         got = sam.get_next_batch()
         assert got == key, (got, key)
         check_batch(sam, key, seeds, task, rep, "%s key %d" % (arch, key))
+        if cache_pct > 0:
+            # the ranking itself is observable through the miss volume of every batch (kLogL1MissBytes,
+            # cuda_loops.cc:1098-1101): rows of nodes outside the first num_cached entries of the rank list
+            cached = np.zeros(NUM_NODE, dtype=bool)
+            cached[rep.rank[:int(NUM_NODE * cache_pct)]] = True
+            misses = int((~cached[task["input_nodes"]]).sum())
+            epoch, step = key // rep.num_step, key % rep.num_step
+            assert sam.get_log_step_value(epoch, step, sam.kLogL1MissBytes) == misses * DIM * 4, (key, misses)
+            miss_total += misses
         n += 1
     assert n == NUM_EPOCH * rep.num_step
     sam.report_step_average(NUM_EPOCH - 1, rep.num_step - 1)
     sam.shutdown()
-    print("%s %s cache %.2f %s ok: %d batches" % (arch, sample_type, cache_pct, "threads" if threaded else "inline", n))
+    print("%s %s cache %.2f %s%s ok: %d batches, %d miss rows" % (arch, sample_type, cache_pct,
+                                                                "threads" if threaded else "inline",
+                                                                " static-presample" if STATIC_PRESAMPLE else "", n,
+                                                                miss_total))
 
 
 def _join_all(procs, roles, limit=600.0):

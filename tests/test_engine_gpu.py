@@ -44,6 +44,24 @@ def test_single_process_two_role_archs(tmp_path, arch, sample_type, cache, mode)
     assert "ok" in _run(tmp_path, arch, sample_type, cache, mode)
 
 
+@pytest.mark.parametrize("arch,sample_type,cache,mode", [("arch3", "khop2", 0.25, "inline"),
+                                                         ("arch2", "random_walk", 0.1, "threads")])
+def test_static_presample_policy(tmp_path, arch, sample_type, cache, mode):
+    """kCacheByPreSampleStatic: frequencies over whole L-hop neighbourhoods (cuda/pre_sampler.cc:69-71,
+    DoGPUSampleAllNeighbour); the ranking is checked through the miss volume of every batch."""
+    out = _run(tmp_path, arch, sample_type, cache, mode, env={"FGNN_TEST_CACHE_POLICY": "static"})
+    assert "static-presample ok" in out
+
+
+def test_static_presample_is_refused_by_the_multi_process_engine(tmp_path):
+    """dist/pre_sampler.cc:87-88: LOG(FATAL) "kCacheByPreSampleStatic is not implemented in DistEngine now!" """
+    p = subprocess.run([sys.executable, RUNNER, "arch5", "khop2", str(tmp_path), "1", "1", "0.25"],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FGNN_TEST_CACHE_POLICY="static"))
+    assert p.returncode != 0
+    assert "kCacheByPreSampleStatic is not implemented in DistEngine now!" in p.stderr
+
+
 @pytest.mark.parametrize("sample_type,ns,nt,cache,mode", [
     ("khop2", 1, 1, 0.25, "pipeline"),       # BASELINE config 3 in miniature: 1S + 1T, presample cache
     ("khop2", 1, 1, 0.0, "inline"),          # no cache: input nodes shipped, all rows fetched from host memory

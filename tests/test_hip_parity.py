@@ -659,3 +659,76 @@ def test_tall_linear_matches_nn_linear():
     torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 3000])
+def test_extract_neighbour_matches_oracle(hip, oracle, graph, n):
+    """GPUExtractNeighbour (cuda_extract_neighbour.cu:111-169): all neighbours, input order, exact count on the device"""
+    indptr, indices = graph
+    d_indptr, d_indices = dev(indptr), dev(indices)
+    inp = _seeds(n, len(indptr) - 1, seed=n)
+    want = oracle.extract_neighbour(indptr, indices, inp)
+    out, d_num = hip.extract_neighbour(d_indptr, d_indices, dev(inp) if n else torch.empty(0, dtype=torch.int32,
+                                                                                         device="cuda"),
+                                       max(len(want), 1))
+    assert int(d_num.item()) == len(want)
+    np.testing.assert_array_equal(host_u32(out, len(want)), want)
+    if n >= 256:
+        # count on the device (capacity > count), output clipped at out_cap, count-only call
+        cap_inp = np.concatenate([inp, np.zeros(500, dtype=np.uint32)])
+        d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+        clip = len(want) // 2
+        out, d_num = hip.extract_neighbour(d_indptr, d_indices, dev(cap_inp), clip, num_input=0, d_num_input=d_n)
+        assert int(d_num.item()) == len(want)
+        np.testing.assert_array_equal(host_u32(out, clip), want[:clip])
+        out, d_num = hip.extract_neighbour(d_indptr, d_indices, dev(inp), 0)
+        assert int(d_num.item()) == len(want)
+
+
+@pytest.mark.gpu
+def test_extract_neighbour_long_and_empty_rows(hip, oracle):
+    """a row far longer than a tile's worth of lanes between empty rows"""
+    deg = np.zeros(600, dtype=np.uint32)
+    deg[[3, 4, 300, 599]] = [70000, 1, 513, 2]
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint32)
+    indices = np.random.default_rng(3).integers(0, 600, int(indptr[-1]), dtype=np.uint32)
+    inp = np.array([0, 3, 1, 2, 599, 4, 5, 300, 3] + list(range(6, 290)), dtype=np.uint32)
+    want = oracle.extract_neighbour(indptr, indices, inp)
+    out, d_num = hip.extract_neighbour(dev(indptr), dev(indices), dev(inp), len(want))
+    assert int(d_num.item()) == len(want)
+    np.testing.assert_array_equal(host_u32(out, len(want)), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,batch", [(1, 40), (2, 300), (3, 7)])
+def test_neighbourhood_expand_matches_oracle(hip, oracle, graph, layers, batch):
+    """DoGPUSampleAllNeighbour (cuda_loops.cc:500-571) as level-wise expansion over a stamp array: same closed
+    neighbourhoods, same access counts over several batches"""
+    indptr, indices = graph
+    n = len(indptr) - 1
+    d_indptr, d_indices = dev(indptr), dev(indices)
+    stamp = torch.zeros(n, dtype=torch.int32, device="cuda")
+    freq = torch.zeros(n, dtype=torch.int32, device="cuda")
+    want_freq = np.zeros(n, dtype=np.uint32)
+    fronts = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    for b in range(4):
+        seeds = _seeds(batch, n, seed=100 + b)
+        want = oracle.sample_all_neighbour(indptr, indices, seeds, layers)
+        want_freq[want] += 1
+        counts = torch.zeros(layers + 1, dtype=torch.int32, device="cuda")
+        seen = [seeds]
+        for l in range(layers):
+            hip.neighbourhood_expand(d_indptr, d_indices, dev(seeds) if l == 0 else fronts[(l - 1) & 1], stamp, b + 1,
+                                     freq, fronts[l & 1], counts[l + 1:l + 2], mark_frontier=(l == 0),
+                                     num_frontier=batch if l == 0 else 0,
+                                     d_num_frontier=None if l == 0 else counts[l:l + 1])
+            seen.append(host_u32(fronts[l & 1], int(counts[l + 1].item())).copy())
+        got = np.concatenate(seen)
+        assert len(got) == len(want) and len(np.unique(got)) == len(got)
+        np.testing.assert_array_equal(np.sort(got), np.sort(want))
+        # level structure: level l holds exactly the nodes first reached after l hops
+        assert set(seen[0].tolist()) == set(want[:batch].tolist())
+    np.testing.assert_array_equal(host_u32(freq), want_freq)
+    # stamps: every node ever reached carries the mark of the last batch that reached it
+    assert int((host_u32(stamp) != 0).sum()) == int((want_freq != 0).sum())

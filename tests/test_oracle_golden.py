@@ -256,3 +256,26 @@ print("same")
     # own process: the reference keeps its mt19937 thread_local per process, it must start fresh
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert p.returncode == 0 and "same" in p.stdout, p.stderr[-2000:]
+
+
+def test_all_neighbour_restatement_is_the_closed_neighbourhood(oracle):
+    """DoGPUSampleAllNeighbour (cuda_loops.cc:500-571) has no random draw: its input_nodes are the closed L-hop
+    neighbourhood of the seeds.  Checked against sparse matrix reachability (T2: formula read from the source)."""
+    import scipy.sparse as sp
+    from fgnn_hip import synth
+    indptr, indices = synth.powerlaw_csr(500, 4000, seed=5)
+    n = len(indptr) - 1
+    a = sp.csr_matrix((np.ones(len(indices), dtype=np.int64), indices.astype(np.int64), indptr.astype(np.int64)),
+                      shape=(n, n))
+    seeds = np.random.default_rng(9).permutation(n)[:11].astype(np.uint32)
+    nbrs = oracle.extract_neighbour(indptr, indices, seeds)
+    np.testing.assert_array_equal(nbrs, np.concatenate([indices[indptr[s]:indptr[s + 1]] for s in seeds]))
+    for layers in (0, 1, 2, 3):
+        reach = np.zeros(n, dtype=np.int64)
+        reach[seeds] = 1
+        for _ in range(layers):
+            reach = reach + a.T.dot(reach)  # row v lists the neighbours v pulls in
+        got = oracle.sample_all_neighbour(indptr, indices, seeds, layers)
+        np.testing.assert_array_equal(got[:len(seeds)], seeds)
+        assert len(np.unique(got)) == len(got)
+        np.testing.assert_array_equal(np.sort(got), np.flatnonzero(reach).astype(np.uint32))
