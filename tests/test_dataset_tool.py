@@ -54,6 +54,47 @@ def test_rankings_and_weight_tables(tool, tmp_path):
         assert (np.diff(seg) >= 1.0).all() and (seg[:1] >= 1.0).all()
 
 
+def test_heuristic_degree_hop_rankings_and_64bit_copies(tool, tmp_path):
+    """cache_by_heuristic.cc:54-88, cache_by_degree_hop.cc:30-165 and generator/32to64.cc:33-82 restated in numpy"""
+    from fgnn_hip import synth
+    num_node = 2000
+    d = synth.write_dataset(str(tmp_path), "g", num_node, 9000, 4, 5, 40, 20, 20, seed=8)
+    indptr = np.fromfile(os.path.join(d, "indptr.bin"), dtype=np.uint32).astype(np.int64)
+    indices = np.fromfile(os.path.join(d, "indices.bin"), dtype=np.uint32)
+    train = np.fromfile(os.path.join(d, "train_set.bin"), dtype=np.uint32)
+
+    def by_degree(deg):  # descending (degree, id)
+        return np.lexsort((-np.arange(num_node), -deg.astype(np.int64))).astype(np.uint32)
+
+    out_deg = np.bincount(indices, minlength=num_node)
+    _run(tool, "cache-by-heuristic", d)
+    want, seen = list(train), set(train.tolist())
+    for v in train:
+        for u in indices[indptr[v]:indptr[v + 1]]:
+            if u not in seen:
+                seen.add(u)
+                want.append(u)
+    want += [v for v in by_degree(out_deg) if v not in seen]
+    np.testing.assert_array_equal(np.fromfile(os.path.join(d, "cache_by_heuristic.bin"), dtype=np.uint32),
+                                  np.array(want, dtype=np.uint32))
+    _run(tool, "cache-by-degree-hop", d)
+    reached = np.zeros(num_node, dtype=bool)
+    reached[train] = True
+    for _ in range(2):
+        rows = np.flatnonzero(reached)
+        reached[np.concatenate([indices[indptr[v]:indptr[v + 1]] for v in rows])] = True
+    rows = np.flatnonzero(reached)
+    sub = np.bincount(np.concatenate([indices[indptr[v]:indptr[v + 1]] for v in rows]), minlength=num_node)
+    deg = np.where(reached, sub | 0x40000000, out_deg)
+    got = np.fromfile(os.path.join(d, "cache_by_degree_hop.bin"), dtype=np.uint32)
+    np.testing.assert_array_equal(got, by_degree(deg))
+    assert 0 < reached.sum() < num_node and reached[got[:reached.sum()]].all()
+    _run(tool, "32to64", d)
+    for name in ("indptr", "indices", "train_set", "test_set", "valid_set"):
+        a32 = np.fromfile(os.path.join(d, name + ".bin"), dtype=np.uint32)
+        np.testing.assert_array_equal(np.fromfile(os.path.join(d, name + "64.bin"), dtype=np.uint64), a32)
+
+
 def test_cache_by_random_matches_standard_library_golden(tool, tmp_path, golden_dir):
     d = tmp_path / "g"
     d.mkdir()

@@ -3,13 +3,17 @@
 //
 //   fgnn_dataset cache-by-degree   <dir>                 -> cache_by_degree.bin   (u32[N] node ranking)
 //   fgnn_dataset cache-by-random   <dir>                 -> cache_by_random.bin
+//   fgnn_dataset cache-by-heuristic <dir>                -> cache_by_heuristic.bin (train set, its neighbours, rest by degree)
+//   fgnn_dataset cache-by-degree-hop <dir>               -> cache_by_degree_hop.bin (degree inside the 2-hop reach first)
+//   fgnn_dataset 32to64            <dir>                 -> indptr64.bin, indices64.bin, {train,test,valid}_set64.bin
 //   fgnn_dataset prob-prefix-table <dir> [policy]        -> prob_prefix_table.bin (f32[E], per-row inclusive sums)
 //   fgnn_dataset alias-table       <dir> [policy]        -> prob_table.bin (f32[E]) + alias_table.bin (u32[E], node ids)
 //   fgnn_dataset coo-to-dataset    <dir> <coo.bin>       -> indptr.bin, indices.bin, {train,valid,test}_set.bin
 //   fgnn_dataset check             <dir>                 -> validates meta.txt against the CSR files
 //
 // What each file must contain follows the reference's generators (utility/data-process/toolkit/cache/
-// cache_by_degree.cc:29-62, cache_by_random.cc:29-50, weight/create_prob_prefix_table.cc:87-136,
+// cache_by_degree.cc:29-62, cache_by_random.cc:29-50, cache_by_heuristic.cc:29-101, cache_by_degree_hop.cc:30-165,
+// generator/32to64.cc:33-82, weight/create_prob_prefix_table.cc:87-136,
 // weight/create_alias_table.cc:95-190, generator/coo_to_dataset.cc:128-222, property/csr_checker.cc); the weight
 // policies are kSrcSuffix (default), kInverseSrcDegreeRand, kDefault and kInverseBothDegreeRand -- the last two draw
 // random weights, here from a generator seeded per row so that runs are reproducible (the reference seeds from
@@ -117,6 +121,92 @@ int CacheByRandom(const Dataset &d) {
     std::swap(rank[d.num_node - i - 1], rank[pick(gen)]);
   }
   WriteFile(d.dir + "cache_by_random.bin", rank);
+  return 0;
+}
+
+std::vector<uint32_t> RankByDegreeDesc(const std::vector<uint32_t> &deg) {
+  std::vector<uint32_t> rank(deg.size());
+  for (size_t i = 0; i < deg.size(); ++i) rank[i] = (uint32_t)i;
+  std::sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) { return deg[a] != deg[b] ? deg[a] > deg[b] : a > b; });
+  return rank;
+}
+
+std::vector<uint32_t> TrainSet(const Dataset &d) {
+  return ReadFile<uint32_t>(d.dir + "train_set.bin", d.meta.at("NUM_TRAIN_SET"));
+}
+
+// cache_by_heuristic.cc:54-88: the train set in file order, then its not yet listed neighbours in row order, then
+// everything else by descending (out-degree, id)
+int CacheByHeuristic(const Dataset &d) {
+  const std::vector<uint32_t> by_degree = RankByDegreeDesc(OutDegrees(d));
+  const std::vector<uint32_t> train = TrainSet(d);
+  std::vector<uint32_t> rank;
+  rank.reserve(d.num_node);
+  std::vector<bool> added(d.num_node, false);
+  for (uint32_t v : train) {
+    if (v >= d.num_node) Die("train_set.bin holds a node id >= NUM_NODE");
+    if (added[v]) Die("train_set.bin lists a node twice");
+    added[v] = true;
+    rank.push_back(v);
+  }
+  for (uint32_t v : train)
+    for (uint32_t e = d.indptr[v]; e < d.indptr[v + 1]; ++e) {
+      const uint32_t u = d.indices[e];
+      if (!added[u]) {
+        added[u] = true;
+        rank.push_back(u);
+      }
+    }
+  for (uint32_t v : by_degree)
+    if (!added[v]) {
+      added[v] = true;
+      rank.push_back(v);
+    }
+  if (rank.size() != d.num_node) Die("node number mismatch");
+  WriteFile(d.dir + "cache_by_heuristic.bin", rank);
+  return 0;
+}
+
+// cache_by_degree_hop.cc:30-165: nodes the train set reaches within two hops are ranked first, by their out-degree
+// counted over the rows of reached nodes only (flag 0x40000000 on the degree); the others follow by whole-graph
+// out-degree.  (The reference leaves the row lengths of unreached nodes uninitialised, :86-93; zero is what it means.)
+int CacheByDegreeHop(const Dataset &d) {
+  std::vector<uint32_t> deg = OutDegrees(d);
+  std::vector<uint8_t> reached(d.num_node, 0), frontier(d.num_node, 0);
+  for (uint32_t v : TrainSet(d)) reached[v] = frontier[v] = 1;
+  for (int hop = 0; hop < 2; ++hop) {
+    std::vector<uint8_t> next(d.num_node, 0);
+    for (size_t v = 0; v < d.num_node; ++v) {
+      if (!frontier[v]) continue;
+      for (uint32_t e = d.indptr[v]; e < d.indptr[v + 1]; ++e)
+        if (!reached[d.indices[e]]) next[d.indices[e]] = 1;
+    }
+    for (size_t v = 0; v < d.num_node; ++v)
+      if (next[v]) reached[v] = 1;
+    frontier.swap(next);
+  }
+  std::vector<uint32_t> sub(d.num_node, 0);
+  for (size_t v = 0; v < d.num_node; ++v)
+    if (reached[v])
+      for (uint32_t e = d.indptr[v]; e < d.indptr[v + 1]; ++e) ++sub[d.indices[e]];
+  for (size_t v = 0; v < d.num_node; ++v)
+    if (reached[v]) deg[v] = sub[v] | 0x40000000u;
+  WriteFile(d.dir + "cache_by_degree_hop.bin", RankByDegreeDesc(deg));
+  return 0;
+}
+
+// generator/32to64.cc:33-82: 64-bit copies of the topology and node sets for the loaders of the DGL / PyG baselines
+int To64(const Dataset &d) {
+  auto widen = [&](const std::vector<uint32_t> &v, const std::string &name) {
+    WriteFile(d.dir + name, std::vector<uint64_t>(v.begin(), v.end()));
+  };
+  widen(d.indptr, "indptr64.bin");
+  widen(d.indices, "indices64.bin");
+  for (const char *set : {"train", "test", "valid"}) {
+    std::string key = std::string("NUM_") + set + "_SET";
+    for (auto &c : key) c = (char)toupper(c);
+    widen(ReadFile<uint32_t>(d.dir + set + "_set.bin", d.meta.at(key)), std::string(set) + "_set64.bin");
+  }
   return 0;
 }
 
@@ -276,7 +366,7 @@ int Check(const Dataset &d) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  if (argc < 3) Die("usage: fgnn_dataset <cache-by-degree|cache-by-random|prob-prefix-table|alias-table|coo-to-dataset|check> <dir> [arg]");
+  if (argc < 3) Die("usage: fgnn_dataset <cache-by-degree|cache-by-random|cache-by-heuristic|cache-by-degree-hop|32to64|prob-prefix-table|alias-table|coo-to-dataset|check> <dir> [arg]");
   const std::string cmd = argv[1];
   if (cmd == "coo-to-dataset") {
     if (argc < 4) Die("coo-to-dataset needs <dir> <coo.bin>");
@@ -285,6 +375,9 @@ int main(int argc, char **argv) {
   const Dataset d = Load(argv[2]);
   if (cmd == "cache-by-degree") return CacheByDegree(d);
   if (cmd == "cache-by-random") return CacheByRandom(d);
+  if (cmd == "cache-by-heuristic") return CacheByHeuristic(d);
+  if (cmd == "cache-by-degree-hop") return CacheByDegreeHop(d);
+  if (cmd == "32to64") return To64(d);
   if (cmd == "prob-prefix-table") return ProbPrefixTable(d, ParsePolicy(argc > 3 ? argv[3] : nullptr));
   if (cmd == "alias-table") return AliasTable(d, ParsePolicy(argc > 3 ? argv[3] : nullptr));
   if (cmd == "check") return Check(d);
