@@ -14,6 +14,7 @@
 //    lane of a wave is busy for any feature width (D=100 -> 25 chunks, D=128 -> 32, D=256 -> 64) and
 //    several independent 16-byte loads are in flight per lane; a scalar path covers rows whose byte
 //    length is not a multiple of 16 (labels: dim 1 x 8 B).
+#include <algorithm>
 #include <cstdlib>
 
 #include "fgnn_device.h"
@@ -426,6 +427,39 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
       default: FGNN_ELEM(unsigned long long); break;
     }
 #undef FGNN_ELEM
+  }
+  return launch_status(__func__);
+}
+
+// ---- dynamic cache index (the arch4 prototype): GPUDynamicCacheManager::ReplaceCacheGPU -----------------------------
+namespace fgnn {
+namespace {
+// hashtable_reset_nodes / hashtable_insert_nodes (cuda_cache_manager_device.cu:212-246): insert == false writes
+// EMPTY at the listed nodes, insert == true writes each node's position in the list
+__global__ __launch_bounds__(kBlock) void cache_table_scatter_kernel(uint32_t *table, const uint32_t *nodes, size_t n,
+                                                                     const uint32_t *d_n, size_t cap, bool insert) {
+  const size_t count = resolve_count(n, d_n, cap);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride)
+    table[nodes[i]] = insert ? (uint32_t)i : FGNN_EMPTY_KEY;
+}
+}  // namespace
+}  // namespace fgnn
+
+extern "C" int fgnn_cache_table_replace(uint32_t *table, const uint32_t *old_nodes, size_t num_old,
+                                        const uint32_t *new_nodes, size_t num_new, void *stream) {
+  if (!table || (num_old && !old_nodes) || (num_new && !new_nodes)) return FGNN_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t most = (size_t)device_cu_count() * 8;
+  if (num_old) {
+    const size_t blocks = std::min(div_up(num_old, kBlock), most);
+    hipLaunchKernelGGL(cache_table_scatter_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, table, old_nodes,
+                       num_old, (const uint32_t *)nullptr, num_old, false);
+  }
+  if (num_new) {
+    const size_t blocks = std::min(div_up(num_new, kBlock), most);
+    hipLaunchKernelGGL(cache_table_scatter_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, table, new_nodes,
+                       num_new, (const uint32_t *)nullptr, num_new, true);
   }
   return launch_status(__func__);
 }

@@ -176,6 +176,7 @@ void Engine::ReleaseBatch(GraphBatch *b) {
   b->pooled.clear();
   for (void *p : b->host_owned) free(p);
   b->host_owned.clear();
+  b->shared.clear();
   if (b->fb) {
     for (auto &s : slots_)
       if (s.fb == b->fb) s.busy = false;
@@ -236,17 +237,21 @@ void Engine::InitSingleGPU(bool extract) {
 void Engine::InitInProcess() {
   SAM_CHECK(RC().sampler_ctx.IsGPU() && RC().trainer_ctx.IsGPU())
       << "arch2-4 need cuda contexts: the sampling path has no CPU fallback";
-  SAM_CHECK(RC().cache_policy != kDynamicCache) << "the dynamic cache prototype (arch4) is not built";
+  // the dynamic cache only exists in arch4's loops (cuda_loops_arch4.cc:218-240); arch2 / arch3 ignore the policy
+  const bool dynamic = RC().cache_policy == kDynamicCache && RC().run_arch == kArch4;
+  if (dynamic) SAM_CHECK(!RC().UseGPUCache()) << "dynamic_cache takes no cache_percentage (cuda_engine.cc:148-178)";
   Timer t;
-  CreateQueue();
+  if (!dynamic) CreateQueue();
   // sampler half
   UploadTopology(RC().sampler_ctx.device_id);
-  mq_->PinMemory();
-  if (mq_->CreateDeviceRing(0, (uint32_t)RC().DeviceRingSlots())) ring_id_ = 0;
-  CreateSampler();
+  if (!dynamic) {
+    mq_->PinMemory();
+    if (mq_->CreateDeviceRing(0, (uint32_t)RC().DeviceRingSlots())) ring_id_ = 0;
+    CreateSampler();
+  }
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, 0, 1, stream_));
-  slots_.resize(2);
+  slots_.resize(dynamic ? 0 : 2);  // the dynamic-cache loop (eng_dynamic.cc) hands batches over in process, no messages
   for (auto &s : slots_) {
     int err = 0;
     s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
@@ -278,6 +283,7 @@ void Engine::InitInProcess() {
   SAM_HIP(hipMemcpy(d_label_, ds_.label.ptr, ds_.label.bytes, hipMemcpyHostToDevice));
   if (RC().UseGPUCache()) BuildTrainerCache();
   pool_.reset(new GraphPool(RC().max_copying_jobs));
+  if (dynamic) InitDynamicCache();
   Profiler::Get().LogInit(kLogInitL1Trainer, tt.Passed());
   initialized_ = true;
 }
@@ -792,6 +798,10 @@ void Engine::RunSampleOnce() {
     // (dist_loops_arch6.cc:209-216): sample + publish, then copy/extract
     SAM_CHECK(!sample_thread_.joinable()) << "samgraph_sample_once after samgraph_start";
     SAM_CHECK(tstream_) << "arch6: samgraph_train_init has not run in this worker";
+    if (dyn_) {  // RunArch4LoopsOnce with UseDynamicGPUCache (cuda_loops_arch4.cc:216-223)
+      SampleOnceDynamic();
+      return;
+    }
     SampleOnceArch5();
     PublishPending();
     TrainerOnce();
@@ -820,6 +830,12 @@ void Engine::Start() {
   if (sample_thread_.joinable()) return;
   // the sampler thread and the copy/extract thread of cuda_loops_arch3.cc:178-196; each handles every batch of the run
   const size_t total = RC().num_epoch * num_step_;
+  if (dyn_) {  // one thread walks sample -> cache copy per batch (see eng_dynamic.cc on the reference's two)
+    sample_thread_ = std::thread([this, total]() {
+      for (size_t i = 0; i < total && !shutdown_; ++i) SampleOnceDynamic();
+    });
+    return;
+  }
   sample_thread_ = std::thread([this, total]() {
     for (size_t i = 0; i < total && !shutdown_; ++i) SampleOnceArch5();
     if (!shutdown_) PublishPending();
@@ -848,6 +864,10 @@ void Engine::Shutdown() {
   if (current_) {
     ReleaseBatch(current_.get());
     current_.reset();
+  }
+  if (dyn_) {  // queued batches share buffers with the cache state: drop them before the pools they return to
+    pool_.reset();
+    dyn_.reset();
   }
   for (auto &s : slots_) {
     if (s.fb) fgnn_batch_destroy(s.fb);

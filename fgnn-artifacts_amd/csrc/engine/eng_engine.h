@@ -57,6 +57,7 @@ struct GraphBatch {      // Task, common.h:205-222 (trainer-side view)
   fgnn_batch *fb = nullptr;           // arch1: pooled sampler-side buffers
   std::vector<void *> pooled;         // arch5 trainer: DevicePool allocations
   std::vector<void *> host_owned;     // malloc'd host arrays
+  std::vector<std::shared_ptr<void>> shared;  // arch4 dynamic cache: buffers the engine may keep using as the cache
 };
 
 class GraphPool {        // graph_pool.cc:31-62
@@ -75,6 +76,9 @@ class GraphPool {        // graph_pool.cc:31-62
 };
 
 enum class DistType { Default, Sample, Extract, Switch };
+
+struct DynamicCache;  // eng_dynamic.cc
+struct DynamicCacheDeleter { void operator()(DynamicCache *p) const; };
 
 class Engine {
  public:
@@ -123,6 +127,9 @@ class Engine {
   void BuildCacheTable();
   void SampleOnceArch5();
   void PublishPending();
+  // arch4 with the dynamic cache prototype (eng_dynamic.cc)
+  void InitDynamicCache();
+  void SampleOnceDynamic();
   // arch5 trainer
   void TrainerOnce();
   void BuildTrainerCache();
@@ -152,6 +159,7 @@ class Engine {
   std::unique_ptr<GraphPool> pool_;
   std::shared_ptr<GraphBatch> current_;
   DevicePool dev_pool_;
+  std::unique_ptr<DynamicCache, DynamicCacheDeleter> dyn_;  // declared after dev_pool_: destroyed before it
 
   // sampler-side batch buffers
   struct Slot {

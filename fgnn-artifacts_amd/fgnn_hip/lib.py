@@ -28,7 +28,7 @@ EXPORTS = [
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
-    "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
+    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
 ]
 
 _lib = None
@@ -289,6 +289,15 @@ def neighbourhood_expand(indptr, indices, frontier, stamp, mark, freq, nxt, d_nu
                                             _ptr(d_num_frontier), C.c_size_t(cap), _ptr(stamp), C.c_uint32(mark),
                                             _ptr(freq), _ptr(nxt), C.c_size_t(nxt.numel()), _ptr(d_num_next),
                                             C.c_int(1 if mark_frontier else 0), _stream()), "fgnn_neighbourhood_expand")
+
+
+def cache_table_replace(table, old_nodes, new_nodes):
+    """ReplaceCacheGPU's index update: old nodes -> EMPTY, new node i -> i"""
+    _need_gpu(table, old_nodes, new_nodes)
+    n_old = 0 if old_nodes is None else old_nodes.numel()
+    _check(load().fgnn_cache_table_replace(_ptr(table), _ptr(old_nodes) if n_old else C.c_void_p(0), C.c_size_t(n_old),
+                                           _ptr(new_nodes), C.c_size_t(new_nodes.numel()), _stream()),
+           "fgnn_cache_table_replace")
 
 
 def get_miss_cache_index(table, nodes, num_nodes=None, d_num_nodes=None, ws=None):

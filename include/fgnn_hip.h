@@ -194,6 +194,12 @@ int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size
                               uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst,
                               uint32_t *d_counts, void *ws, size_t ws_bytes, void *stream);
 
+/* GPUDynamicCacheManager::ReplaceCacheGPU (cuda_cache_manager_device.cu:212-246,632-708), the index half of the arch4
+ * dynamic-cache prototype: table[old_nodes[i]] = FGNN_EMPTY_KEY for i < num_old, then table[new_nodes[i]] = i for
+ * i < num_new (the rows of the batch that has just been extracted become the cache of the next one). */
+int fgnn_cache_table_replace(uint32_t *table, const uint32_t *old_nodes, size_t num_old, const uint32_t *new_nodes,
+                             size_t num_new, void *stream);
+
 /* ---- row gathers: GPUExtract (cuda_extraction.cu:74-117), CombineMissData / CombineCacheData
  *      (cuda_cache_manager_device.cu:339-442) ------------------------------------------------- */
 

@@ -245,6 +245,41 @@ def do_sample(indptr, indices, seeds, fanout, sample_type, rng, batch_key, ht, p
     return out
 
 
+def do_sample_dycache(indptr, indices, seeds, fanout, sample_type, rng, batch_key, ht, prob=None, alias=None):
+    """DoGPUSampleDyCache restatement (cuda_loops.cc:269-498), the sampler of the arch4 dynamic-cache prototype: after
+    layer 1's dedup the table takes ALL neighbours of every node seen so far (:400-421) and that list is the batch's
+    input_nodes; layer 0 is sampled without inserting (:395-399); edges are mapped at the end (:461-476).
+    `ht` must hold num_node items.  Same result layout as do_sample."""
+    L = len(fanout)
+    assert L >= 2 and sample_type in (KHOP0, KHOP1, WEIGHTED_KHOP)  # :333-357: everything else is CHECK(0)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    ht.reset()
+    ht.fill_unique(seeds)  # :286-291
+    unique, all_nodes, raw = seeds, None, [None] * L
+    for i in range(L - 1, -1, -1):
+        if sample_type == KHOP0:
+            src, dst = sample_khop0(indptr, indices, unique, fanout[i], rng, batch_key, i)
+        elif sample_type == KHOP1:
+            src, dst = sample_khop1(indptr, indices, unique, fanout[i], rng, batch_key, i)
+        else:
+            src, dst = sample_weighted_khop(indptr, indices, prob, alias, unique, fanout[i], rng, batch_key, i)
+        num_input = len(unique)
+        if i == 0:
+            num_unique = len(all_nodes)  # RefUnique of the table as it stands, :399
+        else:
+            unique = ht.fill_duplicates(dst)  # FillWithDupRevised + RefUnique, :402-404 / :423-425
+            num_unique = len(unique)
+            if i == 1:
+                all_nodes = ht.fill_duplicates(extract_neighbour(indptr, indices, unique))  # :408-416
+        raw[i] = (src, dst, num_unique, num_input)
+    graphs, total = [], 0
+    for src, dst, num_src, num_dst in raw:
+        col, row = ht.map_edges(src, dst)  # GPUMapEdges over every layer, :461-476
+        graphs.append(dict(row=row, col=col, data=None, num_src=num_src, num_dst=num_dst, num_edge=len(src)))
+        total += len(src)
+    return dict(graphs=graphs, input_nodes=all_nodes, total_edges=total)
+
+
 def cache_table_build(ranking_nodes, num_cached, num_node):
     r, p = _u32(ranking_nodes)
     table = np.empty(num_node, dtype=np.uint32)

@@ -222,6 +222,48 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
                                                                 miss_total))
 
 
+def run_dynamic(sample_type, workdir, threaded):
+    """arch4 with `_cache_policy = dynamic_cache` (cuda_loops_arch4.cc:56-97,136-187): input nodes are the whole
+    neighbourhood of the layer-1 frontier, hits are rows of the previous batch's feature tensor."""
+    path = dataset(workdir, sample_type)
+    import samgraph.common as sc
+    import samgraph.torch as sam
+    cfg = base_config(path, sam.kArch4, sample_type)
+    cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0", _cache_policy=sc.kDynamicCache, cache_percentage=0.0)
+    sam.config(cfg)
+    sam.init()
+    rep = OracleReplay(path, sample_type)
+    rep.ht = rep.o.HashTable(NUM_NODE, NUM_NODE)
+    kw = {}
+    if sample_type == "weighted_khop":
+        kw = dict(prob=rep.kw["prob_prefix"], alias=rep.kw["alias_table"])
+    rep._sample = lambda seeds, key: rep.o.do_sample_dycache(rep.indptr, rep.indices, seeds, rep.fan, rep.st, rep.rng,
+                                                             key, rep.ht, **kw)
+    assert sam.steps_per_epoch() == rep.num_step
+    if threaded:
+        sam.start()
+    n = hits = 0
+    prev = np.empty(0, dtype=np.uint32)
+    for key, seeds, task in rep.epochs():
+        if not threaded:
+            sam.sample_once()
+        got = sam.get_next_batch()
+        assert got == key, (got, key)
+        check_batch(sam, key, seeds, task, rep, "dynamic key %d" % key)
+        # the cache of this batch was the previous batch's node list (ReplaceCacheGPU, cuda_loops.cc:1261-1265)
+        misses = int((~np.isin(task["input_nodes"], prev)).sum())
+        epoch, step = key // rep.num_step, key % rep.num_step
+        assert sam.get_log_step_value(epoch, step, sam.kLogL1MissBytes) == misses * DIM * 4, (key, misses)
+        hits += len(task["input_nodes"]) - misses
+        prev = task["input_nodes"]
+        assert len(prev) > sum(g["num_edge"] for g in task["graphs"][1:])  # whole neighbourhoods, not samples
+        n += 1
+    assert n == NUM_EPOCH * rep.num_step and hits > 0
+    sam.shutdown()
+    print("dynamic-cache %s %s ok: %d batches, %d rows served by the previous batch" % (
+        sample_type, "threads" if threaded else "inline", n, hits))
+
+
 def _join_all(procs, roles, limit=600.0):
     """Waits for all children; as soon as one dies with an error (or the time is up) the rest are terminated, so a
     failure is reported at once instead of after the survivors' time-outs."""
@@ -471,6 +513,8 @@ if __name__ == "__main__":
         run_arch5_switcher(st, wd)
     elif mode in ("arch6", "arch7"):
         run_sgnn(mode, st, wd, int(sys.argv[4]), float(sys.argv[5]), len(sys.argv) > 6 and sys.argv[6] == "background")
+    elif mode == "dynamic":
+        run_dynamic(st, wd, len(sys.argv) > 4 and sys.argv[4] == "threads")
     elif mode in ("arch2", "arch3", "arch4"):
         run_inproc(mode, st, wd, float(sys.argv[4]), sys.argv[5] == "threads")
     else:

@@ -53,6 +53,13 @@ def test_static_presample_policy(tmp_path, arch, sample_type, cache, mode):
     assert "static-presample ok" in out
 
 
+@pytest.mark.parametrize("sample_type,mode", [("khop0", "inline"), ("khop1", "threads"), ("weighted_khop", "inline")])
+def test_arch4_dynamic_cache(tmp_path, sample_type, mode):
+    """the arch4 dynamic-cache prototype (DoGPUSampleDyCache + DoDynamicCacheFeatureCopy): blocks, the prefetch node
+    list, features and the per-batch miss volume against the oracle's restatement"""
+    assert "dynamic-cache %s %s ok" % (sample_type, mode) in _run(tmp_path, "dynamic", sample_type, mode)
+
+
 def test_static_presample_is_refused_by_the_multi_process_engine(tmp_path):
     """dist/pre_sampler.cc:87-88: LOG(FATAL) "kCacheByPreSampleStatic is not implemented in DistEngine now!" """
     p = subprocess.run([sys.executable, RUNNER, "arch5", "khop2", str(tmp_path), "1", "1", "0.25"],
