@@ -336,6 +336,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   for (long l = (long)L - 1; l >= 0 && num_seeds; --l) {
     const size_t fan = s->cfg.fanout[l];
     const size_t ecap = in_cap * fan;
+    bool resolved = false;
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
     if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX || s->cfg.sample_type == FGNN_KHOP1 ||
         s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
@@ -361,9 +362,13 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     else {
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
+      const bool first = start_in_sampler && l == (long)L - 1;
+      // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
+      // (not when this launch also inserts the seeds: their local ids would replace pending edges without a note)
+      resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
       rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
                              tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
-                             &sl.scan_sample, (start_in_sampler && l == (long)L - 1) ? &start : nullptr);
+                             &sl.scan_sample, first ? &start : nullptr, resolved);
     }
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
@@ -375,7 +380,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted, nullptr, /*final_fill=*/l == 0);
+                                      inserted, nullptr, /*final_fill=*/l == 0, resolved);
     if (rc != FGNN_OK) return rc;
     in_cap += ecap;
     cur = out->input_nodes;

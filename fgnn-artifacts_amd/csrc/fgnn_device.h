@@ -24,6 +24,10 @@ struct fgnn_hashtable {
   uint32_t gen;               // current generation, 0 .. gen_limit - 1
   uint32_t gen_limit;         // (1 << (32 - vp1)) - 1: the all-ones generation marks never-used / wiped buckets
   size_t max_fill_items;      // largest fill (pending index) the value field can hold
+  // "you have been replaced" notes of the resolving insert (ht_insert_resolve): disp[j] = generation | pending | i says
+  // that item i took the key over from pending item j.  Generation-tagged like the buckets, zeroed with the table's
+  // wipe.  Only allocated for tables made with a modest max_fill_items (the batch driver's); null otherwise.
+  uint32_t *disp;
 };
 
 namespace fgnn {
@@ -136,6 +140,70 @@ __device__ __forceinline__ uint32_t ht_insert_min(const HtView &t, uint32_t id, 
     h = (h + 1) & t.mask;
   }
   return kNoBucket;
+}
+
+// ---- resolving insert (last fill of a batch) -----------------------------------------------------------------------
+// ht_insert_min leaves the outcome in the table and the later passes read it back: one random 8-byte read per item in
+// ht_count_assign_kernel.  The resolving insert RETURNS the outcome instead -- the key's value as this insert left or
+// found it: pend|i (item i holds the key), pend|j with j < i (duplicate of a pending item), a local id (the node was
+// known before this fill), or EMPTY (table full) -- so that the next pass reads a sequential array.  What an insert
+// cannot know is whether a LATER insert with a smaller index takes the key over; that insert's atomicMin returns the
+// value it replaced, i.e. it knows exactly whom it replaced, and leaves that item a note in disp[].  A duplicate that
+// was pointed at a holder which is replaced afterwards reaches the final owner by following the notes
+// (ht_map_fix_kernel).  Stale reads (non-coherent L2s) only ever show an older = larger value: at worst a redundant
+// atomicMin or one more hop in that chain.
+__device__ __forceinline__ uint32_t ht_lower_resolve(const HtView &t, uint32_t h, uint32_t id, uint32_t seen_v,
+                                                     uint32_t value, uint32_t *disp) {
+  if (seen_v < value) return seen_v;  // a local id, or an earlier pending item
+  const unsigned long long mine = ((unsigned long long)id << 32) | t.gen_base | value;
+  const uint32_t old_v = ht_value(t, atomicMin(&t.table[h], mine));
+  if (old_v < value) return old_v;    // somebody smaller got there between the read and the atomic
+  disp[old_v & (t.pend - 1u)] = t.gen_base | value;  // old_v = pend|j: item j is told who replaced it
+  return value;
+}
+
+__device__ __forceinline__ uint32_t ht_insert_resolve(const HtView &t, uint32_t id, uint32_t value, uint32_t *disp) {
+  const unsigned long long mine = ((unsigned long long)id << 32) | t.gen_base | value;
+  uint32_t h = hash_slot(id, t.shift, t.mask);
+  for (uint32_t probes = 0; probes <= t.mask; ++probes) {
+    unsigned long long cur = t.table[h];
+    for (int tries = 0; tries < 4 && !ht_live(t, cur); ++tries) {
+      const unsigned long long old = atomicCAS(&t.table[h], cur, mine);
+      if (old == cur) return value;
+      cur = old;
+    }
+    if (ht_live(t, cur) && (uint32_t)(cur >> 32) == id) return ht_lower_resolve(t, h, id, ht_value(t, cur), value, disp);
+    h = (h + 1) & t.mask;
+  }
+  return FGNN_EMPTY_KEY;
+}
+
+template <int UB>
+__device__ __forceinline__ void ht_insert_resolve_batch(const HtView &t, const uint32_t (&key)[UB],
+                                                        const uint32_t (&val)[UB], const bool (&live)[UB],
+                                                        uint32_t *disp, uint32_t (&outcome)[UB]) {
+  uint32_t h[UB];
+  unsigned long long cur[UB], old[UB];
+  bool tried[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    h[u] = hash_slot(key[u], t.shift, t.mask);
+    cur[u] = live[u] ? t.table[h[u]] : 0ull;
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    old[u] = cur[u];
+    tried[u] = live[u] && !ht_live(t, cur[u]);
+    if (tried[u]) old[u] = atomicCAS(&t.table[h[u]], cur[u], ((unsigned long long)key[u] << 32) | t.gen_base | val[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    if (!live[u]) continue;
+    if (tried[u] && old[u] == cur[u]) outcome[u] = val[u];
+    else if (ht_live(t, old[u]) && (uint32_t)(old[u] >> 32) == key[u])
+      outcome[u] = ht_lower_resolve(t, h[u], key[u], ht_value(t, old[u]), val[u], disp);
+    else outcome[u] = ht_insert_resolve(t, key[u], val[u], disp);
+  }
 }
 
 // UB independent inserts with their memory operations overlapped: all probe loads are issued first, then all
@@ -390,7 +458,9 @@ struct LayerSummary {
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                 ScanWsHost *scan, bool final_fill = false);
+                                 ScanWsHost *scan, bool final_fill = false, bool resolved = false);
+// can the last fill of `cap` items go through the resolving insert (disp[] allocated, one-launch count+assign)?
+bool hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts
 int hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_counts);
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
@@ -430,6 +500,9 @@ int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const ui
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr);
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr,
+                      bool resolve = false);
+// resolve: the fill is the batch's last (hashtable_fill_duplicates_ex(..., final_fill, resolved = true) must follow):
+// ws[e] receives the insert's OUTCOME (ht_insert_resolve) instead of the bucket.  Needs ht->disp.
 
 }  // namespace fgnn

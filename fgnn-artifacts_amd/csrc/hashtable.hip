@@ -24,6 +24,8 @@
 //    assignment, remap) read the bucket directly instead of re-probing (the reference re-probes in
 //    count_hashmap, compact_hashmap and map_edge_ids);
 //  * owner ranks come from wave ballots + a one-workgroup scan of per-workgroup counts.
+#include <cstdlib>
+
 #include "fgnn_device.h"
 
 
@@ -202,7 +204,10 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
                                                                  const uint32_t *__restrict__ pos,
                                                                  uint32_t *d_num_items, uint32_t *__restrict__ n2o,
                                                                  size_t max_items, LayerSummary summary,
-                                                                 uint32_t *mapped, ScanWs scan, bool final_fill) {
+                                                                 uint32_t *mapped, ScanWs scan, bool final_fill,
+                                                                 const uint32_t *__restrict__ disp) {
+  // disp != null (implies final_fill): pos[] holds the OUTCOMES of a resolving insert (fgnn_device.h), not buckets --
+  // the value the bucket read below would have returned, up to take-overs noted in disp[]: no table access at all
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile;
   const uint32_t n = (uint32_t)resolve_count64(n_host, d_n, cap);  // cap < 2^31 (host check)
@@ -226,8 +231,21 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
       ok[u] = r0 + u < rounds && i < n;
       bk[u] = ok[u] ? pos[i] : kNoBucket;
     }
+    if (disp) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+        v[u] = ok[u] ? bk[u] : FGNN_EMPTY_KEY;
+        if (ok[u] && v[u] == (t.pend | (uint32_t)i)) {  // held the key when it inserted: still?
+          const uint32_t note = disp[i] ^ t.gen_base;   // this generation's note: pend|item that took the key over
+          if ((note >> t.vp1) == 0u && (note & t.pend)) v[u] = note;
+        }
+        bk[u] = 0;  // "has a bucket"
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (ok[u]) {
@@ -282,8 +300,13 @@ __global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(HtView t, size_t n_h
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
-    const uint32_t m = mapped[i];
-    if ((m & t.pend) && m != FGNN_EMPTY_KEY) mapped[i] = mapped[m & (t.pend - 1u)];
+    uint32_t m = mapped[i];
+    if ((m & t.pend) && m != FGNN_EMPTY_KEY) {
+      // one hop, except after a resolving insert: the item pointed at may itself have lost the key later and then
+      // points on (a few hops at most; its entry may be mid-update by its own lane -- either state leads to the owner)
+      for (int hop = 0; hop < 64 && (m & t.pend) && m != FGNN_EMPTY_KEY; ++hop) m = mapped[m & (t.pend - 1u)];
+      mapped[i] = m;
+    }
   }
 }
 
@@ -357,6 +380,7 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max
   ht->gen_limit = (1u << (32 - ht->vp1)) - 1u;         // >= 1; the all-ones generation is the wiped pattern
   ht->gen = 0;
   ht->max_fill_items = max_fill_items;
+  ht->disp = nullptr;
   ht->scan = new ScanWsHost();
   if (ht->scan->create(4096) != FGNN_OK ||
       hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
@@ -368,6 +392,13 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max
     return fail(FGNN_EHIP);
   }
   ht->n2o = ht->n2o_owned;
+  if (max_fill_items <= (size_t(1) << 24)) {  // the batch driver's tables: notes of the resolving insert
+    const size_t bytes = (max_fill_items + 1) * sizeof(uint32_t);
+    if (hipMalloc(&ht->disp, bytes) != hipSuccess || hipMemset(ht->disp, 0, bytes) != hipSuccess) {
+      fgnn_hashtable_destroy(ht);
+      return fail(FGNN_EHIP);
+    }
+  }
   if (h_err) *h_err = FGNN_OK;
   return ht;
 }
@@ -393,6 +424,7 @@ extern "C" void fgnn_hashtable_destroy(fgnn_hashtable *ht) {
   if (ht->table) (void)hipFree(ht->table);
   if (ht->n2o_owned) (void)hipFree(ht->n2o_owned);
   if (ht->d_num_items) (void)hipFree(ht->d_num_items);
+  if (ht->disp) (void)hipFree(ht->disp);
   if (ht->scan) {
     ht->scan->destroy();
     delete ht->scan;
@@ -417,6 +449,8 @@ int fgnn::hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_
     return FGNN_OK;
   }
   ht->gen = 0;
+  // notes of earlier cycles must not read as this cycle's
+  if (ht->disp) FGNN_HIP_CHECK(hipMemsetAsync(ht->disp, 0, (ht->max_fill_items + 1) * sizeof(uint32_t), s));
   size_t blocks = div_up(ht->capacity / 2, (size_t)kBlock * 4);
   const size_t max_blocks = (size_t)device_cu_count() * 8;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -448,11 +482,34 @@ extern "C" int fgnn_hashtable_fill_duplicates(fgnn_hashtable *ht, const uint32_t
                                             stream, fgnn::LayerSummary{nullptr, nullptr, nullptr}, false, nullptr, false);
 }
 
+// grid of the one-launch count+assign path, 0 if the fill is too large for it: the grid must be resident at once
+// (prefix over the lower-numbered workgroups) and a chunk at most 32 rounds
+static size_t count_assign_grid(size_t cap, const fgnn::ScanWsHost *scan) {
+  static int per_cu = -1;
+  if (per_cu < 0 &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_count_assign_kernel, kBlock, 0) != hipSuccess)
+    per_cu = 0;
+  const size_t nb1 = div_up(cap, (size_t)kBlock);
+  size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
+  if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
+  if (grid > nb1) grid = nb1;
+  return grid > 0 && div_up(cap, grid * kBlock) <= 32 ? grid : 0;
+}
+
+bool fgnn::hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap) {
+  if (const char *e = getenv("FGNN_HT_RESOLVE")) {  // A/B switch (tools/ab_env.sh)
+    if (atoi(e) == 0) return false;
+  }
+  return ht && ht->disp && ht->scan && cap > 0 && cap <= ht->max_fill_items && count_assign_grid(cap, ht->scan) > 0;
+}
+
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                       ScanWsHost *scan, bool final_fill) {
+                                       ScanWsHost *scan, bool final_fill, bool resolved) {
   if (!ht) return FGNN_EINVAL;
+  // resolved: pos[] holds insert outcomes (sample_khop_fused(..., resolve = true)); only the one-launch path reads them
+  if (resolved && !(already_inserted && final_fill && mapped && ht->disp)) return FGNN_EINVAL;
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
   if (!items || cap > ht->max_fill_items) return FGNN_EINVAL;  // pending indices must fit the value field
@@ -476,25 +533,19 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items);
   if (!scan) scan = ht->scan;
   if (scan) {
-    // single-pass path: the grid must be resident at once (prefix over the lower-numbered workgroups) and a chunk at most 32 rounds
-    static int per_cu = -1;
-    if (per_cu < 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_count_assign_kernel, kBlock, 0) != hipSuccess)
-      per_cu = 0;
     const size_t nb1 = div_up(cap, (size_t)kBlock);
-    size_t grid = (size_t)per_cu * device_cu_count() * 3 / 4;
-    if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
-    if (grid > nb1) grid = nb1;
-    if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
+    const size_t grid = count_assign_grid(cap, scan);
+    if (grid > 0) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(1), final_fill && mapped != nullptr);
+                         scan->next(1), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
       if (mapped)
         hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
                            mapped);
       return launch_status(__func__);
     }
   }
+  if (resolved) return FGNN_EINVAL;  // the caller checks can_resolve() before it asks the sampler for outcomes
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
   FGNN_HT(ht_count_kernel, tv, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s, nullptr,

@@ -65,7 +65,8 @@ constexpr uint32_t kWriteBack = 0x80000000u;  // flag on a logged swap position:
 
 struct FuseArgs {               // dedup insert fused into phase B (engine path)
   HtView t;                     // t.table == null: not fused
-  uint32_t *pos;                // bucket of every emitted edge
+  uint32_t *pos;                // bucket of every emitted edge (disp != null: the insert's outcome instead)
+  uint32_t *disp;               // non-null: resolving insert (fgnn_device.h), the batch's last fill
   uint32_t *d_num_items;        // the table's {count, count before the running fill}
   BatchStart start;             // start.n2o != null: this is the first launch of a batch
 };
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
       uint32_t ival[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) ival[u] = fuse.t.pend | (uint32_t)(base + p0 + u * T);
-      ht_insert_min_batch<UB>(fuse.t, v, ival, live, bucket);
+      if (fuse.disp) ht_insert_resolve_batch<UB>(fuse.t, v, ival, live, fuse.disp, bucket);
+      else ht_insert_min_batch<UB>(fuse.t, v, ival, live, bucket);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         const uint32_t p = p0 + u * T;
         out_dst[base + p] = v[u];
         out_src[base + p] = srcv[u];
-        if (fuse.t.table) fuse.pos[base + p] = (ablate & 2u) ? kNoBucket : bucket[u];
+        if (fuse.t.table) fuse.pos[base + p] = (ablate & 2u) ? (fuse.disp ? FGNN_EMPTY_KEY : kNoBucket) : bucket[u];
         if (KHOP2 && bigv[u]) {
           sh_o[slot[u]] = v[u];   // value that lands in the consumed tail slot len-1-j
           sh_w[slot[u]] = wv[u];  // value that lands in position s_j
@@ -355,7 +357,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
                 size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr,
-                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr) {
+                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr, bool resolve = false) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
   if (cap == 0) {
@@ -378,7 +380,8 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   const size_t nb = div_up(cap, (size_t)S);
   const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
   const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
-  FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr, BatchStart{nullptr, nullptr, nullptr, 0, 0, 0}};
+  FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr, nullptr,
+                BatchStart{nullptr, nullptr, nullptr, 0, 0, 0}};
   uint32_t *sums = static_cast<uint32_t *>(ws);
   if (fuse_ht) {
     // ws = pos[cap*F] (consumed by the dedup passes) | dedup sums | ... ; this kernel's offsets go at the very end
@@ -387,6 +390,10 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     fuse.t = ht_view(fuse_ht);
     fuse.pos = static_cast<uint32_t *>(ws);
     fuse.d_num_items = fuse_ht->d_num_items;
+    if (resolve) {
+      if (!fuse_ht->disp) return FGNN_EINVAL;
+      fuse.disp = fuse_ht->disp;
+    }
     if (start) fuse.start = *start;
     sums = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes) - (nb + 4);
   } else if (ws_bytes < (nb + 1) * sizeof(uint32_t)) {
@@ -442,14 +449,16 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start) {
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start, bool resolve) {
   if (!ht) return FGNN_EINVAL;
   if (start && (d_num_input || !start->n2o)) return FGNN_EINVAL;  // the first launch takes the seeds with a host count
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start)
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
+                                   resolve)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start);
+                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
+                                    resolve);
 }
 
 }  // namespace fgnn
