@@ -113,14 +113,17 @@ __global__ void ht_advance_kernel(uint32_t *d_num_items, uint32_t add) { d_num_i
 template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_insert_kernel(HtView t, const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
-                                                           uint32_t *__restrict__ pos, uint32_t *d_num_items) {
+                                                           uint32_t *__restrict__ pos, uint32_t *d_num_items,
+                                                           uint32_t *disp) {
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   if (blockIdx.x == 0 && threadIdx.x == 0) d_num_items[1] = d_num_items[0];  // count before this fill
 #pragma unroll
   for (int r = 0; r < IPT; ++r) {
     const size_t i = tile0 + (size_t)r * kBlock + threadIdx.x;
-    if (i < n) pos[i] = ht_insert_min(t, items[i], t.pend | (uint32_t)i);
+    if (i < n)  // disp != null: resolving insert, pos[] takes the outcome (last fill of a batch)
+      pos[i] = disp ? ht_insert_resolve(t, items[i], t.pend | (uint32_t)i, disp)
+                    : ht_insert_min(t, items[i], t.pend | (uint32_t)i);
   }
 }
 
@@ -510,6 +513,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (!ht) return FGNN_EINVAL;
   // resolved: pos[] holds insert outcomes (sample_khop_fused(..., resolve = true)); only the one-launch path reads them
   if (resolved && !(already_inserted && final_fill && mapped && ht->disp)) return FGNN_EINVAL;
+  if (!scan) scan = ht->scan;  // hashtable_can_resolve looks at ht->scan: the descriptors used must be those
   size_t cap = d_num_items ? num_items_cap : num_items;
   if (cap == 0) return FGNN_OK;
   if (!items || cap > ht->max_fill_items) return FGNN_EINVAL;  // pending indices must fit the value field
@@ -529,8 +533,12 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     else hipLaunchKernelGGL((KERNEL<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
-  if (!already_inserted)
-    FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items);
+  if (!already_inserted) {
+    // the last fill of a batch done here (samplers that do not insert themselves) resolves too
+    resolved = final_fill && mapped && scan == ht->scan && hashtable_can_resolve(ht, cap);
+    FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items,
+            resolved ? ht->disp : static_cast<uint32_t *>(nullptr));
+  }
   if (!scan) scan = ht->scan;
   if (scan) {
     const size_t nb1 = div_up(cap, (size_t)kBlock);
