@@ -316,6 +316,10 @@ def main():
     ap.add_argument("--cache-ratio", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the two extra measurements after the timed region (sampler-side stage alone, gather "
+                         "alone): under rocprofv3 --stats every gather launch is then one of the overlapped kind the "
+                         "roofline line is computed from")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads enqueueing batches")
     ap.add_argument("--streams-per-thread", type=int, default=3,
                     help="HIP streams each host thread rotates over (batches in flight = threads x this); measured on "
@@ -465,23 +469,25 @@ def main():
     # dedup + remap + cache-index split, dist_loops_arch5.cc:98-105), same overlap, no feature gather
     metas.clear()
     gather_ms.clear()
-    extract[0] = False
-    n_stage = min(args.steps, 64)
-    run_region(next_seq, next_seq + 8, False)
-    next_seq += 8
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run_region(next_seq, next_seq + n_stage, True)
-    torch.cuda.synchronize()
-    t_stage = time.perf_counter() - t1
-    next_seq += n_stage
-    stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
-    sample_stage = {"edges_per_s": stage_edges / t_stage, "ms_per_step": t_stage / n_stage * 1e3, "steps": n_stage,
-                    "note": "sample + dedup + remap + cache-index split only (no feature gather), same overlap"}
-    extract[0] = True
+    sample_stage = None
+    if not args.timed_only:
+        extract[0] = False
+        n_stage = min(args.steps, 64)
+        run_region(next_seq, next_seq + 8, False)
+        next_seq += 8
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_region(next_seq, next_seq + n_stage, True)
+        torch.cuda.synchronize()
+        t_stage = time.perf_counter() - t1
+        next_seq += n_stage
+        stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+        sample_stage = {"edges_per_s": stage_edges / t_stage, "ms_per_step": t_stage / n_stage * 1e3, "steps": n_stage,
+                        "note": "sample + dedup + remap + cache-index split only (no feature gather), same overlap"}
+        extract[0] = True
     metas.clear()
     gather_ms.clear()
-    if NT > 1 or SPT > 1:
+    if (NT > 1 or SPT > 1) and not args.timed_only:
         nt_saved, spt_saved = NT, SPT
         NT = SPT = 1
         base_seq = next_seq

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. default bench (with cpu baseline), plain
 python3 bench.py > gpurun_out/r01c_bench_default.json 2> gpurun_out/r01c_bench_default.err
 # 2. same command under rocprofv3 stats
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc1 -- python3 bench.py --no-cpu-baseline > gpurun_out/r01c_prof_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc1 -- python3 bench.py --no-cpu-baseline --timed-only > gpurun_out/r01c_prof_default.log 2>&1
 python3 tools/stats_summary.py gpurun_out/pc1 > gpurun_out/r01c_default_stats.md
 cp $(find gpurun_out/pc1 -name "*kernel_stats.csv") gpurun_out/r01c_default_kernel_stats.csv; rm -rf gpurun_out/pc1
 # 3. serial timeline
@@ -17,3 +17,7 @@ done
 python3 tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/r01c_pmc_FETCH_SIZE.log > gpurun_out/r01c_pmc_traffic.json 2> gpurun_out/r01c_pmc.err
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 tail -c 600 gpurun_out/r01c_bench_default.json; cat gpurun_out/r01c_timeline_serial.txt; head -12 gpurun_out/r01c_pmc_traffic.json; cat gpurun_out/r01c_pmc.err | tail -3
+# 6. the other workloads (config 4 / config 5 sampler side)
+python3 bench.py --workload twitter > gpurun_out/r01c_bench_twitter.json 2> gpurun_out/r01c_bench_twitter.err
+python3 bench.py --workload uk-2006-05 > gpurun_out/r01c_bench_uk.json 2> gpurun_out/r01c_bench_uk.err
+tail -c 300 gpurun_out/r01c_bench_twitter.json; tail -c 300 gpurun_out/r01c_bench_uk.json

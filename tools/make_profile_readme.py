@@ -16,8 +16,12 @@ for src, dst in (("r01c_default_kernel_stats.csv", "r01_c_bench_default_kernel_s
     shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 j = last_json(os.path.join(G, "r01c_bench_default.json"))
 json.dump(j, open(os.path.join(P, "r01_c_bench_default.json"), "w"), indent=1)
+for src, dst in (("r01c_bench_twitter.json", "r01_c_bench_twitter.json"), ("r01c_bench_uk.json", "r01_c_bench_uk.json")):
+    if os.path.exists(os.path.join(G, src)):  # refreshed by final_prof.sh step 6
+        json.dump(last_json(os.path.join(G, src)), open(os.path.join(P, dst), "w"), indent=1)
 tw = json.load(open(os.path.join(P, "r01_c_bench_twitter.json")))
 uk = json.load(open(os.path.join(P, "r01_c_bench_uk.json")))
+prof = last_json(os.path.join(G, "r01c_prof_default.log"))
 stats = open(os.path.join(G, "r01c_default_stats.md")).read()
 tl = open(os.path.join(G, "r01c_timeline_serial.txt")).read()
 ph = "\n".join(l for l in open(os.path.join(G, "r01c_phase_probe.txt")).read().split("\n") if "amdgpu.ids" not in l)
@@ -39,8 +43,10 @@ Stream configurations measured on one box (threads x streams per thread): 1x3 0.
 
 ## 2. Same command under `rocprofv3 --kernel-trace --stats` (`r01_c_bench_default_kernel_stats.csv`)
 
-257 batches = 10 warm-up + 151 timed (3 streams) + 72 sampler-stage-only + 24 serial; the gather row averages its 185 launches
-(overlapped and serial ones together).
+`bench.py --no-cpu-baseline --timed-only`: 2 set-up + 10 warm-up + 151 timed batches, all with three batches in flight, so
+the gather row averages launches of the kind `roofline.avg_launch_ms` is computed from.  The bench line printed by this
+profiled run itself: ms_per_step {prof['ms_per_step']:.4f}, gather by HIP events {prof['roofline']['avg_launch_ms']*1e3:.1f} us
+(the profiler's own per-launch overhead makes the profiled run slower than section 1's).
 
 {stats}
 ## 3. One batch, one stream (`bench.py --no-overlap`, rocprofv3 --kernel-trace): `r01_c_timeline_serial.txt`
