@@ -732,3 +732,42 @@ def test_neighbourhood_expand_matches_oracle(hip, oracle, graph, layers, batch):
     np.testing.assert_array_equal(host_u32(freq), want_freq)
     # stamps: every node ever reached carries the mark of the last batch that reached it
     assert int((host_u32(stamp) != 0).sum()) == int((want_freq != 0).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["khop0", "khop2"])
+def test_batch_driver_resolving_insert_across_generation_wrap(hip, oracle, graph, kind):
+    """The last fill of a batch goes through the resolving insert (outcomes + take-over notes instead of bucket
+    reads).  A dense little graph makes most edges duplicates (long take-over chains), and capacities of 2^23..2^24 edges
+    per layer leave the bucket value 7 generation bits, so the table AND the notes are wiped after 127 batches:
+    every batch before, at and after the wrap must match the oracle edge for edge."""
+    indptr, indices = graph                     # 3000 nodes, 60000 edges
+    num_node = len(indptr) - 1
+    fanouts, max_batch, nseed = [45, 50], 4000, 40
+    d_indices = dev(indices.copy())
+    st, ost = (hip.KHOP0, oracle.KHOP0) if kind == "khop0" else (hip.KHOP2, oracle.KHOP2)
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, max_batch, sample_type=st, seed=SEED)
+    assert (1 << 23) < sampler.max_edges(0) <= (1 << 24)
+    bt = sampler.new_batch(0, hip.F32, hip.I64)
+    o_indices = indices.copy()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    dup_edges = 0
+    for b in range(133):
+        seeds = _seeds(nseed, num_node, seed=900 + b)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht)
+        assert m.overflow == 0
+        for li in range(2):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"]), (b, li)
+            np.testing.assert_array_equal(host_u32(row), g["row"], err_msg="batch %d layer %d" % (b, li))
+            np.testing.assert_array_equal(host_u32(col), g["col"], err_msg="batch %d layer %d" % (b, li))
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+        g0 = want["graphs"][0]
+        dup_edges += g0["num_edge"] - (g0["num_src"] - g0["num_dst"])
+    assert dup_edges > 133 * 2000  # duplicates inside the last fill: the take-over notes were exercised
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
