@@ -739,8 +739,9 @@ def test_neighbourhood_expand_matches_oracle(hip, oracle, graph, layers, batch):
 def test_batch_driver_resolving_insert_across_generation_wrap(hip, oracle, graph, kind):
     """The last fill of a batch goes through the resolving insert (outcomes + take-over notes instead of bucket
     reads).  A dense little graph makes most edges duplicates (long take-over chains), and capacities of 2^23..2^24 edges
-    per layer leave the bucket value 7 generation bits, so the table AND the notes are wiped after 127 batches:
-    every batch before, at and after the wrap must match the oracle edge for edge."""
+    per layer leave the bucket value 7 generation bits, so a slot's table AND its notes are wiped after 127 batches of
+    that slot (the driver rotates over 4 slots: 508 batches in all): every batch before, at and after the wraps must
+    match the oracle edge for edge."""
     indptr, indices = graph                     # 3000 nodes, 60000 edges
     num_node = len(indptr) - 1
     fanouts, max_batch, nseed = [45, 50], 4000, 40
@@ -753,7 +754,7 @@ def test_batch_driver_resolving_insert_across_generation_wrap(hip, oracle, graph
     oht = oracle.HashTable(num_node, sampler.max_nodes)
     rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
     dup_edges = 0
-    for b in range(133):
+    for b in range(530):
         seeds = _seeds(nseed, num_node, seed=900 + b)
         sampler.sample(dev(seeds), b, bt)
         bt.finish()
@@ -769,5 +770,5 @@ def test_batch_driver_resolving_insert_across_generation_wrap(hip, oracle, graph
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
         g0 = want["graphs"][0]
         dup_edges += g0["num_edge"] - (g0["num_src"] - g0["num_dst"])
-    assert dup_edges > 133 * 2000  # duplicates inside the last fill: the take-over notes were exercised
+    assert dup_edges > 530 * 2000  # duplicates inside the last fill: the take-over notes were exercised
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
