@@ -38,8 +38,9 @@ sampler-side stage alone {j['sample_stage']['edges_per_s']:.3e} edges/s ({j['sam
 {j['roofline']['avg_launch_ms']*1e3:.1f} us = {j['roofline']['achieved']:.0f} GB/s (frac {j['roofline']['frac']:.3f}), alone {j['roofline']['serial']['avg_launch_ms']*1e3:.1f} us = {j['roofline']['serial']['achieved']:.0f} GB/s
 (frac {j['roofline']['serial']['frac']:.3f}); CPU baseline (kind "{c['kind']}": the reference's own CPU sources, oracle/_ref) {c['value']:.3e} edges/s
 with {c['cores']} OpenMP threads ({c['host_cpus']} host CPUs; 3.4e7 - 4.2e7 over the round's boxes).
-Stream configurations measured on one box (threads x streams per thread): 1x3 0.160, 1x2 0.173, 2x1 0.172, 3x1 0.167-0.177,
-2x2 0.183, 1x4 0.183 ms/step; the gather's overlapped fraction is 0.49 with two batches in flight and 0.44 with three.
+Stream configurations measured on one box with the final build (threads x streams per thread): 1x3 0.160-0.163 ms/step
+(gather fraction 0.43), 1x2 0.166 (0.54), 1x4 0.178-0.185 (0.49-0.51), 2x2 0.177 (0.52); earlier in the round 2x1 0.172,
+3x1 0.167-0.177.  The default is the fastest whole path (1x3), not the best-looking gather fraction.
 
 ## 2. Same command under `rocprofv3 --kernel-trace --stats` (`r01_c_bench_default_kernel_stats.csv`)
 
