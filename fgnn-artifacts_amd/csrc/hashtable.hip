@@ -306,8 +306,16 @@ __global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(HtView t, size_t n_h
     uint32_t m = mapped[i];
     if ((m & t.pend) && m != FGNN_EMPTY_KEY) {
       // one hop, except after a resolving insert: the item pointed at may itself have lost the key later and then
-      // points on (a few hops at most; its entry may be mid-update by its own lane -- either state leads to the owner)
-      for (int hop = 0; hop < 64 && (m & t.pend) && m != FGNN_EMPTY_KEY; ++hop) m = mapped[m & (t.pend - 1u)];
+      // points on (its entry may be mid-update by its own lane -- either state leads to the owner)
+      // every hop leads to a strictly smaller item index (a key is only ever taken over by an earlier item), so the
+      // walk ends at the owner after at most as many hops as the key changed hands
+      uint32_t at = (uint32_t)i;
+      while ((m & t.pend) && m != FGNN_EMPTY_KEY) {
+        const uint32_t j = m & (t.pend - 1u);
+        if (j >= at) break;  // cannot happen with consistent notes; never loop on garbage
+        at = j;
+        m = mapped[j];
+      }
       mapped[i] = m;
     }
   }

@@ -772,3 +772,39 @@ def test_batch_driver_resolving_insert_across_generation_wrap(hip, oracle, graph
         dup_edges += g0["num_edge"] - (g0["num_src"] - g0["num_dst"])
     assert dup_edges > 530 * 2000  # duplicates inside the last fill: the take-over notes were exercised
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
+def test_batch_driver_hub_nodes_in_every_row(hip, oracle):
+    """three hub nodes are neighbours of EVERY node: thousands of duplicates of one key inside a single fill, whatever
+    order the hardware inserts them in (the resolving insert's take-over notes may form long chains)"""
+    num_node, deg = 6000, 12
+    rng_np = np.random.default_rng(31)
+    rows = np.concatenate([np.tile(np.array([5, 77, 4242], dtype=np.uint32), (num_node, 1)),
+                           rng_np.integers(0, num_node, (num_node, deg - 3), dtype=np.uint32)], axis=1)
+    for r in rows:
+        rng_np.shuffle(r)  # hubs at random positions of the row
+    indptr = (np.arange(num_node + 1, dtype=np.uint32) * deg).astype(np.uint32)
+    indices = rows.reshape(-1).copy()
+    fanouts, batch = [12, 12], 1500
+    for kind, st, ost in (("khop0", hip.KHOP0, oracle.KHOP0), ("khop2", hip.KHOP2, oracle.KHOP2)):
+        d_indices = dev(indices.copy())
+        o_indices = indices.copy()
+        sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=st, seed=SEED)
+        bt = sampler.new_batch(0, hip.F32, hip.I64)
+        oht = oracle.HashTable(num_node, sampler.max_nodes)
+        rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+        for b in range(6):
+            seeds = _seeds(batch, num_node, seed=40 + b)
+            sampler.sample(dev(seeds), b, bt)
+            bt.finish()
+            m = bt.wait()
+            want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht)
+            assert m.overflow == 0
+            for li in range(2):
+                row, col, nsrc, ndst = bt.graph(li)
+                g = want["graphs"][li]
+                assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"]), (kind, b, li)
+                np.testing.assert_array_equal(host_u32(row), g["row"], err_msg="%s batch %d layer %d" % (kind, b, li))
+                np.testing.assert_array_equal(host_u32(col), g["col"])
+            np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
