@@ -55,7 +55,7 @@ std::shared_ptr<void> Pooled(DevicePool &pool, size_t bytes) {
 struct DynamicCache {
   fgnn_hashtable *ht = nullptr;
   uint32_t *table = nullptr;  // sampler device: node -> row of prev_feat, or EMPTY
-  DevBuf src[FGNN_MAX_LAYERS], dst[FGNN_MAX_LAYERS], mapped[FGNN_MAX_LAYERS], nbrs, ws, idx[4], counters;
+  DevBuf src[FGNN_MAX_LAYERS], dst[FGNN_MAX_LAYERS], mapped[FGNN_MAX_LAYERS], nbrs, ws, nbr_ws, idx[4], counters;
   DevicePool sampler_pool;    // per-batch arrays that stay on the sampler device (input / output nodes)
   std::shared_ptr<void> prev_nodes, prev_feat;
   size_t num_prev = 0;
@@ -174,12 +174,14 @@ void Engine::SampleOnceDynamic() {
         // :400-421: all neighbours of everything seen so far -> the batch's input nodes
         size_t *d_nn = d_num_out + 1;
         const size_t eb = fgnn_extract_neighbour_scratch_bytes(num_unique);
+        // scratch of its own: the emit launch below is still reading it when the dedup's scratch is (re)sized
+        char *ews = dc.nbr_ws.Reserve<char>(eb);
         SAM_FGNN(fgnn_extract_neighbour(d_indptr_, d_indices_, unique, num_unique, nullptr, num_unique, nullptr, 0, d_nn,
-                                        dc.ws.Reserve<char>(eb), eb, stream_));
+                                        ews, eb, stream_));
         const size_t num_nbrs = read_u64(d_nn);
         uint32_t *nbrs = dc.nbrs.Reserve<uint32_t>(std::max<size_t>(num_nbrs, 1));
         SAM_FGNN(fgnn_extract_neighbour(d_indptr_, d_indices_, unique, num_unique, nullptr, num_unique, nbrs, num_nbrs,
-                                        d_nn, dc.ws.Reserve<char>(eb), eb, stream_));
+                                        d_nn, ews, eb, stream_));
         const size_t fb = fgnn_scratch_bytes(std::max<size_t>(num_nbrs, 1));
         SAM_FGNN(fgnn_hashtable_fill_duplicates(dc.ht, nbrs, num_nbrs, nullptr, std::max<size_t>(num_nbrs, 1), nullptr,
                                                 dc.ws.Reserve<char>(fb), fb, stream_));
