@@ -47,6 +47,10 @@ def main():
                          "arch1 with one")
     ap.add_argument("--cache-percentage", type=float, default=0.0, help="arch2-4: presample cache on the trainer GPU")
     ap.add_argument("--pipeline", action="store_true", help="arch2-4: sam.start() background threads")
+    ap.add_argument("--cache-policy", default="pre_sample",
+                    help="a key of sam.cache_policies: pre_sample, presample_static, degree, ..., or dynamic_cache "
+                         "(arch4 only: the cache is the previous batch's feature tensor; khop0 / khop1 / weighted_khop, "
+                         "cache percentage 0)")
     args = ap.parse_args()
 
     if args.make_dataset:
@@ -68,7 +72,7 @@ def main():
     run_config = dict(dataset_path=args.dataset_path, _arch=sam.builtin_archs[arch]["arch"],
                       _sample_type=sam.sample_types[args.sample_type],
                       batch_size=args.batch_size, num_epoch=args.num_epoch + 1,  # + one warm-up epoch (common_config.py:163)
-                      _cache_policy=sam.kCacheByPreSample, cache_percentage=args.cache_percentage, max_sampling_jobs=10,
+                      _cache_policy=sam.cache_policies[args.cache_policy], cache_percentage=args.cache_percentage, max_sampling_jobs=10,
                       max_copying_jobs=2, omp_thread_num=8, sampler_ctx=sampler_ctx, trainer_ctx=trainer_ctx,
                       num_fanout=len(args.fanout), fanout=args.fanout)
     sam.config(run_config)

@@ -136,7 +136,10 @@ def test_arch5_switcher(tmp_path, sample_type):
     assert "ok" in _run(tmp_path, "switcher", sample_type)
 
 
-@pytest.mark.parametrize("extra", [[], ["--arch", "arch3", "--cache-percentage", "0.2", "--pipeline"]])
+@pytest.mark.parametrize("extra", [[], ["--arch", "arch3", "--cache-percentage", "0.2", "--pipeline"],
+                                   ["--arch", "arch3", "--cache-percentage", "0.2", "--cache-policy", "presample_static"],
+                                   ["--arch", "arch4", "--cache-policy", "dynamic_cache", "--sample-type", "khop0",
+                                    "--pipeline"]])
 def test_training_example_runs(tmp_path, extra):
     """examples/train_graphsage.py = the reference's single-process script shape (config -> init -> [start] ->
     sample_once -> get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's
