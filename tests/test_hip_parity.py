@@ -808,3 +808,57 @@ def test_batch_driver_hub_nodes_in_every_row(hip, oracle):
                 np.testing.assert_array_equal(host_u32(row), g["row"], err_msg="%s batch %d layer %d" % (kind, b, li))
                 np.testing.assert_array_equal(host_u32(col), g["col"])
             np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
+@pytest.mark.gpu
+def test_batch_driver_random_configurations(hip, oracle):
+    """Differential test over 120 seeded random configurations: sampler type, 1-3 layers, fanouts 1..30 (below and above
+    the rows' lengths), graphs from 60 to 20 000 nodes from sparse to dense (few to almost-all duplicates), batch sizes
+    1..700 with a short last batch -- three batches each, every block, node list and (khop2) the mutated CSR bit-exact."""
+    from fgnn_hip import synth
+    rs = np.random.default_rng(20240611)
+    kinds = ["khop0", "khop2", "khop1", "weighted_khop", "weighted_khop_prefix", "weighted_khop_hash_dedup"]
+    for case in range(120):
+        kind = kinds[case % len(kinds)]
+        num_node = int(rs.choice([60, 500, 4000, 20000]))
+        avg_deg = float(rs.choice([1.5, 6, 25, 60]))
+        num_edge = max(num_node, int(num_node * avg_deg))
+        L = int(rs.integers(1, 4))
+        fanouts = [int(rs.integers(1, 31)) for _ in range(L)]
+        batch = int(min(num_node, rs.choice([1, 7, 64, 300, 700])))
+        indptr, indices = synth.powerlaw_csr(num_node, num_edge, seed=1000 + case)
+        what = "case %d: %s fanouts %s batch %d nodes %d edges %d" % (case, kind, fanouts, batch, num_node, len(indices))
+        kw, okw = {}, {}
+        if kind == "weighted_khop_prefix":
+            prefix = synth.prob_prefix_table(indptr, indices)
+            kw, okw = dict(prob_prefix=dev(prefix)), dict(prob_prefix=prefix)
+        elif kind in ("weighted_khop", "weighted_khop_hash_dedup"):
+            prob, alias = synth.alias_tables(indptr, indices)
+            kw, okw = dict(prob_table=dev(prob), alias_table=dev(alias)), dict(prob_prefix=prob, alias_table=alias)
+        hst = dict(khop0=hip.KHOP0, khop2=hip.KHOP2, khop1=hip.KHOP1, weighted_khop=hip.WEIGHTED_KHOP,
+                   weighted_khop_prefix=hip.WEIGHTED_KHOP_PREFIX, weighted_khop_hash_dedup=hip.WEIGHTED_KHOP_HASH_DEDUP)[kind]
+        ost = dict(khop0=oracle.KHOP0, khop2=oracle.KHOP2, khop1=oracle.KHOP1, weighted_khop=oracle.WEIGHTED_KHOP,
+                   weighted_khop_prefix=oracle.WEIGHTED_KHOP_PREFIX,
+                   weighted_khop_hash_dedup=oracle.WEIGHTED_KHOP_HASH_DEDUP)[kind]
+        d_indices = dev(indices.copy())
+        o_indices = indices.copy()
+        sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=hst, seed=SEED + case, **kw)
+        bt = sampler.new_batch()
+        oht = oracle.HashTable(num_node, sampler.max_nodes)
+        rng = oracle.make_rng(oracle.RNG_PHILOX, SEED + case)
+        for b, n in enumerate([batch, batch, max(1, batch // 2)]):
+            seeds = _seeds(n, num_node, seed=5000 + 10 * case + b)
+            sampler.sample(dev(seeds), 77 + b, bt)
+            bt.finish()
+            m = bt.wait()
+            want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, 77 + b, oht, **okw)
+            assert m.overflow == 0 and m.num_layers == L, what
+            for li in range(L):
+                row, col, nsrc, ndst = bt.graph(li)
+                g = want["graphs"][li]
+                assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"]), (what, b, li)
+                np.testing.assert_array_equal(host_u32(row), g["row"], err_msg="%s batch %d layer %d" % (what, b, li))
+                np.testing.assert_array_equal(host_u32(col), g["col"], err_msg="%s batch %d layer %d" % (what, b, li))
+            np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"], err_msg=what)
+        np.testing.assert_array_equal(host_u32(d_indices), o_indices, err_msg=what)
+        del sampler, bt
