@@ -508,10 +508,11 @@ static size_t count_assign_grid(size_t cap, const fgnn::ScanWsHost *scan) {
 }
 
 bool fgnn::hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap) {
-  if (const char *e = getenv("FGNN_HT_RESOLVE")) {  // A/B switch (tools/ab_env.sh)
-    if (atoi(e) == 0) return false;
-  }
-  return ht && ht->disp && ht->scan && cap > 0 && cap <= ht->max_fill_items && count_assign_grid(cap, ht->scan) > 0;
+  static const bool enabled = [] {  // A/B switch (tools/ab_env.sh), read once
+    const char *e = getenv("FGNN_HT_RESOLVE");
+    return !(e && atoi(e) == 0);
+  }();
+  return enabled && ht && ht->disp && ht->scan && cap > 0 && cap <= ht->max_fill_items && count_assign_grid(cap, ht->scan) > 0;
 }
 
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
