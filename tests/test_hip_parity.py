@@ -862,3 +862,46 @@ def test_batch_driver_random_configurations(hip, oracle):
             np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"], err_msg=what)
         np.testing.assert_array_equal(host_u32(d_indices), o_indices, err_msg=what)
         del sampler, bt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["khop2", "khop0", "khop1"])
+def test_batch_driver_empty_and_isolated_batches(hip, oracle, kind):
+    """a batch without seeds, a batch whose seeds have no neighbours at all, then ordinary batches: the summaries are
+    what the reference's loop would report (no edges, input nodes = seeds) and the chain of later batches is intact"""
+    from fgnn_hip import synth
+    num_node = 5000
+    indptr, indices = synth.powerlaw_csr(num_node, 40000, seed=77)
+    deg = np.diff(indptr.astype(np.int64))
+    isolated = np.flatnonzero(deg == 0).astype(np.uint32)
+    assert len(isolated) >= 20
+    fanouts, batch = [6, 4], 300
+    hst, ost = dict(khop2=(hip.KHOP2, oracle.KHOP2), khop0=(hip.KHOP0, oracle.KHOP0), khop1=(hip.KHOP1, oracle.KHOP1))[kind]
+    d_indices = dev(indices.copy())
+    o_indices = indices.copy()
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=hst, seed=SEED)
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    plans = [np.empty(0, dtype=np.uint32), isolated[:20], _seeds(batch, num_node, seed=1), np.empty(0, dtype=np.uint32),
+             _seeds(41, num_node, seed=2)]
+    for b, seeds in enumerate(plans):
+        d_seeds = dev(seeds) if len(seeds) else torch.empty(0, dtype=torch.int32, device="cuda")
+        sampler.sample(d_seeds, 300 + b, bt)
+        bt.finish()
+        m = bt.wait()
+        assert m.overflow == 0 and m.num_output == len(seeds), (kind, b)
+        if len(seeds) == 0:
+            assert m.num_input == 0 and all(int(m.num_edge[l]) == 0 for l in range(2)), (kind, b)
+            continue
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, 300 + b, oht)
+        for li in range(2):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"]), (kind, b, li)
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+        if b == 1:
+            assert want["total_edges"] == 0 and len(want["input_nodes"]) == 20
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
