@@ -1,31 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- sampled-edges/sec of the sampling-and-extraction hot path on MI355X.
 
-One "step" = one mini-batch through the whole path on one GPU, inputs resident in HBM:
+One "step" = one mini-batch through the whole path, inputs resident in HBM when the timed region starts:
     batch slice of the shuffled train set -> k-hop sampling (khop2) -> dedup/compaction -> remap
-    -> cache-index split -> feature gather + label gather -> batch summary to pinned host memory.
-Workload at N=1 (default): papers100M-shaped synthetic graph (BASELINE.json metric: GraphSAGE fanout
-[25,10], batch 8000, N=111 059 956, E=1 615 685 872, D=128 f32), full feature table resident in HBM.
-For N>1 every rank holds a full replica and samples its own DistShuffler step range
-(dist/dist_shuffler.cc:59-79); there is no collective on the data path (weak scaling).
+    -> cache-index split -> [hand-off to the trainer GPU] -> feature gather + label gather.
+Workload (BASELINE.json metric): papers100M-shaped graph (N=111 059 956, E=1 615 685 872, D=128 f32), GraphSAGE fanout
+[25,10], batch 8000.  The graph is the R-MAT graph of SURVEY.md 8(d) (fgnn_hip/rmat.py; --graph powerlaw = round 1's).
+
+--gpus 1   one GPU does both halves through the kernel-level C ABI (libfgnn_hip.so), full feature table in HBM; after
+           the timed region two more are measured and reported beside it: the sampler-side stage alone, and BASELINE
+           config 3's extract leg (features in host memory, HBM cache of the top cache_ratio*N rows ranked by the
+           pre-sampler, misses gathered over the host link).
+--gpus N   the factored pipeline of the reference (multi_gpu/train_graphsage.py:103-432): S sampler processes and
+           N - S trainer processes, one per GPU, driving arch5 through samgraph.torch / c_lib.so -- DistShuffler step
+           ranges per sampler (dist_shuffler.cc:59-79), hand-off through the HBM message ring, trainers extracting
+           with the pre-sample cache.  No collective on the data path; gloo carries two barriers and the reductions.
+           Started by torchrun (RANK / WORLD_SIZE in the environment), or -- when they are absent -- bench.py itself
+           starts N fresh rank processes before it touches the GPU and relays rank 0's line.
+The timed region covers K steps IN TOTAL for every N ("scaling": "strong").
 
 Prints ONE JSON line on rank 0 (contract in the task description).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
 
-from fgnn_hip import lib, synth  # noqa: E402
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HOST_LINK_GBS = 64.0    # PCIe Gen5 x16 per direction (secondary bound of the miss rows)
+XGMI_LINK_GBS = 153.0   # one xGMI link (sampler -> trainer peer reads)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+import torch
+
+from fgnn_hip import lib, synth  # noqa: E402
 
 WORKLOADS = {
     # name: shape + run config (reference defaults: batch 8000, common_config.py:63; fanout train_graphsage.py:77)
@@ -82,8 +96,8 @@ def gen_prefix_on_gpu(indptr, total, seed, device):
     return out
 
 
-def gen_graph_on_gpu(num_node, num_edge, seed, device):
-    """Same construction as synth.powerlaw_csr (power-law row lengths, hub-skewed neighbour ids), done with
+def gen_powerlaw_on_gpu(num_node, num_edge, seed, device):
+    """--graph powerlaw (round 1's generator; no community structure).  Same construction as synth.powerlaw_csr (power-law row lengths, hub-skewed neighbour ids), done with
     torch on the GPU in chunks so that a 1.6 G-edge CSR is built in seconds without host memory."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -152,14 +166,18 @@ def local_step_range(steps_per_epoch, rank, world):
     return first, count
 
 
-def pmc_traffic_ratio():
-    """HBM bytes / algorithmic bytes of the feature gather, from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["traffic_over_algorithmic"]
-    except Exception:
-        return None
+def pmc_traffic():
+    """HBM bytes / algorithmic bytes per kernel from the committed rocprofv3 PMC passes of this round
+    (profiles/r02_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, separate
+    --pmc passes of this command); falls back to round 1's file.  Returns (gather ratio or None, per-kernel dict)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return d.get("traffic_over_algorithmic"), d.get("per_kernel"), name
+        except Exception:
+            continue
+    return None, None, None
 
 
 def algorithmic_bytes(metas, feat_dim, batch_size):
@@ -307,55 +325,50 @@ def cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train, budget_s
             "rows_per_s": rows / t_total, "host_cpus": os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=151)   # one papers100M epoch at batch 8000
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
-    ap.add_argument("--cache-ratio", type=float, default=0.2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
-    ap.add_argument("--timed-only", action="store_true",
-                    help="skip the two extra measurements after the timed region (sampler-side stage alone, gather "
-                         "alone): under rocprofv3 --stats every gather launch is then one of the overlapped kind the "
-                         "roofline line is computed from")
-    ap.add_argument("--host-threads", type=int, default=1, help="host threads enqueueing batches")
-    ap.add_argument("--streams-per-thread", type=int, default=3,
-                    help="HIP streams each host thread rotates over (batches in flight = threads x this); measured on "
-                         "MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
-    ap.add_argument("--sample-type", default=None, choices=list(SAMPLE_TYPES),
-                    help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
-                         "multi_gpu/train_graphsage.py:75)")
-    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
-    args = ap.parse_args()
+def gen_graph(args, w, dev):
+    """(indptr, indices, num_edge, description) of the workload graph on `dev`"""
+    if args.graph == "rmat":
+        from fgnn_hip import rmat
+        indptr, indices, ne = rmat.rmat_csr(w["num_node"], w["num_edge"], 42, dev)
+        return indptr, indices, ne, "R-MAT (0.57,0.19,0.19,0.05) seed 42, directed, de-duplicated, CSR by destination"
+    indptr, indices, ne = gen_powerlaw_on_gpu(w["num_node"], w["num_edge"], 42, dev)
+    return indptr, indices, ne, "power-law degrees, hub-skewed ids (round 1 generator)"
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+def gen_train_set(args, w, dev):
+    """train ids (uniform random ids, seed 1), shuffled once like one DistShuffler epoch"""
+    from fgnn_hip import rmat
+    train = rmat.train_set(w["num_node"], w["num_train"], 1, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    return train[torch.randperm(train.numel(), generator=g, device=dev)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# N = 1: both halves on one GPU through the kernel-level C ABI
+
+def run_single(args):
+    import threading
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local_rank %= max(1, torch.cuda.device_count())  # more ranks than GPUs (a functional check on one GPU) share them
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        # control plane only (two barriers and two 16-byte reductions): the data path has no collective, every rank
-        # samples its own step range of the identically shuffled train set.  gloo keeps it off the GPUs entirely.
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
     lib.load()
-
     w = WORKLOADS[args.workload]
     if args.sample_type is None:
         args.sample_type = w["sample_type"]
     t_setup = time.time()
-    indptr, indices, num_edge = gen_graph_on_gpu(w["num_node"], w["num_edge"], 42, dev)
+    indptr, indices, num_edge, graph_desc = gen_graph(args, w, dev)
     feat = gen_features_on_gpu(w["num_node"], w["feat_dim"], dev)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     label = torch.randint(0, w["num_class"], (w["num_node"],), generator=g, device=dev, dtype=torch.int64)
-    train = torch.randperm(w["num_node"], generator=g, device=dev)[:w["num_train"]].to(torch.int32)
-    # cache table: top cache_ratio*N nodes by in-degree (stand-in rank list; the split kernel does not care)
+    train = gen_train_set(args, w, dev)
+    bs = w["batch_size"]
+    steps_per_epoch = (train.numel() + bs - 1) // bs
+    # headline region: cache-index split against a stand-in table (top cache_ratio*N rows by in-degree; the split
+    # kernel does not care which rows are cached), every row gathered from the HBM-resident table.  The pre-sampler's
+    # table is used by the extract leg below.
     deg = (indptr[1:].to(torch.int64) - indptr[:-1].to(torch.int64)) & 0xFFFFFFFF
     n_cached = int(w["num_node"] * args.cache_ratio)
     table = torch.full((w["num_node"],), -1, dtype=torch.int32, device=dev)
@@ -364,12 +377,6 @@ def main():
         table[top] = torch.arange(n_cached, device=dev, dtype=torch.int32)
         del top
     del deg
-    # one epoch's shuffle (identical on every rank, like DistShuffler's seed = epoch); each rank takes a step range
-    g.manual_seed(0)
-    train = train[torch.randperm(train.numel(), generator=g, device=dev)]
-    bs = w["batch_size"]
-    steps_per_epoch = (train.numel() + bs - 1) // bs
-    local_first, _ = local_step_range(steps_per_epoch, rank, world)
 
     prefix = gen_prefix_on_gpu(indptr, num_edge, 11, dev) if args.sample_type == "weighted_khop_prefix" else None
     prob_t = alias_t = None
@@ -385,51 +392,62 @@ def main():
     for bt in batches:
         bt.enable_timing(True)  # HIP events around the feature gather, on the stream it is launched on
     # Batches go round-robin over NT x SPT HIP streams (batch i -> stream i % (NT*SPT), enqueued by host thread i % NT;
-    # one thread is enough: enqueueing a batch takes ~0.06-0.1 ms): whole
-    # batches overlap -- the latency-bound sampling/dedup chain of one with the bandwidth-bound gather of another.
-    # fgnn_sampler_run_batch is thread-safe and keeps khop2's in-place CSR swaps in batch order (sequence numbers),
-    # so the results are the same as a serial run.  (The reference also overlaps its sample and copy loops.)
+    # one thread is enough: enqueueing a batch takes ~0.06-0.1 ms): whole batches overlap -- the latency-bound
+    # sampling/dedup chain of one with the bandwidth-bound gather of another.  fgnn_sampler_run_batch is thread-safe
+    # and keeps khop2's in-place CSR swaps in batch order (sequence numbers), so the results are the same as a serial
+    # run.  (The reference also overlaps its sample and copy loops.)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NT * SPT)]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    import threading
     metas, gather_ms, host_busy = [], [], [0.0] * NT
+    cached_ms = []
     lock = threading.Lock()
 
     def seeds_of(i):
-        step = (local_first + i) % steps_per_epoch
+        step = i % steps_per_epoch
         return step, train[step * bs:min(train.numel(), (step + 1) * bs)]
 
-    extract = [True]  # False: sample + dedup + remap + cache-index split only (the sampler-side stage)
+    # what a batch does after sampling: "full" = cache split + gather from the HBM table (headline), "sample" = cache
+    # split only (sampler-side stage), "cached" = config 3's extract (cache split against the pre-sampler's table,
+    # misses from host memory, hits from the HBM cache)
+    mode = ["full"]
+    leg = {}
 
     def worker(t, first, last, timed):
         torch.cuda.set_device(dev)
         if t >= NT:
             return
-        mine, gm = [], []
+        mine, gm, cm = [], [], []
+
+        def collect(bt):
+            m = bt.wait()
+            if timed:
+                mine.append(m)
+                gm.append(bt.gather_ms() if mode[0] == "full" else -1.0)
+                if mode[0] == "cached":
+                    cm.append(bt.extract_cached_ms())
         for i in range(first + ((t - first) % NT), last, NT):
             bt = batches[i % NBUF]
             if i - first >= NBUF:           # buffer reuse: collect the summary of the batch that used it
-                m = bt.wait()
-                if timed:
-                    mine.append(m)
-                    gm.append(bt.gather_ms() if extract[0] else -1.0)
+                collect(bt)
             step, seeds = seeds_of(i)
+            st = streams[i % len(streams) if NT > 1 or SPT > 1 else 0]
             t_h = time.perf_counter()
-            if extract[0]:
-                sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=streams[i % len(streams) if NT > 1 or SPT > 1 else 0])
+            if mode[0] == "full":
+                sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=st)
+            elif mode[0] == "sample":
+                sampler.run_batch(i, seeds, step, bt, table, None, None, stream=st)
             else:
-                sampler.run_batch(i, seeds, step, bt, table, None, None, stream=streams[i % len(streams) if NT > 1 or SPT > 1 else 0])
+                sampler.run_batch_cached(i, seeds, step, bt, leg["table"], leg["cache_rows"], leg["host_feat"], label,
+                                         stream=st)
             host_busy[t] += time.perf_counter() - t_h
         for i in range(max(first, last - NBUF) + ((t - max(first, last - NBUF)) % NT), last, NT):
-            m = batches[i % NBUF].wait()
-            if timed:
-                mine.append(m)
-                gm.append(batches[i % NBUF].gather_ms() if extract[0] else -1.0)
+            collect(batches[i % NBUF])
         with lock:
             metas.extend(mine)
             gather_ms.extend(gm)
+            cached_ms.extend(cm)
 
     def run_region(first, last, timed):
         ths = [threading.Thread(target=worker, args=(t, first, last, timed)) for t in range(NT)]
@@ -438,10 +456,6 @@ def main():
         for th in ths:
             th.join()
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
     # set-up, not warm-up: a few batches so that code objects are loaded, occupancy queries cached and every buffer
     # touched once even when the caller asks for a very short warm-up (sequence numbers stay consecutive)
     prime = max(0, 12 - args.warmup)
@@ -449,20 +463,15 @@ def main():
     torch.cuda.synchronize()
     run_region(prime, prime + args.warmup, False)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    host_busy = [0.0] * NT
+    for t in range(NT):
+        host_busy[t] = 0.0
     t0 = time.perf_counter()
     run_region(prime + args.warmup, prime + args.warmup + args.steps, True)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_enqueue_ms = sum(host_busy) / args.steps * 1e3  # of the timed region only
     assert len(metas) == args.steps, (len(metas), args.steps)
 
-    # the same kernel with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency
-    # from the slowdown it accepts when it shares the chip with the next batch's sampling chain
-    serial = None
     next_seq = prime + args.warmup + args.steps  # sequence numbers must stay consecutive
     metas_t, gather_t = list(metas), list(gather_ms)
     # the sampler-side stage alone (what the reference's kLogEpochSampleTotalTime covers: shuffle slice + sample +
@@ -471,7 +480,7 @@ def main():
     gather_ms.clear()
     sample_stage = None
     if not args.timed_only:
-        extract[0] = False
+        mode[0] = "sample"
         n_stage = min(args.steps, 64)
         run_region(next_seq, next_seq + 8, False)
         next_seq += 8
@@ -482,24 +491,44 @@ def main():
         t_stage = time.perf_counter() - t1
         next_seq += n_stage
         stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+        ab_s = algorithmic_bytes(metas, w["feat_dim"], bs)
+        stage_bytes = (ab_s["sample"] + ab_s["dedup_remap"] + ab_s["cache_split"]) / max(len(metas), 1)
         sample_stage = {"edges_per_s": stage_edges / t_stage, "ms_per_step": t_stage / n_stage * 1e3, "steps": n_stage,
+                        "algorithmic_bytes_per_step": stage_bytes,
+                        "hbm_frac": stage_bytes / (t_stage / n_stage) / 1e9 / HBM_PEAK_GBS,
                         "note": "sample + dedup + remap + cache-index split only (no feature gather), same overlap"}
-        extract[0] = True
+        mode[0] = "full"
     metas.clear()
     gather_ms.clear()
+    # the gather with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency from
+    # the slowdown it accepts when it shares the chip with the next batch's sampling chain
+    serial = None
     if (NT > 1 or SPT > 1) and not args.timed_only:
         nt_saved, spt_saved = NT, SPT
         NT = SPT = 1
-        base_seq = next_seq
-        run_region(base_seq, base_seq + 24, True)
+        run_region(next_seq, next_seq + 24, True)
+        next_seq += 24
         torch.cuda.synchronize()
-        g = [x for x in gather_ms if x >= 0]
+        gsel = [x for x in gather_ms if x >= 0]
         b = sum(int(m.num_input) * (4 + 8 * w["feat_dim"]) for m in metas) / max(len(metas), 1)
-        if g:
-            ach = b / (float(np.mean(g)) * 1e-3) / 1e9
-            serial = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(g)), "unit": "GB/s",
+        if gsel:
+            ach = b / (float(np.mean(gsel)) * 1e-3) / 1e9
+            serial = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(gsel)), "unit": "GB/s",
                       "note": "same launch with no concurrent batch (1 host thread / stream)"}
         NT, SPT = nt_saved, spt_saved
+    metas.clear()
+    gather_ms.clear()
+
+    # ---- BASELINE config 3's extract leg on this GPU: features in HOST memory, HBM cache of the top cache_ratio*N
+    # rows ranked by the pre-sampler (dist/pre_sampler.cc:75-162 -> fgnn_presample_count / fgnn_presample_rank), hit
+    # rows from the cache, miss rows read by the gather kernel over the host link (dist_loops.cc:713-846)
+    extract_leg = None
+    if args.cache_ratio > 0 and not args.timed_only and not args.no_extract_leg and args.sample_type in ("khop2", "khop0"):
+        try:
+            extract_leg, next_seq = run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
+                                                    steps_per_epoch, next_seq, run_region, mode, leg, metas, cached_ms)
+        except Exception as e:  # the headline must not be lost to a problem in a secondary measurement
+            extract_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     metas[:] = metas_t
     gather_ms[:] = gather_t
 
@@ -507,73 +536,613 @@ def main():
     edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
     rows = sum(int(m.num_input) for m in metas)
     overflow = any(m.overflow for m in metas)
-    gather_ms = [g for g in gather_ms if g >= 0]
+    gather_ms = [x for x in gather_ms if x >= 0]
     ab = algorithmic_bytes(metas, w["feat_dim"], bs)
     # dominant kernel = feature gather: U*(4 + 8*D) bytes per launch (index read + row read + row write)
     gather_feat_bytes = sum(int(m.num_input) * (4 + 8 * w["feat_dim"]) for m in metas)
     gather_avg_ms = float(np.mean(gather_ms))
     achieved = gather_feat_bytes / len(metas) / (gather_avg_ms * 1e-3) / 1e9
 
-    elapsed, edges, rows = reduce_over_ranks(elapsed, edges, rows)
-
-    ratio = pmc_traffic_ratio()
+    ratio, per_kernel, pmc_file = pmc_traffic()
     # reference point next to the 8 TB/s spec peak the fraction is quoted against: what torch's plain device-to-device
     # copy of 2 GiB reaches on this GPU right now (read + write bytes per second; ordinary loads/stores -- the gather's
-    # non-temporal accesses beat it; tools/gather_sweep.py measured 6.5 TB/s for the gather kernel in isolation)
-    copy_gbs = None
-    if world == 1:
-        a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
-        bdst = torch.empty_like(a)
+    # non-temporal accesses beat it)
+    a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+    bdst = torch.empty_like(a)
+    bdst.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
         bdst.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            bdst.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a, bdst
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, bdst
+    out = {
+        "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, full hot "
+                  "path: sample + dedup + remap + cache-index split + feature/label gather)",
+        "value": edges / elapsed, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-shaped synthetic graph: {graph_desc}; N={w['num_node']}, "
+                               f"E={num_edge}, train set {w['num_train']} uniform random ids (seed 1), feat "
+                               f"f32[N,{w['feat_dim']}] resident in HBM, {args.sample_type} fanout {w['fanout']}, batch "
+                               f"{bs}, cache table ratio {args.cache_ratio}, 1 GPU samples and extracts",
+                   "global_batch": bs, "parallelism": "1 GPU (sampler + extractor)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (gather_feat_bytes / len(metas) * ratio) if ratio else None,
+                     "traffic_source": f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                       "per-launch bytes = measured ratio x this run's algorithmic bytes)"
+                     if pmc_file else None,
+                     "traffic_over_algorithmic_per_kernel": per_kernel,
+                     "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
+                     "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas),
+                     "serial": serial, "torch_copy_GBps": copy_gbs},
+        "roofline_extract": extract_leg,
+        "epoch_time_s": {"sample_plus_extract": steps_per_epoch * (elapsed / args.steps),
+                         "sample_plus_extract_cache_0.2_host_misses":
+                             steps_per_epoch * extract_leg["ms_per_step"] * 1e-3
+                             if extract_leg and "ms_per_step" in extract_leg else None,
+                         "note": f"{steps_per_epoch} steps/epoch x ms_per_step; no training step -- the reference's "
+                                 "Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s); the epoch WITH "
+                                 "training is measured by the N >= 2 runs (trainer processes)"},
+        "sample_stage": sample_stage,
+        "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps,
+        "input_nodes_per_step": rows / args.steps,
+        "algorithmic_bytes_per_step": {k: v / len(metas) for k, v in ab.items()},
+        "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "overflow": bool(overflow), "setup_s": t_setup,
+        "host_threads": NT, "streams": NT * SPT, "host_enqueue_ms_per_step": host_enqueue_ms,
+    }
+    if not args.no_cpu_baseline:
+        if args.sample_type in ("khop2", "khop0"):
+            out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train, sample_type=args.sample_type)
+        else:
+            out["cpu_baseline"] = cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train)
+    print(json.dumps(out), flush=True)
+
+
+def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label, steps_per_epoch, next_seq, run_region,
+                    mode, leg, metas, cached_ms):
+    bs = w["batch_size"]
+    num_node, dim = w["num_node"], w["feat_dim"]
+    t_init = time.time()
+    # pre-sampling: one epoch of the sampling path, frequency of every input node (keys of their own so that the
+    # draws differ from the measured batches', eng_engine.cc:PreSample)
+    freq = torch.zeros(num_node, dtype=torch.int32, device=dev)
+    bt = batches[0]
+    with torch.cuda.stream(streams[0]):
+        for step in range(steps_per_epoch):
+            seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
+            sampler.sample(seeds, (1 << 63) | step, bt, seq=next_seq)
+            next_seq += 1
+            lib.presample_count(freq, bt.input_nodes_buffer(), d_num_nodes=bt.d_num_input())
+        bt.finish()
+        bt.wait()
+        rank = lib.presample_rank(freq)
+        n_cached = int(num_node * args.cache_ratio)
+        ptable = lib.cache_table_build(rank, n_cached)
+        streams[0].synchronize()
+    t_presample = time.time() - t_init
+    # host feature table: 2^k rows, node ids masked (SAMGRAPH_EMPTY_FEAT / the reference's papers100M_empty): the full
+    # 57 GB table is not needed to exercise random host-DRAM row reads; 2^24 rows x 512 B = 8.6 GB is far beyond any cache
+    bits = min(args.empty_feat_bits, int(np.floor(np.log2(num_node))))
+    mask = (1 << bits) - 1
+    host_feat = torch.empty((1 << bits, dim), dtype=torch.float32).pin_memory()
+    host_feat.copy_(feat[:1 << bits])
+    # the cache holds the rows the trainer would read for the cached nodes: feat[rank[i] & mask]
+    cache_rows = torch.empty((n_cached, dim), dtype=torch.float32, device=dev)
+    lib.gather_rows(cache_rows, feat, src_index=rank[:n_cached], src_row_mask=mask)
+    for b in batches:
+        lib.load().fgnn_batch_set_feat_row_mask(b.h, mask)
+    leg.update(table=ptable, cache_rows=cache_rows, host_feat=host_feat)
+    torch.cuda.synchronize()
+    mode[0] = "cached"
+    # correctness of the leg, once: every row of one batch equals feat[input_nodes & mask]
+    step0 = 3
+    sampler.run_batch_cached(next_seq, train[step0 * bs:(step0 + 1) * bs], step0, bt, ptable, cache_rows, host_feat,
+                             label, stream=streams[0])
+    next_seq += 1
+    m = bt.wait()
+    torch.cuda.synchronize()
+    want = feat[(bt.input_nodes().to(torch.int64) & 0xFFFFFFFF) & mask]
+    if not torch.equal(bt.feat(), want):
+        raise RuntimeError("cached extraction differs from the direct gather")
+    del want
+    n = min(args.steps, 64)
+    metas.clear()
+    cached_ms.clear()
+    run_region(next_seq, next_seq + 6, False)
+    next_seq += 6
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_region(next_seq, next_seq + n, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    next_seq += n
+    edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+    rows = sum(int(m.num_input) for m in metas)
+    miss = sum(int(m.num_miss) for m in metas)
+    hit = sum(int(m.num_cache) for m in metas)
+    row_b = dim * 4
+    ms_miss = [a for a, _ in cached_ms if a >= 0]
+    ms_hit = [b for _, b in cached_ms if b >= 0]
+    # per-launch rates from the HIP events of each launch (launches of different batches overlap on the link / in
+    # HBM, so these are what one launch gets while the others run); the whole-region rates are bytes / wall time
+    miss_bytes, hit_bytes = miss * (row_b + 8), hit * (2 * row_b + 8)
+    res = {
+        "workload": f"features in host memory ({1 << bits} rows, ids masked), HBM cache of {n_cached} rows "
+                    f"(ratio {args.cache_ratio}) ranked by the pre-sampler over one epoch, same batches and overlap as "
+                    "the headline",
+        "steps": n, "ms_per_step": dt / n * 1e3, "edges_per_s": edges / dt, "rows_per_s": rows / dt,
+        "hit_rate": hit / max(rows, 1), "miss_rows_per_step": miss / n, "hit_rows_per_step": hit / n,
+        "miss": {"bound": "host link", "bytes_per_step": miss * row_b / n,
+                 "achieved": miss * row_b / dt / 1e9, "peak": HOST_LINK_GBS, "unit": "GB/s",
+                 "frac": miss * row_b / dt / 1e9 / HOST_LINK_GBS,
+                 "avg_launch_ms": float(np.mean(ms_miss)) if ms_miss else None,
+                 "note": "host-link bytes = miss rows x row bytes, over the WALL time of the region (all batches)"},
+        "cached": {"bound": "hbm", "bytes_per_step": hit_bytes / n,
+                   "avg_launch_ms": float(np.mean(ms_hit)) if ms_hit else None,
+                   "achieved": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 if ms_hit else None,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_hit else None,
+                   "note": "CombineCacheData launch: hit rows x (read + write + 2 index words) / its HIP-event time"},
+        "presample_s": t_presample, "init_s": time.time() - t_init - dt,
+        "checked": "one batch compared row by row with the direct gather",
+    }
+    for b in batches:
+        lib.load().fgnn_batch_set_feat_row_mask(b.h, 0xFFFFFFFF)
+    mode[0] = "full"
+    leg.clear()
+    del host_feat, cache_rows, ptable, freq, rank
+    return res, next_seq
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# N >= 2: the factored pipeline, one process per GPU
+
+def default_samplers(n_gpus):
+    """1S+1T at 2 GPUs, 2S+6T at 8 (exp/table4/run.py:329-330 for GraphSAGE / papers100M); one sampler below 8"""
+    return max(1, n_gpus // 4)
+
+
+def split_count(total, parts, index):
+    """how many of `total` units part `index` of `parts` takes (the trainers' share, multi_gpu/train_graphsage.py:293-298)"""
+    return total // parts + (1 if index < total % parts else 0)
+
+
+def pipeline_roles(world, samplers=None):
+    s = samplers if samplers else default_samplers(world)
+    if not (0 < s < world):
+        raise ValueError("need at least one sampler and one trainer: %d samplers of %d ranks" % (s, world))
+    return s, world - s
+
+
+def write_dataset(args, w, dev, out_dir):
+    """the engine's on-disk layout without feat.bin (SAMGRAPH_EMPTY_FEAT, like papers100M_empty)"""
+    os.makedirs(out_dir, exist_ok=True)
+    indptr, indices, ne, desc = gen_graph(args, w, dev)
+    indptr.cpu().numpy().view(np.uint32).tofile(os.path.join(out_dir, "indptr.bin"))
+    chunk = 1 << 28
+    with open(os.path.join(out_dir, "indices.bin"), "wb") as f:
+        for a in range(0, ne, chunk):
+            f.write(indices[a:a + chunk].cpu().numpy().view(np.uint32).tobytes())
+    del indptr, indices
+    from fgnn_hip import rmat
+    train = rmat.train_set(w["num_node"], w["num_train"], 1, dev)
+    train.cpu().numpy().view(np.uint32).tofile(os.path.join(out_dir, "train_set.bin"))
+    np.zeros(0, dtype=np.uint32).tofile(os.path.join(out_dir, "valid_set.bin"))
+    np.zeros(0, dtype=np.uint32).tofile(os.path.join(out_dir, "test_set.bin"))
+    with open(os.path.join(out_dir, "meta.txt"), "w") as f:
+        f.write(f"NUM_NODE {w['num_node']}\nNUM_EDGE {ne}\nFEAT_DIM {w['feat_dim']}\nNUM_CLASS {w['num_class']}\n"
+                f"NUM_TRAIN_SET {w['num_train']}\nNUM_VALID_SET 0\nNUM_TEST_SET 0\n")
+    torch.cuda.empty_cache()
+    return ne, desc
+
+
+class EngineBackend:
+    """the product: arch5 through samgraph.torch / c_lib.so on this rank's GPU"""
+
+    def __init__(self, args, w, job, S, T, is_sampler, idx, dev_id, num_epoch):
+        import samgraph.torch as sam
+        self.sam, self.w, self.is_sampler, self.idx, self.ctx = sam, w, is_sampler, idx, "cuda:%d" % dev_id
+        self.dev_id = dev_id
+        cfg = dict(dataset_path=job["dir"], _arch=sam.kArch5, _sample_type=sam.sample_types[args.sample_type],
+                   batch_size=w["batch_size"], num_epoch=num_epoch, _cache_policy=sam.cache_policies["pre_sample"],
+                   presample_epoch=1, cache_percentage=args.cache_ratio, max_sampling_jobs=10, max_copying_jobs=2,
+                   omp_thread_num=8, num_sample_worker=S, num_train_worker=T, num_fanout=len(w["fanout"]),
+                   fanout=w["fanout"], seed=args.seed)
+        sam.config(cfg)
+        sam.data_init()  # attaches to / creates the job's shared regions; no GPU touched
+
+    def role_init(self):
+        torch.cuda.set_device(self.dev_id)
+        if self.is_sampler:
+            self.sam.sample_init(self.idx, self.ctx)  # sampler 0 pre-samples; the others wait for it inside
+        else:
+            self.sam.train_init(self.idx, self.ctx)
+
+    def num_local_step(self):
+        return self.sam.num_local_step()
+
+    def sample_once(self):
+        self.sam.sample_once()
+
+    def extract_start(self, n):
+        self.sam.extract_start(n)
+
+    def next_batch(self):
+        return self.sam.get_next_batch()
+
+    def blocks(self, key):
+        return self.sam.get_dgl_blocks(key, len(self.w["fanout"]))
+
+    def sampler_stats(self, keys):
+        sam = self.sam
+        return {"edges": sum(sam.get_log_step_value(e, s, sam.kLogL1NumSample) for e, s in keys)}
+
+    def trainer_stats(self, keys):
+        sam, row_b = self.sam, self.w["feat_dim"] * 4
+
+        def tot(item):
+            return sum(sam.get_log_step_value(e, s, item) for e, s in keys)
+        return {"rows": tot(sam.kLogL1FeatureBytes) / row_b, "miss_rows": tot(sam.kLogL1MissBytes) / row_b,
+                "graph_bytes": tot(sam.kLogL1GraphBytes), "ms_miss": tot(sam.kLogL3CacheCombineMissTime) * 1e3,
+                "ms_cache": tot(sam.kLogL3CacheCombineCacheTime) * 1e3}
+
+    def shutdown(self):
+        self.sam.shutdown()
+
+
+class RehearsalBackend:
+    """--rehearse: the job's control plane without a GPU -- launcher, rendezvous, roles, step ranges, the REAL shared
+    ring of c_lib.so between the rank processes (named regions), reductions and the JSON line; a batch is an empty
+    message {key, a number of edges derived from the key}.  Numbers printed in this mode measure nothing."""
+    SLOTS, SLOT_BYTES = 8, 4096
+
+    def __init__(self, args, w, job, S, T, is_sampler, idx, dev_id, num_epoch):
+        import ctypes as C
+        self.C = C
+        self.eng = C.CDLL(os.path.join(ROOT, "fgnn-artifacts_amd", "samgraph", "torch", "c_lib.so"))
+        self.eng.fgnn_host_queue_open.restype = C.c_void_p
+        self.q = C.c_void_p(self.eng.fgnn_host_queue_open(C.c_size_t(self.SLOTS), C.c_size_t(self.SLOT_BYTES)))
+        bs = w["batch_size"]
+        self.steps_per_epoch = (w["num_train"] + bs - 1) // bs
+        self.first, self.local = local_step_range(self.steps_per_epoch, idx, S) if is_sampler else (0, 0)
+        self.j = 0
+        self.got = {}
+
+    @staticmethod
+    def edges_of(key):
+        return 1000 + key % 97
+
+    def role_init(self):
+        pass
+
+    def num_local_step(self):
+        return self.local
+
+    def sample_once(self):
+        key = (self.j // self.local) * self.steps_per_epoch + self.first + self.j % self.local
+        self.j += 1
+        self.eng.fgnn_host_queue_send(self.q, self.C.c_uint64(key), self.C.c_uint64(self.edges_of(key)))
+
+    def extract_start(self, n):
+        pass
+
+    def next_batch(self):
+        k, v = self.C.c_uint64(), self.C.c_uint64()
+        self.eng.fgnn_host_queue_recv(self.q, self.C.byref(k), self.C.byref(v))
+        self.got[k.value] = v.value
+        return k.value
+
+    def sampler_stats(self, keys):
+        return {"edges": float(sum(self.edges_of(e * self.steps_per_epoch + s) for e, s in keys))}
+
+    def trainer_stats(self, keys):
+        assert all(self.got[e * self.steps_per_epoch + s] == self.edges_of(e * self.steps_per_epoch + s) for e, s in keys)
+        return {"rows": float(len(keys)), "miss_rows": 0.0, "graph_bytes": 0.0, "ms_miss": 0.0, "ms_cache": 0.0}
+
+    def shutdown(self):
+        self.eng.fgnn_host_queue_close(self.q)
+
+
+def run_pipeline_rank(args, rank, world):
+    import datetime
+    import shutil
+    import torch.distributed as dist
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+    S, T = pipeline_roles(world, args.samplers)
+    is_sampler = rank < S
+    idx = rank if is_sampler else rank - S
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 and not args.rehearse:
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    dev_id = local_rank % max(n_dev, 1)  # more ranks than GPUs (a functional check on one GPU): they share
+    w = WORKLOADS[args.workload]
+    if args.sample_type is None:
+        args.sample_type = w["sample_type"]
+    bs = w["batch_size"]
+    W, K = args.warmup, args.steps
+    K2 = 0 if (args.no_train_leg or args.rehearse) else min(K, args.train_steps)
+    # ---- job-wide names from rank 0: shared-memory prefix (the processes have no common forking parent) and the
+    # dataset directory
+    obj = [None]
     if rank == 0:
-        out = {
-            "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, full hot "
-                      "path: sample + dedup + remap + cache-index split + feature/label gather)",
-            "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-shaped synthetic power-law CSR, N={w['num_node']}, "
-                                   f"E={num_edge}, feat f32[N,{w['feat_dim']}] resident in HBM, {args.sample_type} fanout "
-                                   f"{w['fanout']}, batch {bs}, cache table ratio {args.cache_ratio}, "
-                                   f"1 process per GPU, full replica per GPU, disjoint step ranges",
-                       "global_batch": bs * world, "parallelism": f"dp{world} (independent samplers)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (gather_feat_bytes / len(metas) * ratio) if ratio else None,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "separate passes; per-launch bytes = measured ratio x this run's "
-                                           "algorithmic bytes)",
-                         "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
-                         "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas),
-                         "serial": serial, "torch_copy_GBps": copy_gbs},
-            "epoch_time_s": {"sample_plus_extract": steps_per_epoch * (elapsed / args.steps) / world,
-                             "note": f"{steps_per_epoch} steps/epoch x ms_per_step / n_gpus; no training step -- the "
-                                     "reference's Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s)"},
-            "sample_stage": sample_stage if world == 1 else None,
-            "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps / world,
-            "input_nodes_per_step": rows / args.steps / world,
-            "algorithmic_bytes_per_step": {k: v / len(metas) for k, v in ab.items()},
-            "whole_path_hbm_frac": sum(ab.values()) / len(metas) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
-            if world == 1 else None,
-            "overflow": bool(overflow), "setup_s": t_setup,
-            "host_threads": NT, "streams": NT * SPT, "host_enqueue_ms_per_step": sum(host_busy) / args.steps * 1e3,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            if args.sample_type in ("khop2", "khop0"):
-                out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train, sample_type=args.sample_type)
+        tag = "fgnn_bench_%d_%x" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFF)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and \
+            os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > (48 << 30) else "/tmp"
+        obj[0] = {"prefix": tag, "dir": os.path.join(base, tag + "_ds")}
+    dist.broadcast_object_list(obj, 0)
+    job = obj[0]
+    os.environ["SAMGRAPH_SHM_PREFIX"] = job["prefix"]
+    os.environ["SAMGRAPH_SHM_KEEP"] = "1"  # rank 0 removes the names after the last barrier
+    os.environ["SAMGRAPH_EMPTY_FEAT"] = str(args.empty_feat_bits)
+    os.environ.setdefault("SAMGRAPH_LOG_LEVEL", "warn")
+    t_setup = time.time()
+    info = [None]
+    if rank == 0:
+        if args.rehearse:
+            info[0] = {"num_edge": w["num_edge"], "graph": "none (rehearsal)"}
+        else:
+            torch.cuda.set_device(dev_id)
+            ne, desc = write_dataset(args, w, torch.device("cuda", dev_id), job["dir"])
+            info[0] = {"num_edge": ne, "graph": desc}
+    dist.broadcast_object_list(info, 0)
+    try:
+        steps_per_epoch = (w["num_train"] + bs - 1) // bs
+        min_local = steps_per_epoch // S
+        per_sampler = max(split_count(W, S, 0) + split_count(K, S, 0) + split_count(K2, S, 0), 1)
+        num_epoch = (per_sampler + min_local - 1) // min_local + 1
+        be = (RehearsalBackend if args.rehearse else EngineBackend)(args, w, job, S, T, is_sampler, idx, dev_id, num_epoch)
+        dist.barrier()  # every process has attached to every shared region
+        if is_sampler:
+            be.role_init()
+            dist.barrier()  # the rank list is in shared memory: trainers may build their caches
+        else:
+            dist.barrier()
+            be.role_init()
+        dist.barrier()
+        t_setup = time.time() - t_setup
+
+        first_step, local_steps = local_step_range(steps_per_epoch, idx, S) if is_sampler else (0, 0)
+        if is_sampler:
+            assert be.num_local_step() == local_steps, (be.num_local_step(), local_steps)
+        sampled = [0]  # batches this sampler has produced
+        keys = []
+
+        model = opt = loss_fcn = None
+        if K2 and T > 1:
+            # gradient all-reduce between the trainers: RCCL ("nccl") when each has its own GPU, gloo when ranks
+            # share one (functional check on a single-GPU box: RCCL refuses two ranks on one device).  new_group is
+            # a collective call: every rank takes part
+            tgroup = dist.new_group(ranks=list(range(S, world)), backend="nccl" if n_dev >= world else "gloo",
+                                    timeout=datetime.timedelta(seconds=600))
+        if not is_sampler and K2:
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            from models import MODELS
+            model = MODELS["graphsage"](w["feat_dim"], 256, w["num_class"], len(w["fanout"]), 0.5).to("cuda:%d" % dev_id)
+            if T > 1:
+                model = torch.nn.parallel.DistributedDataParallel(
+                    model, device_ids=[dev_id] if n_dev >= world else None, process_group=tgroup)
+            loss_fcn = torch.nn.CrossEntropyLoss()
+            opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True)
+            model.train()
+
+        def region(total, train):
+            """`total` batches through the pipeline: this rank's share as a sampler (sample_once) or as a trainer
+            (get_next_batch [+ training step]); returns (wall time between the two barriers, this rank's busy time)"""
+            mine = split_count(total, S, idx) if is_sampler else split_count(total, T, idx)
+            dist.barrier()
+            t0 = time.perf_counter()
+            if is_sampler:
+                for _ in range(mine):
+                    be.sample_once()
+                    j = sampled[0]
+                    sampled[0] += 1
+                    keys.append((j // local_steps, first_step + j % local_steps))
             else:
-                out["cpu_baseline"] = cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+                if mine:
+                    be.extract_start(mine)
+                for _ in range(mine):
+                    key = be.next_batch()
+                    if train:
+                        blocks, feat, label = be.blocks(key)
+                        loss = loss_fcn(model(blocks, feat), label)
+                        opt.zero_grad()
+                        loss.backward()
+                        opt.step()
+                        torch.cuda.current_stream().synchronize()
+                    keys.append((key // steps_per_epoch, key % steps_per_epoch))
+            busy = time.perf_counter() - t0
+            dist.barrier()  # every batch of the region has been consumed
+            return time.perf_counter() - t0, busy
+
+        region(W, False)
+        del keys[:]
+        elapsed, busy = region(K, False)
+        # a sampler's publisher thread logs a batch when it publishes it: all published by the barrier above
+        stats = dict(edges=0.0, rows=0.0, miss_rows=0.0, graph_bytes=0.0, ms_miss=0.0, ms_cache=0.0)
+        stats.update(be.sampler_stats(keys) if is_sampler else be.trainer_stats(keys))
+        n_batches = len(keys)
+        train_elapsed = None
+        if K2:
+            del keys[:]
+            train_elapsed, _ = region(K2, True)
+
+        # reductions: time = MAX over ranks, work = SUM over ranks; per-role busy time = MAX within the role
+        def red(vals, op):
+            t = torch.tensor(vals, dtype=torch.float64)
+            dist.all_reduce(t, op=op)
+            return [float(x) for x in t]
+        t_max, t_train, s_busy, t_busy, setup_max = red(
+            [elapsed, train_elapsed or 0.0, busy if is_sampler else 0.0, busy if not is_sampler else 0.0, t_setup],
+            dist.ReduceOp.MAX)
+        edges, rows, miss_rows, graph_bytes, ms_miss, ms_cache, nb_s, nb_t = red(
+            [stats["edges"], stats["rows"], stats["miss_rows"], stats["graph_bytes"], stats["ms_miss"],
+             stats["ms_cache"], n_batches if is_sampler else 0, n_batches if not is_sampler else 0],
+            dist.ReduceOp.SUM)
+        be.shutdown()
+        dist.barrier()
+        if rank == 0:
+            assert int(nb_s) == K and int(nb_t) == K, (nb_s, nb_t, K)
+            row_b = w["feat_dim"] * 4
+            hit_rows = rows - miss_rows
+            handoff_bytes = graph_bytes + 8 * rows + 4 * bs * K  # COO arrays + (miss|cache) index pairs + output ids
+            cache_launch_bytes = hit_rows * (2 * row_b + 8)
+            out = {
+                "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, "
+                          "factored pipeline: sampler GPUs (sample + dedup + remap + cache-index split) -> HBM message "
+                          "ring -> trainer GPUs (cached feature extraction)); edges of the batches the trainers "
+                          "consumed / wall time",
+                "value": edges / t_max, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": t_max / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "u32", "data": "synthetic" if not args.rehearse else "none (control-plane rehearsal)",
+                "config": {"workload": f"{args.workload}-shaped synthetic graph: {info[0]['graph']}; N={w['num_node']}, "
+                                       f"E={info[0]['num_edge']}, train set {w['num_train']} uniform random ids (seed 1), "
+                                       f"{args.sample_type} fanout {w['fanout']}, batch {bs}; features in host memory "
+                                       f"(2^{args.empty_feat_bits} rows, ids masked = SAMGRAPH_EMPTY_FEAT), pre-sample "
+                                       f"cache ratio {args.cache_ratio} in every trainer's HBM; arch5 through "
+                                       "samgraph.torch / c_lib.so, one process per GPU",
+                           "global_batch": bs, "parallelism": f"{S}S+{T}T (samplers -> device ring -> trainers)"},
+                "roofline": {"bound": "hbm", "kernel": "gather_rows16_kernel (CombineCacheData on the trainer GPUs)",
+                             "achieved": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 if ms_cache else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cache else None,
+                             "traffic": None, "avg_launch_ms": ms_cache / K,
+                             "algorithmic_bytes_per_launch": cache_launch_bytes / K,
+                             "note": "hit rows x (row read + row write + 2 index words) / HIP-event time of the launch, "
+                                     "summed over the trainers' batches"},
+                "pipeline": {
+                    "samplers": S, "trainers": T, "devices": min(n_dev, world),
+                    "sampler_side_edges_per_s": edges / s_busy if s_busy else None,
+                    "sampler_busy_s": s_busy, "trainer_busy_s": t_busy,
+                    "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
+                    "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
+                    "handoff_peak_GBps": XGMI_LINK_GBS,
+                    "miss": {"bound": "host link", "bytes_per_step": miss_rows * row_b / K,
+                             "achieved": miss_rows * row_b / t_max / 1e9 / T, "peak": HOST_LINK_GBS,
+                             "unit": "GB/s per trainer GPU", "frac": miss_rows * row_b / t_max / 1e9 / T / HOST_LINK_GBS,
+                             "avg_launch_ms": ms_miss / K,
+                             "launch_GBps": miss_rows * row_b / (ms_miss * 1e-3) / 1e9 if ms_miss else None},
+                },
+                "epoch_time_s": {"sample_plus_extract": steps_per_epoch * t_max / K,
+                                 "with_training": steps_per_epoch * t_train / K2 if K2 else None,
+                                 "training_steps_timed": K2,
+                                 "note": f"{steps_per_epoch} steps/epoch x seconds per step of the region; with_training "
+                                         "= the same pipeline with a GraphSAGE step (examples/models.py, hidden 256, "
+                                         "Adam) on every batch, gradients all-reduced over RCCL between trainers"},
+                "edges_per_step": edges / K, "input_nodes_per_step": rows / K, "setup_s": setup_max,
+            }
+            print(json.dumps(out), flush=True)
+    finally:
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        if rank == 0:
+            shutil.rmtree(job["dir"], ignore_errors=True)
+            if os.path.isdir("/dev/shm"):
+                for f in os.listdir("/dev/shm"):
+                    if f.startswith(job["prefix"]):
+                        try:
+                            os.unlink(os.path.join("/dev/shm", f))
+                        except OSError:
+                            pass
+    dist.destroy_process_group()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (nothing in this process has touched
+    the GPU), let them rendezvous on 127.0.0.1, relay rank 0's JSON line."""
+    import socket
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FGNN_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line = None
+    rc = 0
+    try:
+        out0 = b""
+        while True:
+            try:
+                out0, _ = procs[0].communicate(timeout=1.0)
+                break
+            except subprocess.TimeoutExpired:
+                bad = [p.returncode for p in procs[1:] if p.poll() not in (None, 0)]
+                if bad:  # a rank died: the others would wait for it until the rendezvous times out
+                    rc = bad[0]
+                    break
+        for ln in out0.decode(errors="replace").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+        if not rc:
+            for p in procs:
+                rc = rc or p.wait()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if line is None or rc:
+        sys.exit("bench.py: rank processes failed (rc %s)" % rc)
+    print(line, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=151)   # one papers100M epoch at batch 8000
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
+    ap.add_argument("--graph", default=os.environ.get("FGNN_BENCH_GRAPH", "rmat"), choices=["rmat", "powerlaw"],
+                    help="rmat: SURVEY.md 8(d)'s generator (default); powerlaw: round 1's locality-free generator")
+    ap.add_argument("--cache-ratio", type=float, default=0.2)
+    ap.add_argument("--empty-feat-bits", type=int, default=24,
+                    help="host feature table of 2^k rows, node ids masked (SAMGRAPH_EMPTY_FEAT)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extract-leg", action="store_true", help="N=1: skip the cache-0.2 / host-miss extract leg")
+    ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="N=1: skip the extra measurements after the timed region: under rocprofv3 --stats every "
+                         "gather launch is then one of the overlapped kind the roofline line is computed from")
+    ap.add_argument("--host-threads", type=int, default=1, help="N=1: host threads enqueueing batches")
+    ap.add_argument("--streams-per-thread", type=int, default=3,
+                    help="N=1: HIP streams each host thread rotates over (batches in flight = threads x this); "
+                         "measured on MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
+    ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
+    ap.add_argument("--no-train-leg", action="store_true", help="N>=2: skip the region with a training step per batch")
+    ap.add_argument("--train-steps", type=int, default=40, help="N>=2: batches of the training region (<= --steps)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>=2 without a GPU: launcher, rendezvous, roles, step ranges, the real shared ring and the "
+                         "reductions with empty batches (tests); measures nothing")
+    ap.add_argument("--sample-type", default=None, choices=list(SAMPLE_TYPES),
+                    help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
+                         "multi_gpu/train_graphsage.py:75)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            return launch_ranks(args)  # before anything touches the GPU
+        return run_single(args)
+    world, rank = int(env_world), int(os.environ.get("RANK", "0"))
+    if args.gpus not in (1, world):
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if world == 1:
+        return run_single(args)
+    return run_pipeline_rank(args, rank, world)
 
 
 if __name__ == "__main__":

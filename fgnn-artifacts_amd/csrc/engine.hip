@@ -60,7 +60,10 @@ struct fgnn_batch {
   void *ws;                               // scratch for the cache split
   size_t ws_bytes;
   hipEvent_t done;
-  hipEvent_t t0, t1;                      // optional: bracket the feature gather (fgnn_batch_enable_timing)
+  hipEvent_t t0, t1, t2;                  // optional (fgnn_batch_enable_timing): t0..t1 bracket the feature gather of
+                                          // fgnn_batch_extract / the miss-row gather of fgnn_batch_extract_cached,
+                                          // t1..t2 the cached-row gather
+  bool timed2;
   bool timing, timed;
   fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
   uint32_t feat_row_mask;                 // SAMGRAPH_EMPTY_FEAT mock extraction (all ones = off)
@@ -199,6 +202,7 @@ extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->t0) (void)hipEventDestroy(b->t0);
   if (b->t1) (void)hipEventDestroy(b->t1);
+  if (b->t2) (void)hipEventDestroy(b->t2);
   delete b;
 }
 
@@ -433,9 +437,10 @@ extern "C" int fgnn_batch_enable_timing(fgnn_batch *b, int on) {
   if (on && !b->t0) {
     FGNN_HIP_CHECK(hipEventCreate(&b->t0));
     FGNN_HIP_CHECK(hipEventCreate(&b->t1));
+    FGNN_HIP_CHECK(hipEventCreate(&b->t2));
   }
   b->timing = on != 0;
-  b->timed = false;
+  b->timed = b->timed2 = false;
   return FGNN_OK;
 }
 
@@ -443,6 +448,15 @@ extern "C" float fgnn_batch_gather_ms(fgnn_batch *b) {
   float ms = -1.0f;
   if (b && b->timed && hipEventElapsedTime(&ms, b->t0, b->t1) != hipSuccess) ms = -1.0f;
   return ms;
+}
+
+extern "C" int fgnn_batch_extract_cached_ms(fgnn_batch *b, float out[2]) {
+  if (!b || !out) return FGNN_EINVAL;
+  out[0] = out[1] = -1.0f;
+  if (!b->timed2) return FGNN_OK;
+  if (hipEventElapsedTime(&out[0], b->t0, b->t1) != hipSuccess) out[0] = -1.0f;
+  if (hipEventElapsedTime(&out[1], b->t1, b->t2) != hipSuccess) out[1] = -1.0f;
+  return FGNN_OK;
 }
 
 extern "C" int fgnn_batch_set_feat_row_mask(fgnn_batch *b, uint32_t mask) {
@@ -474,15 +488,37 @@ extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, 
                                          const void *label, void *stream) {
   if (!b || !b->feat_dim) return FGNN_EINVAL;
   int rc = FGNN_OK;
+  auto st = static_cast<hipStream_t>(stream);
+  const bool timing = b->timing && full_feat && cache_rows;
+  if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
   if (full_feat)  // CombineMissData with the row fetch fused in
     rc = fgnn_gather_rows_masked(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss,
                                  b->feat_rows_cap, b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
+  if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
   if (rc == FGNN_OK && cache_rows)  // CombineCacheData
     rc = fgnn_gather_rows(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,
                           b->feat_dim, b->feat_dtype, stream);
+  if (timing) {
+    FGNN_HIP_CHECK(hipEventRecord(b->t2, st));
+    b->timed2 = true;
+  }
   if (rc == FGNN_OK && label && b->num_output)
     rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
                           b->label_dtype, stream);
+  return rc;
+}
+
+// sampler + trainer side of one batch on ONE GPU with a feature cache: sample -> cache index -> CombineMissData (rows
+// fetched from `full_feat`, typically registered host memory) + CombineCacheData -> finish
+extern "C" int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                             uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
+                                             const void *cache_rows, const void *full_feat, const void *label,
+                                             void *stream) {
+  if (!cache_table) return FGNN_EINVAL;
+  int rc = fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
+  if (rc == FGNN_OK) rc = fgnn_batch_cache_index(out, cache_table, stream);
+  if (rc == FGNN_OK) rc = fgnn_batch_extract_cached(out, cache_rows, full_feat, label, stream);
+  if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
   return rc;
 }
 

@@ -5,16 +5,107 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
+#include <cstring>
 #include <fstream>
 #include <unordered_map>
+#include <vector>
 
 namespace sam {
 
-void *SharedAnonymous(size_t bytes) {
+// ---- memory shared by the processes of one job -------------------------------------------------------------------
+// Default: MAP_SHARED|MAP_ANONYMOUS, inherited through fork (the reference's layout: config + data_init in the parent,
+// workers forked afterwards).  With SAMGRAPH_SHM_PREFIX=<name> the k-th region a process asks for is the POSIX shared
+// memory object "/<name>.<k>" instead: processes that were NOT forked from a common parent (one process per GPU started
+// by torchrun) run the same config + data_init and therefore meet in the same regions.  Whoever creates a region
+// initialises and publishes it, everybody else blocks in SharedCreate until then.  A header page in front of the user
+// pointer carries the hand-shake; it exists in both modes so that the two differ in nothing else.
+namespace {
+constexpr size_t kShmHeader = 4096;
+struct ShmHeader {
+  uint64_t magic;
+  uint64_t bytes;
+  int ready;
+};
+constexpr uint64_t kShmMagic = 0x46474e4e53484d31ull;  // "FGNNSHM1"
+std::vector<std::string> &OwnedNames() {
+  static std::vector<std::string> v;
+  return v;
+}
+void UnlinkOwned() {
+  for (auto &n : OwnedNames()) shm_unlink(n.c_str());
+  OwnedNames().clear();
+}
+}  // namespace
+
+SharedRegion SharedCreate(size_t bytes) {
   if (bytes == 0) bytes = 4096;
-  void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
-  SAM_CHECK(p != MAP_FAILED) << "mmap of " << bytes << " bytes failed";
-  return p;
+  const size_t total = bytes + kShmHeader;
+  static int counter = 0;
+  const char *prefix = getenv("SAMGRAPH_SHM_PREFIX");
+  SharedRegion r{nullptr, true};
+  void *p = MAP_FAILED;
+  if (!prefix || !*prefix) {
+    p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    SAM_CHECK(p != MAP_FAILED) << "mmap of " << total << " bytes failed";
+  } else {
+    const std::string name = std::string("/") + prefix + "." + std::to_string(counter++);
+    int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd >= 0) {
+      // the creator removes the names when it exits (the mappings stay valid); SAMGRAPH_SHM_KEEP=1 leaves that to the
+      // launcher, for jobs whose processes may attach after the creator has gone
+      const char *keep = getenv("SAMGRAPH_SHM_KEEP");
+      if (!(keep && atoi(keep))) {
+        if (OwnedNames().empty()) atexit(UnlinkOwned);
+        OwnedNames().push_back(name);
+      }
+      SAM_CHECK(ftruncate(fd, (off_t)total) == 0) << "cannot size " << name << " to " << total << " bytes";
+    } else {
+      SAM_CHECK(errno == EEXIST) << "shm_open " << name << ": " << strerror(errno);
+      r.creator = false;
+      fd = shm_open(name.c_str(), O_RDWR, 0600);
+      SAM_CHECK(fd >= 0) << "shm_open " << name << ": " << strerror(errno);
+      Timer t;
+      for (;;) {  // the creator sizes the object right after creating it
+        struct stat st;
+        SAM_CHECK(fstat(fd, &st) == 0);
+        if ((size_t)st.st_size == total) break;
+        SAM_CHECK(st.st_size == 0) << name << " has " << st.st_size << " bytes, expected " << total
+                                   << ": the processes of a job must run the same configuration";
+        SAM_CHECK(t.Passed() < 600.0) << name << " was never sized by its creator";
+        usleep(200);
+      }
+    }
+    p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    SAM_CHECK(p != MAP_FAILED) << "mmap of " << name << " (" << total << " bytes) failed";
+    close(fd);
+  }
+  auto *h = static_cast<ShmHeader *>(p);
+  r.ptr = static_cast<char *>(p) + kShmHeader;
+  if (r.creator) {
+    h->magic = kShmMagic;
+    h->bytes = bytes;
+  } else {
+    Timer t;
+    while (__atomic_load_n(&h->ready, __ATOMIC_ACQUIRE) != 1) {
+      SAM_CHECK(t.Passed() < 1800.0) << "shared region " << counter - 1 << " was never published by its creator";
+      usleep(200);
+    }
+    SAM_CHECK(h->magic == kShmMagic && h->bytes == bytes);
+  }
+  return r;
+}
+
+void SharedPublish(void *ptr) {
+  auto *h = reinterpret_cast<ShmHeader *>(static_cast<char *>(ptr) - kShmHeader);
+  SAM_CHECK(h->magic == kShmMagic);
+  __atomic_store_n(&h->ready, 1, __ATOMIC_RELEASE);
+}
+
+void *SharedAnonymous(size_t bytes) {
+  SharedRegion r = SharedCreate(bytes);
+  if (r.creator) SharedPublish(r.ptr);
+  return r.ptr;
 }
 
 HostArray MapFile(const std::string &path, size_t expect_bytes, bool required) {
@@ -49,14 +140,18 @@ static HostArray ReadFileShared(const std::string &path, size_t expect_bytes) {
   struct stat st;
   SAM_CHECK(fstat(fd, &st) == 0);
   SAM_CHECK_EQ((size_t)st.st_size, expect_bytes) << path << " has the wrong size ";
-  a.ptr = SharedAnonymous(expect_bytes);
+  SharedRegion reg = SharedCreate(expect_bytes);
+  a.ptr = reg.ptr;
   a.bytes = expect_bytes;
   a.from_file = true;
-  size_t done = 0;
-  while (done < expect_bytes) {
-    ssize_t r = pread(fd, static_cast<char *>(a.ptr) + done, expect_bytes - done, (off_t)done);
-    SAM_CHECK(r > 0) << "short read from " << path;
-    done += (size_t)r;
+  if (reg.creator) {
+    size_t done = 0;
+    while (done < expect_bytes) {
+      ssize_t r = pread(fd, static_cast<char *>(a.ptr) + done, expect_bytes - done, (off_t)done);
+      SAM_CHECK(r > 0) << "short read from " << path;
+      done += (size_t)r;
+    }
+    SharedPublish(a.ptr);
   }
   close(fd);
   return a;

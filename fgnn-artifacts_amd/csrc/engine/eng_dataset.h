@@ -24,8 +24,16 @@ struct Dataset {
   void Load(const RunConfig &rc);
 };
 
-// MAP_SHARED|MAP_ANONYMOUS zero-filled host memory visible to forked children
-void *SharedAnonymous(size_t bytes);
+// Zero-filled host memory shared by the processes of a job: MAP_SHARED|MAP_ANONYMOUS inherited through fork, or -- with
+// SAMGRAPH_SHM_PREFIX set -- a named POSIX shared-memory object that processes started independently (torchrun) meet in
+// (eng_dataset.cc).  The creator of a region fills it and calls SharedPublish; SharedCreate blocks everybody else until then.
+struct SharedRegion {
+  void *ptr;
+  bool creator;
+};
+SharedRegion SharedCreate(size_t bytes);
+void SharedPublish(void *ptr);
+void *SharedAnonymous(size_t bytes);  // a region without initial content (published at once)
 HostArray MapFile(const std::string &path, size_t expect_bytes, bool required);
 
 }  // namespace sam

@@ -108,12 +108,15 @@ void Engine::Init() {
     // the two halves of that worker, so each creates its own after the fork
     Timer tq;
     if (RC().run_arch == kArch5) CreateQueue();
-    void *bp = SharedAnonymous(sizeof(pthread_barrier_t));
-    sampler_barrier_ = static_cast<pthread_barrier_t *>(bp);
-    pthread_barrierattr_t attr;
-    pthread_barrierattr_init(&attr);
-    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
-    pthread_barrier_init(sampler_barrier_, &attr, (unsigned)RC().num_sample_worker);
+    SharedRegion bp = SharedCreate(sizeof(pthread_barrier_t));
+    sampler_barrier_ = static_cast<pthread_barrier_t *>(bp.ptr);
+    if (bp.creator) {
+      pthread_barrierattr_t attr;
+      pthread_barrierattr_init(&attr);
+      pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+      pthread_barrier_init(sampler_barrier_, &attr, (unsigned)RC().num_sample_worker);
+      SharedPublish(bp.ptr);
+    }
     Profiler::Get().LogInit(kLogInitL2DistQueue, tq.Passed());
   }
   Profiler::Get().LogInit(kLogInitL1Common, t.Passed());
@@ -277,6 +280,7 @@ void Engine::InitInProcess() {
   SAM_HIP(hipSetDevice(RC().trainer_ctx.device_id));
   tdevice_ = RC().trainer_ctx.device_id;
   SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
+  for (auto &e : te_) SAM_HIP(hipEventCreate(&e));
   SAM_HIP(hipHostRegister(ds_.feat.ptr, ds_.feat.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
   dev_host_feat_ = DeviceVisible(ds_.feat.ptr);
   SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
@@ -391,7 +395,7 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_, arch6));
   pool_.reset(new GraphPool(RC().max_copying_jobs));
-  slots_.resize(2);
+  slots_.resize(3);  // batches in flight: enqueued by sample_once, published by the publisher thread
   for (auto &s : slots_) {
     int err = 0;
     s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
@@ -498,15 +502,36 @@ void Engine::BuildCacheTable() {
 }
 
 void Engine::PublishPending() {
-  if (pending_slot_ < 0) return;
+  std::unique_lock<std::mutex> lk(pub_mu_);
+  pub_cv_.wait(lk, [&] { return pub_q_.empty(); });
+}
+
+void Engine::PublisherLoop() {
   SAM_HIP(hipSetDevice(device_));
-  Slot &s = slots_[pending_slot_];
+  for (;;) {
+    int cur;
+    {
+      std::unique_lock<std::mutex> lk(pub_mu_);
+      pub_cv_.wait(lk, [&] { return pub_stop_ || !pub_q_.empty(); });
+      if (pub_q_.empty()) return;
+      cur = pub_q_.front();
+    }
+    PublishSlot(cur);
+    {
+      std::lock_guard<std::mutex> lk(pub_mu_);
+      pub_q_.pop_front();
+      slots_[cur].pending = false;
+    }
+    pub_cv_.notify_all();
+  }
+}
+
+void Engine::PublishSlot(int slot) {
+  Slot &s = slots_[slot];
   fgnn_batch_meta m;
   SAM_FGNN(fgnn_batch_wait(s.fb, &m));  // the pack kernel is ordered before the summary copy
   SAM_CHECK_EQ(m.overflow, 0u) << "batch exceeded its buffers";
   mq_->SimpleSend(s.mq_key);
-  s.pending = false;
-  pending_slot_ = -1;
   float ms_sample = 0, ms_index = 0, ms_send = 0;
   (void)hipEventElapsedTime(&ms_sample, s.e0, s.e1);
   (void)hipEventElapsedTime(&ms_index, s.e1, s.e2);
@@ -536,7 +561,11 @@ void Engine::SampleOnceArch5() {
   const uint64_t key = BatchKey(shuffler_->Epoch(), shuffler_->Step());
   const int cur = (int)(next_slot_++ % slots_.size());
   Slot &s = slots_[cur];
-  SAM_CHECK(!s.pending);
+  {  // the slot's previous batch (slots_.size() batches ago) must have been published
+    std::unique_lock<std::mutex> lk(pub_mu_);
+    pub_cv_.wait(lk, [&] { return !s.pending; });
+    if (!publish_thread_.joinable()) publish_thread_ = std::thread([this] { PublisherLoop(); });
+  }
   s.started = Timer();
   s.key = key;
   SAM_HIP(hipEventRecord(s.e0, s.st));
@@ -566,12 +595,14 @@ void Engine::SampleOnceArch5() {
   a.slot_bytes = mq_->SlotBytes();
   SAM_FGNN(LaunchPack(a, s.st));
   SAM_FGNN(fgnn_batch_finish(s.fb, s.st));
-  s.pending = true;
-  // publish the PREVIOUS batch now that this one is in flight (the reference's PIPELINE branch,
-  // dist_loops_arch5.cc:108-146); the last batch of an epoch is flushed immediately
-  const int prev = pending_slot_;
-  if (prev >= 0) PublishPending();
-  pending_slot_ = cur;
+  {  // hand the batch to the publisher thread: it waits for the GPU work and publishes in this order
+    std::lock_guard<std::mutex> lk(pub_mu_);
+    s.pending = true;
+    pub_q_.push_back(cur);
+  }
+  pub_cv_.notify_all();
+  // the next call reshuffles the seed array on the device: every batch reading it must be through (the reference
+  // flushes at the same point, dist_loops_arch5.cc:131-137)
   if (shuffler_->IsLastBatch()) PublishPending();
 }
 
@@ -596,6 +627,7 @@ void Engine::TrainInit(int worker_id, Context ctx, DistType type) {
   SAM_HIP(hipSetDevice(ctx.device_id));
   tdevice_ = ctx.device_id;
   SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
+  for (auto &e : te_) SAM_HIP(hipEventCreate(&e));
   if (!second_half) mq_->PinMemory();
   // the host feature table becomes GPU-readable: miss rows are fetched by the gather kernel itself
   // (replaces the OpenMP ExtractMissData + H2D copy, cuda_cache_manager_host.cc:38-56)
@@ -713,6 +745,7 @@ void Engine::TrainerOnce() {
   b->feat = d_feat;
   b->feat_rows = hdr.input_size;
   size_t miss_rows = num_miss;
+  bool timed_gathers = false;
   if (!use_cache) {
     SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
                                      ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
@@ -733,12 +766,16 @@ void Engine::TrainerOnce() {
     SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
                               tstream_));
   } else {
+    SAM_HIP(hipEventRecord(te_[0], tstream_));
     if (num_miss)   // CombineMissData with the host fetch fused in
       SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss,
                                        ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
+    SAM_HIP(hipEventRecord(te_[1], tstream_));
     if (num_cache)  // CombineCacheData
       SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, d_cidx[2], d_cidx[3], num_cache, nullptr, num_cache,
                                 ds_.feat_dim, FGNN_F32, tstream_));
+    SAM_HIP(hipEventRecord(te_[2], tstream_));
+    timed_gathers = true;
   }
   // labels (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) -- gathered on the GPU from the HBM copy
   void *d_lab = dev_pool_.Alloc(hdr.output_size * 8);
@@ -755,6 +792,13 @@ void Engine::TrainerOnce() {
   P.LogStep(b->key, kLogL1RecvTime, recv_time);
   P.LogStep(b->key, kLogL1CopyTime, recv_time + copy_time);
   P.LogStep(b->key, kLogL2CacheCopyTime, copy_time);
+  if (timed_gathers) {  // device time of the two gathers (the reference times them on the host around syncs)
+    float ms_miss = 0, ms_cache = 0;
+    (void)hipEventElapsedTime(&ms_miss, te_[0], te_[1]);
+    (void)hipEventElapsedTime(&ms_cache, te_[1], te_[2]);
+    P.LogStep(b->key, kLogL3CacheCombineMissTime, ms_miss * 1e-3);
+    P.LogStep(b->key, kLogL3CacheCombineCacheTime, ms_cache * 1e-3);
+  }
   P.LogStep(b->key, kLogL1FeatureBytes, (double)hdr.input_size * row_bytes);
   P.LogStep(b->key, kLogL1MissBytes, (double)miss_rows * row_bytes);
   P.LogStep(b->key, kLogL1LabelBytes, (double)hdr.output_size * 8);
@@ -850,11 +894,20 @@ void Engine::Shutdown() {
   if (pool_) pool_->Stop();
   if (sample_thread_.joinable()) sample_thread_.join();
   if (extract_thread_.joinable()) extract_thread_.join();
-  if (dist_type_ == DistType::Sample || sampler_) PublishPending();
+  if (publish_thread_.joinable()) {  // publishes what is still in flight, then stops
+    {
+      std::lock_guard<std::mutex> lk(pub_mu_);
+      pub_stop_ = true;
+    }
+    pub_cv_.notify_all();
+    publish_thread_.join();
+  }
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto &sl : slots_)
     if (sl.st) (void)hipStreamSynchronize(sl.st);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
+  for (auto &e : te_)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (mq_ && ring_id_ >= 0) {
     // messages published into this sampler's HBM ring must stay readable until their receivers have copied them
     // (the in-process engines read their own ring and their threads have been joined: nothing to wait for)

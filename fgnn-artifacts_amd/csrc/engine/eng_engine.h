@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -126,7 +127,9 @@ class Engine {
   void PreSampleStatic();
   void BuildCacheTable();
   void SampleOnceArch5();
-  void PublishPending();
+  void PublishPending();          // returns once every batch enqueued so far has been published
+  void PublishSlot(int slot);     // publisher thread: wait for the batch in `slot`, publish it, log its times
+  void PublisherLoop();
   // arch4 with the dynamic cache prototype (eng_dynamic.cc)
   void InitDynamicCache();
   void SampleOnceDynamic();
@@ -142,6 +145,7 @@ class Engine {
   hipStream_t stream_ = nullptr;
   int tdevice_ = -1;            // trainer-side device (arch5 trainer process, arch2-4 extractor)
   hipStream_t tstream_ = nullptr;
+  hipEvent_t te_[3] = {nullptr, nullptr, nullptr};  // trainer: brackets of the miss-row and cached-row gathers
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
@@ -175,7 +179,15 @@ class Engine {
   };
   std::vector<Slot> slots_;
   size_t next_slot_ = 0;
-  int pending_slot_ = -1;
+  // arch5 sampler: batches whose GPU work is enqueued, oldest first.  The publisher thread waits for each one's
+  // completion and publishes it, so sample_once returns after ENQUEUEING a batch and no batch is ever held back until
+  // the next call (the reference's PIPELINE branch keeps the newest batch unpublished until the next sample_once or
+  // the end of the epoch, dist_loops_arch5.cc:108-146)
+  std::deque<int> pub_q_;
+  std::mutex pub_mu_;
+  std::condition_variable pub_cv_;
+  std::thread publish_thread_;
+  bool pub_stop_ = false;
 
   // arch5 shared state (created before fork)
   MemoryQueue *mq_ = nullptr;

@@ -96,6 +96,55 @@ extern "C" int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t 
   return bad;
 }
 
+extern "C" int fgnn_host_queue_named_role(size_t slots, size_t slot_bytes, size_t messages, int role, int index,
+                                          int peers) {
+  if (peers < 1 || index < 0 || index >= peers || slot_bytes < 64) return 2;
+  MemoryQueue mq(slot_bytes, slots);
+  if (role == 0) {
+    for (size_t m = (size_t)index; m < messages; m += (size_t)peers) {
+      size_t key;
+      auto *w = static_cast<uint64_t *>(mq.GetPtr(&key));
+      const size_t words = 2 + (Mix(m) % ((mq.SlotBytes() / 8) - 2));
+      w[0] = m;
+      w[1] = words;
+      for (size_t i = 2; i < words; ++i) w[i] = Mix(m * 1315423911ull + i);
+      mq.SimpleSend(key);
+    }
+    return 0;
+  }
+  int bad = 0;
+  const size_t mine = messages / (size_t)peers + ((size_t)index < messages % (size_t)peers ? 1 : 0);
+  for (size_t k = 0; k < mine; ++k) {
+    size_t key;
+    auto *w = static_cast<const uint64_t *>(mq.Recv(&key));
+    const size_t m = w[0], words = w[1];
+    bool ok = m < messages && words >= 2 && words <= mq.SlotBytes() / 8;
+    for (size_t i = 2; ok && i < words; ++i) ok = w[i] == Mix(m * 1315423911ull + i);
+    if (!ok) bad = 1;
+    mq.Release(key);
+  }
+  return bad;
+}
+
+extern "C" void *fgnn_host_queue_open(size_t slots, size_t slot_bytes) { return new MemoryQueue(slot_bytes, slots); }
+extern "C" void fgnn_host_queue_send(void *q, uint64_t key, uint64_t value) {
+  auto *mq = static_cast<MemoryQueue *>(q);
+  size_t k;
+  auto *w = static_cast<uint64_t *>(mq->GetPtr(&k));
+  w[0] = key;
+  w[1] = value;
+  mq->SimpleSend(k);
+}
+extern "C" void fgnn_host_queue_recv(void *q, uint64_t *key, uint64_t *value) {
+  auto *mq = static_cast<MemoryQueue *>(q);
+  size_t k;
+  auto *w = static_cast<const uint64_t *>(mq->Recv(&k));
+  *key = w[0];
+  *value = w[1];
+  mq->Release(k);
+}
+extern "C" void fgnn_host_queue_close(void *q) { delete static_cast<MemoryQueue *>(q); }
+
 extern "C" int fgnn_host_config_probe(const char **keys, const char **vals, size_t n, size_t out[4]) {
   RunConfig rc;
   rc.Parse(keys, vals, n);

@@ -20,7 +20,8 @@ enum {
   kLogL1NumSample = 0, kLogL1NumNode = 1, kLogL1SampleTime = 2, kLogL1SendTime = 3, kLogL1RecvTime = 4,
   kLogL1CopyTime = 5, kLogL1FeatureBytes = 8, kLogL1LabelBytes = 9, kLogL1IdBytes = 10, kLogL1GraphBytes = 11,
   kLogL1MissBytes = 12, kLogL2ShuffleTime = 15, kLogL2LastLayerSize = 17, kLogL2CoreSampleTime = 18,
-  kLogL2ExtractTime = 22, kLogL2CacheCopyTime = 24, kLogL3CacheGetIndexTime = 46,
+  kLogL2ExtractTime = 22, kLogL2CacheCopyTime = 24, kLogL3CacheGetIndexTime = 46, kLogL3CacheCombineMissTime = 50,
+  kLogL3CacheCombineCacheTime = 51,
 };
 enum {
   kLogEpochSampleTime = 0, kLogEpochSampleGetCacheMissIndexTime = 1, kLogEpochSampleSendTime = 2,

@@ -1,5 +1,7 @@
 #include "eng_queue.h"
 
+#include "eng_dataset.h"
+
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -14,9 +16,13 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
   SAM_CHECK(num_slots > 0 && num_slots <= kMaxSlots);
   slot_bytes = (slot_bytes + 255) & ~size_t(255);
   total_bytes_ = sizeof(QueueMeta) + slot_bytes * num_slots;
-  void *p = mmap(nullptr, total_bytes_, PROT_READ | PROT_WRITE, MAP_ANONYMOUS | MAP_SHARED, -1, 0);
-  SAM_CHECK(p != MAP_FAILED) << "cannot map " << total_bytes_ << " bytes for the memory queue";
-  meta_ = static_cast<QueueMeta *>(p);
+  // shared by every process of the job: inherited through fork, or a named region (SAMGRAPH_SHM_PREFIX, eng_dataset.cc)
+  SharedRegion reg = SharedCreate(total_bytes_);
+  meta_ = static_cast<QueueMeta *>(reg.ptr);
+  if (!reg.creator) {  // somebody else set the queue up: same geometry, or the job is misconfigured
+    SAM_CHECK(meta_->max_size == num_slots && meta_->mq_nbytes == slot_bytes);
+    return;
+  }
   meta_->send_cnt = 0;
   meta_->recv_cnt = 0;
   meta_->max_size = num_slots;
@@ -28,6 +34,7 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
   }
   memset(meta_->rings, 0, sizeof(meta_->rings));
   meta_->ipc_broken = 0;
+  SharedPublish(meta_);
 }
 
 bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {

@@ -28,6 +28,7 @@ EXPORTS = [
     "fgnn_hashtable_fill_unique", "fgnn_hashtable_fill_duplicates", "fgnn_hashtable_map", "fgnn_hashtable_n2o",
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
+    "fgnn_presample_count", "fgnn_presample_rank_scratch_bytes", "fgnn_presample_rank", "fgnn_cache_table_build",
     "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
 ]
 
@@ -291,6 +292,38 @@ def neighbourhood_expand(indptr, indices, frontier, stamp, mark, freq, nxt, d_nu
                                             C.c_int(1 if mark_frontier else 0), _stream()), "fgnn_neighbourhood_expand")
 
 
+def presample_count(freq, nodes, num_nodes=None, d_num_nodes=None):
+    """PreSampler's counting step: freq[nodes[i]] += 1 (dist/pre_sampler.cc:117-131).  Asynchronous."""
+    _need_gpu(freq, nodes)
+    cap = nodes.numel()
+    n = cap if num_nodes is None else num_nodes
+    _check(load().fgnn_presample_count(_ptr(freq), _ptr(nodes), C.c_size_t(n), _ptr(d_num_nodes), C.c_size_t(cap),
+                                       _stream()), "fgnn_presample_count")
+
+
+def presample_rank(freq):
+    """rank list (int32 device tensor, u32 storage): nodes by (frequency desc, id desc) (dist/pre_sampler.cc:140-160)."""
+    L = load()
+    _need_gpu(freq)
+    L.fgnn_presample_rank_scratch_bytes.restype = C.c_size_t
+    n = freq.numel()
+    ws = torch.empty(L.fgnn_presample_rank_scratch_bytes(C.c_size_t(n)), dtype=torch.uint8, device=freq.device)
+    rank = torch.empty(n, dtype=torch.int32, device=freq.device)
+    _check(L.fgnn_presample_rank(_ptr(freq), C.c_size_t(n), _ptr(rank), _ptr(ws), C.c_size_t(ws.numel()), _stream()),
+           "fgnn_presample_rank")
+    return rank
+
+
+def cache_table_build(rank, num_cached, num_node=None):
+    """direct-map table node -> cache slot (SampleCacheTableInit, dist_engine.cc:193-229)"""
+    _need_gpu(rank)
+    n = rank.numel() if num_node is None else num_node
+    table = torch.empty(n, dtype=torch.int32, device=rank.device)
+    _check(load().fgnn_cache_table_build(_ptr(table), C.c_size_t(n), _ptr(rank), C.c_size_t(num_cached), _stream()),
+           "fgnn_cache_table_build")
+    return table
+
+
 def cache_table_replace(table, old_nodes, new_nodes):
     """ReplaceCacheGPU's index update: old nodes -> EMPTY, new node i -> i"""
     _need_gpu(table, old_nodes, new_nodes)
@@ -347,7 +380,7 @@ EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
     "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_sampler_sample_ordered",
     "fgnn_sampler_run_batch", "fgnn_batch_enable_timing", "fgnn_batch_gather_ms", "fgnn_batch_cache_index", "fgnn_batch_extract",
-    "fgnn_batch_extract_cached", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
+    "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta",
 ]
@@ -456,6 +489,18 @@ class Sampler:
                                              _ptr(label), st), "fgnn_sampler_run_batch")
 
 
+    def run_batch_cached(self, seq, seeds, batch_key, batch, cache_table, cache_rows, full_feat, label=None,
+                         stream=None):
+        """sample + cache index + CombineMissData (rows read from `full_feat`: device or pinned host tensor) +
+        CombineCacheData + finish in one C call."""
+        _need_gpu(seeds, cache_table, cache_rows)
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        _check(load().fgnn_sampler_run_batch_cached(self.h, C.c_uint64(seq), _ptr(seeds), C.c_size_t(seeds.numel()),
+                                                    C.c_uint64(batch_key), batch.h, _ptr(cache_table),
+                                                    _ptr(cache_rows), _ptr(full_feat), _ptr(label), st),
+               "fgnn_sampler_run_batch_cached")
+
+
 class Batch:
     def __init__(self, sampler, feat_dim, feat_dtype, label_dtype, feat_rows_cap):
         L = load()
@@ -492,6 +537,21 @@ class Batch:
     def gather_ms(self):
         load().fgnn_batch_gather_ms.restype = C.c_float
         return float(load().fgnn_batch_gather_ms(self.h))
+
+    def extract_cached_ms(self):
+        """(miss-row gather ms, cached-row gather ms) of the last extract_cached, -1 where not timed"""
+        out = (C.c_float * 2)()
+        _check(load().fgnn_batch_extract_cached_ms(self.h, out), "fgnn_batch_extract_cached_ms")
+        return float(out[0]), float(out[1])
+
+    def d_num_input(self):
+        """device view (int32[1]) of the batch summary's num_input"""
+        p = load().fgnn_batch_device_meta(self.h)
+        return _wrap_device_u32(p + BatchMeta.num_input.offset, 1, self.sampler.device)
+
+    def input_nodes_buffer(self):
+        """the whole input_nodes buffer (capacity max_nodes); valid entries = num_input"""
+        return _wrap_device_u32(load().fgnn_batch_input_nodes(self.h), self.sampler.max_nodes, self.sampler.device)
 
     def wait(self):
         m = BatchMeta()

@@ -33,6 +33,20 @@ void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_la
  * intact.  Returns 0 on success. */
 int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t messages, int producers, int consumers);
 
+/* The same ring between processes that were NOT forked from a common parent (one process per GPU started by torchrun):
+ * with SAMGRAPH_SHM_PREFIX set, every process calling this attaches to the same named ring (eng_dataset.cc:
+ * SharedCreate).  role 0 = producer `index` of `peers` (sends its share of `messages`), role 1 = consumer `index` of
+ * `peers` (receives its share, verifies the checksums).  Returns 0 on success. */
+int fgnn_host_queue_named_role(size_t slots, size_t slot_bytes, size_t messages, int role, int index, int peers);
+
+/* The ring as single calls, for control-plane rehearsals of a multi-process job without a GPU (bench.py --rehearse):
+ * open attaches to / creates the job's ring (SAMGRAPH_SHM_PREFIX), send publishes one message {key, value}, recv
+ * blocks for the next message. */
+void *fgnn_host_queue_open(size_t slots, size_t slot_bytes);
+void fgnn_host_queue_send(void *q, uint64_t key, uint64_t value);
+void fgnn_host_queue_recv(void *q, uint64_t *key, uint64_t *value);
+void fgnn_host_queue_close(void *q);
+
 /* Parses a config through the same code as samgraph_config and returns 0; on an invalid config the
  * process aborts like the reference.  Writes steps-per-epoch style derived values for inspection:
  * out[0] = #layers, out[1] = fanout[0], out[2] = run_arch, out[3] = UseGPUCache. */

@@ -225,6 +225,18 @@ int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_inde
 int fgnn_block_aggregate(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
                          size_t num_edge, const float *h, size_t dim, float *out, void *stream);
 
+/* ---- pre-sampling cache policy (init-time) --------------------------------------------------
+ * PreSampler (dist/pre_sampler.cc:75-162): freq[node] += 1 for every input node of every presample batch, then
+ * rank = nodes by (frequency desc, id desc).  fgnn_cache_table_build = SampleCacheTableInit (dist_engine.cc:193-229):
+ * table[rank[i]] = i for i < num_cached, FGNN_EMPTY_KEY elsewhere. */
+int fgnn_presample_count(uint32_t *d_freq, const uint32_t *d_nodes, size_t num_nodes, const uint32_t *d_num_nodes,
+                         size_t num_nodes_cap, void *stream);
+size_t fgnn_presample_rank_scratch_bytes(size_t num_node);
+int fgnn_presample_rank(const uint32_t *d_freq, size_t num_node, uint32_t *d_rank, void *ws, size_t ws_bytes,
+                        void *stream);
+int fgnn_cache_table_build(uint32_t *d_table, size_t num_node, const uint32_t *d_rank, size_t num_cached,
+                           void *stream);
+
 /* ---- batch driver -------------------------------------------------------------------------
  * One object per sampler GPU that enqueues a whole mini-batch without a single host round trip:
  * DoGPUSample (cuda_loops.cc:50-267 == dist/dist_loops.cc:51-269), DoGetCacheMissIndex
@@ -308,6 +320,13 @@ int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void 
  * full_feat is device-accessible (HBM, or pinned / registered host memory read over the host link). */
 int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void *full_feat, const void *label,
                               void *stream);
+/* fgnn_sampler_run_batch with the cached extraction: sample_ordered + cache_index + extract_cached + finish */
+int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                  uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
+                                  const void *cache_rows, const void *full_feat, const void *label, void *stream);
+/* with fgnn_batch_enable_timing: out[0] = ms of the miss-row gather, out[1] = ms of the cached-row gather of the last
+ * fgnn_batch_extract_cached (valid after fgnn_batch_wait; -1 when not bracketed) */
+int fgnn_batch_extract_cached_ms(fgnn_batch *b, float out[2]);
 /* Optional HIP-event bracket around the feature gather launched by fgnn_batch_extract (on its stream);
  * fgnn_batch_gather_ms returns the elapsed time of the last bracketed launch after fgnn_batch_wait, or -1. */
 int fgnn_batch_enable_timing(fgnn_batch *b, int on);

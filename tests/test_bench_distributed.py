@@ -1,46 +1,98 @@
-"""The N>1 path of bench.py on CPU: one process per rank over gloo (world_size 2), disjoint step ranges, MAX-time /
-SUM-work reduction.  There is no data-path collective to test beyond this: the path shards by mini-batch."""
+"""The N>1 path of bench.py on CPU (world_size 2 and 4 over gloo), through bench.main's own code path:
+`--rehearse` runs the launcher, the rendezvous, the sampler / trainer roles, the DistShuffler step ranges, the REAL
+shared hand-off ring of c_lib.so between the rank processes (named shared-memory regions) and the MAX-time / SUM-work
+reductions with empty batches -- everything of the multi-process job except the GPU work.  There is no data-path
+collective to test beyond this: the path shards by mini-batch."""
+import json
 import os
+import socket
+import subprocess
 import sys
 
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def _worker(rank, world, port, out):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _expected_edges(world, samplers, warmup, steps):
+    """edges the samplers report for the timed region: sampler i walks its own step range (dist_shuffler.cc:59-79)
+    from its first step, the warm-up share first"""
     import bench
-    first, count = bench.local_step_range(151, rank, world)
-    elapsed, edges, rows = bench.reduce_over_ranks(1.0 + rank, 1000.0 * (rank + 1), 10.0 * (rank + 1))
-    out.put((rank, first, count, elapsed, edges, rows))
-    dist.destroy_process_group()
+    total = 0
+    for i in range(samplers):
+        first, local = bench.local_step_range(151, i, samplers)
+        skip = bench.split_count(warmup, samplers, i)
+        for j in range(skip, skip + bench.split_count(steps, samplers, i)):
+            key = (j // local) * 151 + first + j % local
+            total += bench.RehearsalBackend.edges_of(key)
+    return total
 
 
-def test_two_ranks_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (r0, f0, c0, t0, e0, w0), (r1, f1, c1, t1, e1, w1) = res
-    assert (f0, c0, f1, c1) == (0, 75, 75, 76)          # papers100M: 151 steps -> 75 + 76 (dist_shuffler.cc:59-79)
-    assert t0 == t1 == 2.0 and e0 == e1 == 3000.0 and w0 == w1 == 30.0
+def _run(cmd, env=None):
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout.decode()
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus,samplers", [(2, 0), (4, 2), (3, 0)])
+def test_plain_launch_spawns_ranks(gpus, samplers):
+    """`python bench.py --gpus N` (how the driver ran it in round 1): bench.py starts the N rank processes itself"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "bench.py", "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--rehearse"]
+    if samplers:
+        cmd += ["--samplers", str(samplers)]
+    out = _run(cmd, env)
+    S = samplers or 1
+    assert out["n_gpus"] == gpus and out["steps"] == 20 and out["warmup"] == 5
+    assert out["pipeline"]["samplers"] == S and out["pipeline"]["trainers"] == gpus - S
+    assert out["config"]["parallelism"].startswith("%dS+%dT" % (S, gpus - S))
+    assert round(out["edges_per_step"] * 20) == _expected_edges(gpus, S, 5, 20)
+    assert out["input_nodes_per_step"] == 1.0  # every one of the 20 batches reached exactly one trainer
+    assert out["scaling"] == "strong" and out["ms_per_step"] > 0
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fgnn_bench_")]  # rank 0 removed the job's names
+
+
+def test_torchrun_launch():
+    """the launch line of the task description: one rank per GPU started by torch.distributed.run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "12",
+                "--warmup", "3", "--rehearse"], env)
+    assert out["n_gpus"] == 2 and out["steps"] == 12
+    assert round(out["edges_per_step"] * 12) == _expected_edges(2, 1, 3, 12)
+
+
+def test_gpus_flag_must_match_the_launcher():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--rehearse"], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert res.returncode != 0 and b"--gpus 3" in res.stderr
+
+
+def test_roles_and_shares():
+    import bench
+    assert [bench.default_samplers(n) for n in (2, 3, 4, 8)] == [1, 1, 1, 2]  # 1S+1T at 2, 2S+6T at 8 (table4/run.py)
+    assert bench.pipeline_roles(8) == (2, 6) and bench.pipeline_roles(4, 2) == (2, 2)
+    with pytest.raises(ValueError):
+        bench.pipeline_roles(2, 2)
+    for total in (0, 1, 20, 151):
+        for parts in (1, 2, 3, 6):
+            assert sum(bench.split_count(total, parts, i) for i in range(parts)) == total
 
 
 def test_step_ranges_cover_epoch():
-    sys.path.insert(0, ROOT)
     import bench
+    assert bench.local_step_range(151, 0, 2) == (0, 75) and bench.local_step_range(151, 1, 2) == (75, 76)
     for steps in (1, 7, 151, 152):
         for world in (1, 2, 3, 4, 8):
             seen = []
@@ -48,9 +100,3 @@ def test_step_ranges_cover_epoch():
                 f, c = bench.local_step_range(steps, r, world)
                 seen += list(range(f, f + c))
             assert seen == list(range(steps))
-
-
-def test_single_process_passthrough():
-    sys.path.insert(0, ROOT)
-    import bench
-    assert bench.reduce_over_ranks(1.5, 10, 2) == (1.5, 10, 2)

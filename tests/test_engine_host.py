@@ -137,3 +137,34 @@ def test_queue_multiprocess(eng, producers, consumers, slots):
     """world_size > 1 on CPU: forked writers and readers over the shared ring; every message exactly once."""
     rc = eng.fgnn_host_queue_selftest(C.c_size_t(slots), C.c_size_t(4096), C.c_size_t(500), producers, consumers)
     assert rc == 0
+
+
+_NAMED_ROLE = r"""
+import ctypes as C, sys
+eng = C.CDLL(sys.argv[1])
+role, index, peers, slots, messages = map(int, sys.argv[2:7])
+sys.exit(eng.fgnn_host_queue_named_role(C.c_size_t(slots), C.c_size_t(4096), C.c_size_t(messages), role, index, peers))
+"""
+
+
+@pytest.mark.parametrize("producers,consumers,slots", [(1, 1, 2), (2, 3, 5)])
+def test_queue_named_regions_between_unrelated_processes(eng, producers, consumers, slots):
+    """The torchrun launch style: processes that share no forking parent meet in named shared-memory regions
+    (SAMGRAPH_SHM_PREFIX); whoever comes first creates and initialises the ring, the others wait for it."""
+    prefix = "fgnn_test_%d_%d%d" % (os.getpid(), producers, consumers)
+    env = dict(os.environ, SAMGRAPH_SHM_PREFIX=prefix, SAMGRAPH_SHM_KEEP="1")  # the test removes the names
+    procs = []
+    for role, peers in ((1, consumers), (0, producers)):  # consumers first: they must wait for a creator either way
+        for i in range(peers):
+            procs.append(subprocess.Popen([sys.executable, "-c", _NAMED_ROLE, ENG, str(role), str(i), str(peers),
+                                           str(slots), "300"], env=env))
+    try:
+        assert [p.wait(timeout=120) for p in procs] == [0] * len(procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(prefix):
+                os.unlink(os.path.join("/dev/shm", f))
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(prefix)]
