@@ -280,7 +280,10 @@ void Engine::InitInProcess() {
   SAM_HIP(hipSetDevice(RC().trainer_ctx.device_id));
   tdevice_ = RC().trainer_ctx.device_id;
   SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
-  for (auto &e : te_) SAM_HIP(hipEventCreate(&e));
+  for (auto &x : xctx_) {
+    SAM_HIP(hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
+    for (auto &e : x.ev) SAM_HIP(hipEventCreate(&e));
+  }
   SAM_HIP(hipHostRegister(ds_.feat.ptr, ds_.feat.bytes, hipHostRegisterPortable | hipHostRegisterMapped));
   dev_host_feat_ = DeviceVisible(ds_.feat.ptr);
   SAM_HIP(hipMalloc(&d_label_, ds_.label.bytes));
@@ -627,7 +630,10 @@ void Engine::TrainInit(int worker_id, Context ctx, DistType type) {
   SAM_HIP(hipSetDevice(ctx.device_id));
   tdevice_ = ctx.device_id;
   SAM_HIP(hipStreamCreateWithFlags(&tstream_, hipStreamNonBlocking));
-  for (auto &e : te_) SAM_HIP(hipEventCreate(&e));
+  for (auto &x : xctx_) {
+    SAM_HIP(hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
+    for (auto &e : x.ev) SAM_HIP(hipEventCreate(&e));
+  }
   if (!second_half) mq_->PinMemory();
   // the host feature table becomes GPU-readable: miss rows are fetched by the gather kernel itself
   // (replaces the OpenMP ExtractMissData + H2D copy, cuda_cache_manager_host.cc:38-56)
@@ -662,9 +668,21 @@ void Engine::BuildTrainerCache() {
   if (dist_type_ == DistType::Switch) BuildCacheTable();  // the switcher splits hits/misses itself
 }
 
+// One batch of the trainer-side loop in two halves, so that StartExtract's thread can keep several batches in flight
+// (each on its own stream): TrainerIssue receives a message and enqueues its copies and gathers, TrainerComplete waits
+// for them, hands the queue slot back and submits the batch.  The reference does both in one step with a sync in
+// between every copy (dist_loops.cc:713-929); with one batch at a time the host link idles while the next message is
+// parsed and its ~10 copies are enqueued, and the GPU idles while the host waits.
 void Engine::TrainerOnce() {
   SAM_HIP(hipSetDevice(tdevice_));
   while (pool_->Full()) std::this_thread::sleep_for(std::chrono::microseconds(1));
+  TrainerIssue(xctx_[0]);
+  TrainerComplete(xctx_[0]);
+}
+
+void Engine::TrainerIssue(ExtractCtx &x) {
+  hipStream_t tstream_ = x.st;  // everything of this batch goes to the context's stream
+  hipEvent_t *te_ = x.ev;
   Timer t_recv;
   size_t mq_key = 0;
   const char *msg = static_cast<const char *>(mq_->Recv(&mq_key));
@@ -684,6 +702,8 @@ void Engine::TrainerOnce() {
   const uint32_t *p = reinterpret_cast<const uint32_t *>(msg + sizeof(TransData));
   const ptrdiff_t to_payload = payload - msg;
   auto b = std::make_shared<GraphBatch>();
+  x.b = b;
+  x.mq_key = mq_key;
   b->key = hdr.key;
   b->num_layer = hdr.num_layer;
   b->num_input = hdr.input_size;
@@ -783,6 +803,26 @@ void Engine::TrainerOnce() {
   b->label = d_lab;
   SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
                             tstream_));
+  x.recv_time = recv_time;
+  x.t_copy = t_copy;
+  x.timed_gathers = timed_gathers;
+  x.miss_rows = miss_rows;
+  x.graph_bytes = graph_bytes;
+  x.input_size = hdr.input_size;
+  x.output_size = hdr.output_size;
+}
+
+void Engine::TrainerComplete(ExtractCtx &x) {
+  hipStream_t tstream_ = x.st;
+  hipEvent_t *te_ = x.ev;
+  std::shared_ptr<GraphBatch> b = std::move(x.b);
+  const size_t mq_key = x.mq_key, miss_rows = x.miss_rows, graph_bytes = x.graph_bytes;
+  const double recv_time = x.recv_time;
+  const Timer &t_copy = x.t_copy;
+  const bool timed_gathers = x.timed_gathers;
+  const size_t row_bytes = ds_.feat_dim * 4;
+  struct { size_t input_size, output_size; } hdr{x.input_size, x.output_size};
+  while (pool_->Full() && !shutdown_) std::this_thread::sleep_for(std::chrono::microseconds(1));
   SAM_HIP(hipStreamSynchronize(tstream_));
   mq_->Release(mq_key);
   pool_->Submit(b);
@@ -828,7 +868,20 @@ void Engine::StartExtract(int count) {
   if (extract_thread_.joinable()) extract_thread_.join();
   extract_thread_ = std::thread([this, count]() {
     SAM_HIP(hipSetDevice(tdevice_));
-    for (int i = 0; i < count && !shutdown_; ++i) TrainerOnce();
+    // up to kExtractDepth batches in flight; a batch is completed as soon as no further message is waiting, so a
+    // received batch is never held back behind a blocking receive
+    int issued = 0, head = 0, inflight = 0;
+    while ((issued < count || inflight) && !shutdown_) {
+      if (inflight && (issued >= count || inflight == kExtractDepth || mq_->Pending() == 0)) {
+        TrainerComplete(xctx_[head]);
+        head = (head + 1) % kExtractDepth;
+        --inflight;
+        continue;
+      }
+      TrainerIssue(xctx_[(head + inflight) % kExtractDepth]);
+      ++inflight;
+      ++issued;
+    }
   });
 }
 
@@ -906,8 +959,13 @@ void Engine::Shutdown() {
   for (auto &sl : slots_)
     if (sl.st) (void)hipStreamSynchronize(sl.st);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
-  for (auto &e : te_)
-    if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto &x : xctx_) {
+    if (x.st) (void)hipStreamSynchronize(x.st);
+    for (auto &e : x.ev)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (x.st) { (void)hipStreamDestroy(x.st); x.st = nullptr; }
+    x.b.reset();
+  }
   if (mq_ && ring_id_ >= 0) {
     // messages published into this sampler's HBM ring must stay readable until their receivers have copied them
     // (the in-process engines read their own ring and their threads have been joined: nothing to wait for)

@@ -135,6 +135,9 @@ class Engine {
   void SampleOnceDynamic();
   // arch5 trainer
   void TrainerOnce();
+  struct ExtractCtx;
+  void TrainerIssue(ExtractCtx &x);
+  void TrainerComplete(ExtractCtx &x);
   void BuildTrainerCache();
 
   Dataset ds_;
@@ -145,7 +148,18 @@ class Engine {
   hipStream_t stream_ = nullptr;
   int tdevice_ = -1;            // trainer-side device (arch5 trainer process, arch2-4 extractor)
   hipStream_t tstream_ = nullptr;
-  hipEvent_t te_[3] = {nullptr, nullptr, nullptr};  // trainer: brackets of the miss-row and cached-row gathers
+  // trainer: a batch being received / extracted (eng_engine.cc: TrainerIssue / TrainerComplete)
+  static constexpr int kExtractDepth = 3;
+  struct ExtractCtx {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // brackets of the miss-row and cached-row gathers
+    std::shared_ptr<GraphBatch> b;
+    size_t mq_key = 0, miss_rows = 0, graph_bytes = 0, input_size = 0, output_size = 0;
+    double recv_time = 0;
+    Timer t_copy;
+    bool timed_gathers = false;
+  };
+  ExtractCtx xctx_[kExtractDepth];
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;

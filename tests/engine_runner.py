@@ -23,6 +23,10 @@ NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, 2000
 BATCH, NUM_EPOCH = 256, 2
 # FGNN_TEST_CACHE_POLICY=static: the kCacheByPreSampleStatic policy (whole neighbourhoods instead of sampled ones)
 STATIC_PRESAMPLE = os.environ.get("FGNN_TEST_CACHE_POLICY", "") == "static"
+# where the arch5 workers run: both on cuda:0 by default; FGNN_TEST_TRAINER_DEVICE=cuda:1 puts the trainers on a second
+# GPU (the hand-off then crosses xGMI: the sampler's HBM ring is mapped by hipIpcOpenMemHandle and read peer to peer)
+SAMPLER_DEV = os.environ.get("FGNN_TEST_SAMPLER_DEVICE", "cuda:0")
+TRAINER_DEV = os.environ.get("FGNN_TEST_TRAINER_DEVICE", "cuda:0")
 
 
 def dataset(workdir, sample_type):
@@ -294,7 +298,7 @@ def _sampler_proc(worker, num_sampler, barrier, err):
     try:
         faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
-        sam.sample_init(worker, "cuda:0")
+        sam.sample_init(worker, SAMPLER_DEV)
         barrier.wait()
         num_step = sam.steps_per_epoch()
         local = num_step - (num_step // num_sampler) * worker if worker == num_sampler - 1 else num_step // num_sampler
@@ -314,7 +318,7 @@ def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample
         faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
         barrier.wait()  # samplers (and the presample) are done initialising
-        sam.train_init(worker, "cuda:0")
+        sam.train_init(worker, TRAINER_DEV)
         # expected batches of every sampler, by key
         expected = {}
         rank = None
@@ -367,6 +371,47 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     if bad or err.value:
         sys.exit(1)
     print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
+
+
+class _FileBarrier:
+    """barrier between processes that share nothing but a directory (the torchrun launch style)"""
+
+    def __init__(self, workdir, me, n):
+        self.dir, self.me, self.n, self.round = workdir, me, n, 0
+
+    def wait(self, limit=300.0):
+        import time
+        tag = "barrier%d." % self.round
+        self.round += 1
+        open(os.path.join(self.dir, tag + self.me), "w").close()
+        t0 = time.time()
+        while len([f for f in os.listdir(self.dir) if f.startswith(tag)]) < self.n:
+            if time.time() - t0 > limit:
+                raise RuntimeError("barrier %s: only %s arrived" % (tag, os.listdir(self.dir)))
+            time.sleep(0.01)
+
+
+class _Err:
+    value = 0
+
+
+def run_arch5_named_role(sample_type, workdir, role, idx, num_sampler, num_trainer, cache_pct):
+    """One worker of an arch5 job whose processes have NO common forking parent (one process per GPU started by a
+    launcher such as torchrun): every process runs config + data_init itself and meets the others in the named shared
+    regions of SAMGRAPH_SHM_PREFIX (set by the test, which also wrote the dataset)."""
+    import samgraph.torch as sam
+    path = os.path.join(workdir, "synth")
+    cfg = base_config(path, sam.kArch5, sample_type)
+    cfg.update(num_sample_worker=num_sampler, num_train_worker=num_trainer, cache_percentage=cache_pct)
+    sam.config(cfg)
+    sam.data_init()
+    barrier = _FileBarrier(workdir, "%s%d" % (role, idx), num_sampler + num_trainer)
+    barrier.wait()  # every process has attached to every region
+    if role == "s":
+        _sampler_proc(idx, num_sampler, barrier, _Err())
+    else:
+        _trainer_proc(idx, num_trainer, num_sampler, path, sample_type, cache_pct > 0, True, barrier, _Err())
+    print("arch5-named %s%d ok" % (role, idx))
 
 
 def _sgnn_worker(arch, worker, num_worker, path, sample_type, cache_pct, background, barrier, err):
@@ -507,7 +552,12 @@ def run_arch5_switcher(sample_type, workdir):
 
 if __name__ == "__main__":
     mode, st, wd = sys.argv[1:4]
-    if mode == "arch1":
+    if mode == "dataset":
+        dataset(wd, st)
+    elif mode == "arch5_named":
+        run_arch5_named_role(st, wd, sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]),
+                             float(sys.argv[8]))
+    elif mode == "arch1":
         run_arch1(st, wd)
     elif mode == "switcher":
         run_arch5_switcher(st, wd)

@@ -83,6 +83,82 @@ def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)
 
 
+def _two_gpu_env():
+    import torch
+    if torch.cuda.device_count() < 2:  # counting devices does not initialise the GPU in this process
+        pytest.skip("needs two GPUs: sampler on cuda:0, trainers on cuda:1")
+    return {"FGNN_TEST_SAMPLER_DEVICE": "cuda:0", "FGNN_TEST_TRAINER_DEVICE": "cuda:1", "SAMGRAPH_LOG_LEVEL": "info"}
+
+
+@pytest.mark.parametrize("sample_type,ns,nt,cache,slots", [
+    ("khop2", 1, 1, 0.25, None),             # BASELINE config 3's topology: sampler GPU -> trainer GPU
+    ("random_walk", 2, 2, 0.2, 2),           # few ring slots: part of the messages travel through the host ring
+    ("khop2", 1, 2, 0.0, None),              # no cache: input nodes shipped
+    ("khop2", 2, 1, 0.25, -1),               # the receiver pretends it cannot map the ring: copied back on request
+])
+def test_arch5_across_two_devices(tmp_path, sample_type, ns, nt, cache, slots):
+    """The hand-off across devices (task_queue.cc:154-347 replaced by the HBM message ring): samplers on cuda:0,
+    trainers on cuda:1 -- the ring is mapped with hipIpcOpenMemHandle and read peer to peer over xGMI.  Same batches,
+    bit for bit; the forced-spill fallback is exercised across devices as well.  Skipped on a one-GPU box."""
+    import re
+    env = _two_gpu_env()
+    if slots is not None and slots >= 0:
+        env["SAMGRAPH_DEVICE_RING_SLOTS"] = str(slots)
+    if slots == -1:
+        env["SAMGRAPH_DEVICE_RING_FORCE_SPILL"] = "1"
+    out = _run(tmp_path, "arch5", sample_type, ns, nt, cache, "pipeline", env=env)
+    assert "ok" in out
+    used = [tuple(int(x) for x in m) for m in
+            re.findall(r"device ring \d+: (\d+) messages through HBM, (\d+) through the host ring, (\d+) copied", out)]
+    assert used and all(a > 0 for a, _, _ in used), out[-2000:]
+    if slots == -1:
+        assert sum(c for _, _, c in used) > 0
+
+
+@pytest.mark.parametrize("sample_type,ns,nt,cache", [("khop2", 1, 1, 0.25), ("khop2", 2, 2, 0.2),
+                                                     ("random_walk", 1, 2, 0.0)])
+def test_arch5_unrelated_processes_named_regions(tmp_path, sample_type, ns, nt, cache):
+    """The MI355X launch style -- one process per GPU started by a launcher, no forking parent: every worker runs
+    config + data_init itself and the queue, the sampler barrier, the rank list and the feature table live in named
+    shared-memory regions (SAMGRAPH_SHM_PREFIX).  Same batches, bit for bit."""
+    subprocess.run([sys.executable, RUNNER, "dataset", sample_type, str(tmp_path)], check=True, timeout=600)
+    prefix = "fgnn_gputest_%d" % os.getpid()
+    env = dict(os.environ, SAMGRAPH_SHM_PREFIX=prefix, SAMGRAPH_SHM_KEEP="1")
+    procs = []
+    try:
+        for role, n in (("t", nt), ("s", ns)):
+            for i in range(n):
+                procs.append(subprocess.Popen([sys.executable, RUNNER, "arch5_named", sample_type, str(tmp_path), role,
+                                               str(i), str(ns), str(nt), str(cache)], env=env, stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=900)[0] for p in procs]
+        assert [p.returncode for p in procs] == [0] * len(procs), "\n".join(o[-3000:] for o in outs)
+        assert all("arch5-named" in o and "ok" in o for o in outs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(prefix):
+                os.unlink(os.path.join("/dev/shm", f))
+
+
+def test_bench_pipeline_two_processes(tmp_path):
+    """bench.py --gpus 2 = 1S+1T as two processes through bench.main's launcher, the engine and the device ring (both
+    ranks share cuda:0 on a one-GPU box)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small", "--steps",
+                        "12", "--warmup", "3", "--train-steps", "4", "--empty-feat-bits", "16"], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["pipeline"]["samplers"] == 1
+    assert out["value"] > 0 and out["edges_per_step"] > 1000 and 0 < out["pipeline"]["hit_rate"] <= 1
+    assert out["epoch_time_s"]["with_training"] > 0
+
+
 @pytest.mark.parametrize("arch,sample_type,workers,cache,mode", [
     ("arch6", "khop2", 2, 0.25, "inline"),       # 2 workers, each samples + extracts its own aligned share
     ("arch6", "khop2", 3, 0.0, "background"),    # train set padded to a multiple of 3; samgraph_extract_start thread

@@ -905,3 +905,72 @@ def test_batch_driver_empty_and_isolated_batches(hip, oracle, kind):
         if b == 1:
             assert want["total_edges"] == 0 and len(want["input_nodes"]) == 20
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
+def test_presample_rank_and_cache_table_match_oracle(hip, oracle):
+    """fgnn_presample_count / fgnn_presample_rank / fgnn_cache_table_build (dist/pre_sampler.cc:75-162,
+    dist_engine.cc:193-229) against the oracle: frequencies counted with device-side sizes, rank = (frequency desc,
+    id desc), table[rank[i]] = i for the cached head."""
+    num_node = 50000
+    rs = np.random.default_rng(5)
+    freq = torch.zeros(num_node, dtype=torch.int32, device="cuda")
+    want = np.zeros(num_node, dtype=np.uint32)
+    for k in range(6):
+        cap = 9000
+        n = int(rs.integers(0, cap + 1)) if k else cap
+        nodes = (rs.zipf(1.3, size=cap) % num_node).astype(np.uint32)
+        d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+        if k % 2:
+            hip.presample_count(freq, dev(nodes), d_num_nodes=d_n)   # device-side count, capacity = len(nodes)
+        else:
+            hip.presample_count(freq, dev(nodes), num_nodes=n)
+        np.add.at(want, nodes[:n], 1)
+    np.testing.assert_array_equal(host_u32(freq), want)
+    rank = hip.presample_rank(freq)
+    o_rank = oracle.presample_rank(want)
+    np.testing.assert_array_equal(host_u32(rank), o_rank)
+    for n_cached in (0, 1, num_node // 5, num_node):
+        table = hip.cache_table_build(rank, n_cached)
+        np.testing.assert_array_equal(host_u32(table), oracle.cache_table_build(o_rank, n_cached, num_node))
+
+
+@pytest.mark.gpu
+def test_run_batch_cached_matches_oracle(hip, oracle):
+    """fgnn_sampler_run_batch_cached: sample + cache split + CombineMissData (rows fetched from PINNED HOST memory by
+    the gather kernel) + CombineCacheData in one call, with a masked 2^k-row feature table (SAMGRAPH_EMPTY_FEAT)."""
+    from fgnn_hip import synth
+    num_node, dim, batch, fanouts, bits = 30000, 128, 1500, [10, 5], 13
+    mask = (1 << bits) - 1
+    indptr, indices = synth.powerlaw_csr(num_node, 500000, seed=77)
+    feat = synth.node_features(1 << bits, dim)
+    label = np.random.default_rng(3).integers(0, 40, size=num_node).astype(np.int64)
+    rank = np.random.default_rng(4).permutation(num_node).astype(np.uint32)
+    n_cached = num_node // 4
+    table = oracle.cache_table_build(rank, n_cached, num_node)
+    cache_rows = feat[rank[:n_cached] & mask]
+    d_indices = dev(indices.copy())
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=hip.KHOP2, seed=SEED)
+    bt = sampler.new_batch(dim, hip.F32, hip.I64)
+    bt.enable_timing(True)
+    hip.load().fgnn_batch_set_feat_row_mask(bt.h, mask)
+    host_feat = torch.from_numpy(feat).pin_memory()
+    d_table, d_cache, d_label = dev(table), dev(cache_rows), dev(label)
+    o_indices = indices.copy()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for b in range(3):
+        seeds = _seeds(batch if b < 2 else 17, num_node, seed=300 + b)
+        sampler.run_batch_cached(b, dev(seeds), 50 + b, bt, d_table, d_cache, host_feat, d_label)
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, oracle.KHOP2, rng, 50 + b, oht)
+        nodes = host_u32(bt.input_nodes())
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        for got, w in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(table, nodes)):
+            np.testing.assert_array_equal(host_u32(got), w)
+        assert m.num_miss + m.num_cache == m.num_input and m.num_miss > 0 and m.num_cache > 0
+        assert bt.feat().cpu().numpy().tobytes() == feat[nodes & mask].tobytes()
+        np.testing.assert_array_equal(bt.label().cpu().numpy(), label[seeds])
+        ms = bt.extract_cached_ms()
+        assert ms[0] >= 0 and ms[1] >= 0
+        np.testing.assert_array_equal(host_u32(bt.d_num_input()), [m.num_input])
