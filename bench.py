@@ -861,6 +861,9 @@ class RehearsalBackend:
 def run_pipeline_rank(args, rank, world):
     import datetime
     import shutil
+    if os.environ.get("FGNN_BENCH_WATCHDOG"):  # a stuck rank shows where it is stuck, then exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FGNN_BENCH_WATCHDOG"]), exit=True)
     import torch.distributed as dist
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
     S, T = pipeline_roles(world, args.samplers)
@@ -954,7 +957,14 @@ def run_pipeline_rank(args, rank, world):
                     j = sampled[0]
                     sampled[0] += 1
                     keys.append((j // local_steps, first_step + j % local_steps))
+                if args.decoupled:
+                    busy = time.perf_counter() - t0
+                    time.sleep(0.02)  # the publisher thread publishes the last batches as their GPU work completes
+                    dist.barrier()
             else:
+                if args.decoupled:
+                    dist.barrier()  # diagnostic: the samplers have filled the queue, the trainers run alone
+                    t0 = time.perf_counter()
                 if mine:
                     be.extract_start(mine)
                 for _ in range(mine):
@@ -967,7 +977,8 @@ def run_pipeline_rank(args, rank, world):
                         opt.step()
                         torch.cuda.current_stream().synchronize()
                     keys.append((key // steps_per_epoch, key % steps_per_epoch))
-            busy = time.perf_counter() - t0
+            if not (args.decoupled and is_sampler):
+                busy = time.perf_counter() - t0
             dist.barrier()  # every batch of the region has been consumed
             return time.perf_counter() - t0, busy
 
@@ -1132,6 +1143,11 @@ def parse_args(argv=None):
     ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
     ap.add_argument("--no-train-leg", action="store_true", help="N>=2: skip the region with a training step per batch")
     ap.add_argument("--train-steps", type=int, default=40, help="N>=2: batches of the training region (<= --steps)")
+    ap.add_argument("--decoupled", action="store_true",
+                    help="N>=2 diagnostic (one-GPU development box, where sampler and trainer ranks share the GPU): the "
+                         "samplers fill the queue first, then the trainers drain it -- sampler_busy_s and trainer_busy_s "
+                         "are then each stage's time ALONE; needs steps <= queue slots (set "
+                         "SAMGRAPH_DEVICE_RING_SLOTS >= steps to keep the payloads in HBM)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>=2 without a GPU: launcher, rendezvous, roles, step ranges, the real shared ring and the "
                          "reductions with empty batches (tests); measures nothing")

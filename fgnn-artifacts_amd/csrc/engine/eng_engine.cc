@@ -710,11 +710,39 @@ void Engine::TrainerIssue(ExtractCtx &x) {
   b->num_output = hdr.output_size;
   b->device = tdevice_;
 
+  // Arrays that outlive the queue slot (ids, COO) go into ONE pooled buffer, copied by ONE kernel; the cache index
+  // arrays are used in place by the gathers below (the slot is released only after they have run).  `in_place`
+  // translates a position in the host slot into the device-visible address of the same position in the payload slot.
+  auto in_place = [&](const uint32_t *src) -> const uint32_t * {
+    const char *q = reinterpret_cast<const char *>(src) + to_payload;
+    return reinterpret_cast<const uint32_t *>(payload_on_device ? q : static_cast<const char *>(mq_->DeviceVisiblePtr(q)));
+  };
+  constexpr size_t kAlignWords = 64;  // 256-byte aligned sub-arrays
+  auto padded = [&](size_t n) { return (n + kAlignWords - 1) / kAlignWords * kAlignWords; };
+  size_t keep_words = padded(hdr.output_size) + (ship_input ? padded(hdr.input_size) : 0);
+  {
+    const uint32_t *q = p + (ship_input ? hdr.input_size : 0) + hdr.output_size;
+    if (use_cache) q += 2 * hdr.input_size;  // miss + cache index pairs
+    for (int l = 0; l < hdr.num_layer; ++l) {
+      uint64_t g[3];
+      memcpy(g, q, sizeof(g));
+      keep_words += (hdr.have_data ? 3 : 2) * padded(g[2]);
+      q += sizeof(GraphData) / sizeof(uint32_t) + g[2] * (hdr.have_data ? 3 : 2);
+    }
+  }
+  uint32_t *keep = static_cast<uint32_t *>(dev_pool_.Alloc(keep_words * sizeof(uint32_t)));
+  b->pooled.push_back(keep);
+  UnpackArgs ua;
+  ua.num_segments = 0;
   auto to_device = [&](const uint32_t *src, size_t n) -> uint32_t * {
-    uint32_t *d = static_cast<uint32_t *>(dev_pool_.Alloc(n * sizeof(uint32_t)));
-    b->pooled.push_back(d);
-    const void *from = reinterpret_cast<const char *>(src) + to_payload;
-    if (n) SAM_HIP(hipMemcpyAsync(d, from, n * sizeof(uint32_t), hipMemcpyDefault, tstream_));
+    uint32_t *d = keep;
+    keep += padded(n);
+    if (n) {
+      auto &sg = ua.seg[ua.num_segments++];
+      sg.dst = d;
+      sg.src = in_place(src);
+      sg.words = n;
+    }
     return d;
   };
 
@@ -731,15 +759,15 @@ void Engine::TrainerIssue(ExtractCtx &x) {
   b->output_device = tdevice_;
 
   const size_t num_miss = hdr.num_miss, num_cache = hdr.input_size - hdr.num_miss;
-  uint32_t *d_cidx[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint32_t *d_cidx[4] = {nullptr, nullptr, nullptr, nullptr};
   if (use_cache) {
     if (num_miss) {
-      d_cidx[0] = to_device(p, num_miss); p += num_miss;
-      d_cidx[1] = to_device(p, num_miss); p += num_miss;
+      d_cidx[0] = in_place(p); p += num_miss;
+      d_cidx[1] = in_place(p); p += num_miss;
     }
     if (num_cache) {
-      d_cidx[2] = to_device(p, num_cache); p += num_cache;
-      d_cidx[3] = to_device(p, num_cache); p += num_cache;
+      d_cidx[2] = in_place(p); p += num_cache;
+      d_cidx[3] = in_place(p); p += num_cache;
     }
   }
   size_t graph_bytes = 0;
@@ -757,6 +785,7 @@ void Engine::TrainerIssue(ExtractCtx &x) {
     graph_bytes += v.num_edge * (hdr.have_data ? 12 : 8);
   }
   SAM_CHECK_LE((size_t)((const char *)p - msg), mq_->SlotBytes());
+  SAM_FGNN(LaunchUnpack(ua, tstream_));
 
   // features (DoCacheFeatureCopy / DoSwitchCacheFeatureCopy / DoCPUFeatureExtract+DoFeatureCopy)
   const size_t row_bytes = ds_.feat_dim * 4;
@@ -803,6 +832,9 @@ void Engine::TrainerIssue(ExtractCtx &x) {
   b->label = d_lab;
   SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
                             tstream_));
+  xstat_.recv += recv_time;
+  xstat_.issue += t_copy.Passed();
+  ++xstat_.n;
   x.recv_time = recv_time;
   x.t_copy = t_copy;
   x.timed_gathers = timed_gathers;
@@ -822,8 +854,12 @@ void Engine::TrainerComplete(ExtractCtx &x) {
   const bool timed_gathers = x.timed_gathers;
   const size_t row_bytes = ds_.feat_dim * 4;
   struct { size_t input_size, output_size; } hdr{x.input_size, x.output_size};
+  Timer t_wait;
   while (pool_->Full() && !shutdown_) std::this_thread::sleep_for(std::chrono::microseconds(1));
+  xstat_.pool_wait += t_wait.Passed();
+  Timer t_sync;
   SAM_HIP(hipStreamSynchronize(tstream_));
+  xstat_.sync += t_sync.Passed();
   mq_->Release(mq_key);
   pool_->Submit(b);
 
@@ -959,6 +995,12 @@ void Engine::Shutdown() {
   for (auto &sl : slots_)
     if (sl.st) (void)hipStreamSynchronize(sl.st);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
+  if (xstat_.n)
+    SAM_LOG(kInfo) << "extraction thread: " << xstat_.n << " batches; per batch: waiting for a message "
+                   << xstat_.recv / xstat_.n * 1e3 << " ms, parsing + enqueueing copies and gathers "
+                   << xstat_.issue / xstat_.n * 1e3 << " ms, waiting for room in the graph pool "
+                   << xstat_.pool_wait / xstat_.n * 1e3 << " ms, waiting for the GPU " << xstat_.sync / xstat_.n * 1e3
+                   << " ms";
   for (auto &x : xctx_) {
     if (x.st) (void)hipStreamSynchronize(x.st);
     for (auto &e : x.ev)

@@ -160,6 +160,8 @@ class Engine {
     bool timed_gathers = false;
   };
   ExtractCtx xctx_[kExtractDepth];
+  // where the extraction thread's time goes (reported at shutdown, log level info)
+  struct { double recv = 0, issue = 0, pool_wait = 0, sync = 0; size_t n = 0; } xstat_;
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;

@@ -38,30 +38,38 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
 }
 
 bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {
-  SAM_CHECK(ring >= 0 && ring < kMaxRings && !local_ring_[ring]);
+  SAM_CHECK(ring >= 0 && ring < kMaxRings && !owns_ring_[ring]);
   if (slots == 0) return false;
   if (slots > (uint32_t)kMaxRingSlots) slots = kMaxRingSlots;
   RingInfo &r = meta_->rings[ring];
-  void *p = nullptr;
-  if (hipMalloc(&p, (size_t)slots * meta_->mq_nbytes) != hipSuccess) {
-    (void)hipGetLastError();
-    SAM_LOG(kWarning) << "device ring: no HBM for " << slots << " slots; messages use the host ring";
-    return false;
+  uint32_t made = 0;
+  for (; made < slots; ++made) {
+    void *p = nullptr;
+    if (hipMalloc(&p, meta_->mq_nbytes) != hipSuccess) {
+      (void)hipGetLastError();
+      SAM_LOG(kWarning) << "device ring: HBM for " << made << " of " << slots << " slots only";
+      break;
+    }
+    if (hipIpcGetMemHandle(&r.handle[made], p) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p);
+      SAM_LOG(kWarning) << "device ring: hipIpcGetMemHandle refused; messages use the host ring";
+      for (uint32_t i = 0; i < made; ++i) {
+        (void)hipFree(local_slot_[ring][i]);
+        local_slot_[ring][i] = nullptr;
+      }
+      return false;
+    }
+    local_slot_[ring][made] = p;
   }
-  hipIpcMemHandle_t h;
-  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(p);
-    SAM_LOG(kWarning) << "device ring: hipIpcGetMemHandle refused; messages use the host ring";
-    return false;
-  }
-  local_ring_[ring] = p;
+  if (made == 0) return false;
+  slots = made;
+  owns_ring_[ring] = true;
   int dev = 0;
   SAM_HIP(hipGetDevice(&dev));
   r.device = dev;
   r.pid = (int)getpid();
   r.slots = slots;
-  r.handle = h;
   for (auto &b : r.busy) b = 0;
   for (auto &b : r.spill) b = 0;
   r.sent_device = r.sent_host = r.spilled = 0;
@@ -89,15 +97,14 @@ void MemoryQueue::ServiceSpills(int ring) {
     if (__atomic_load_n(&r.spill[i], __ATOMIC_ACQUIRE) != 1) continue;
     // the device slot holds the complete message (headers included): overwrite the host slot with it
     char *host = meta_->data + (r.slot_key[i] % meta_->max_size) * meta_->mq_nbytes;
-    const char *dev = static_cast<const char *>(local_ring_[ring]) + (size_t)i * meta_->mq_nbytes;
-    SAM_HIP(hipMemcpy(host, dev, meta_->mq_nbytes, hipMemcpyDeviceToHost));
+    SAM_HIP(hipMemcpy(host, local_slot_[ring][i], meta_->mq_nbytes, hipMemcpyDeviceToHost));
     ++r.spilled;
     __atomic_store_n(&r.spill[i], 2u, __ATOMIC_RELEASE);
   }
 }
 
 void *MemoryQueue::ClaimDeviceSlot(int ring, size_t key) {
-  if (ring < 0 || ring >= kMaxRings || !local_ring_[ring]) return nullptr;
+  if (ring < 0 || ring >= kMaxRings || !owns_ring_[ring]) return nullptr;
   RingInfo &r = meta_->rings[ring];
   for (uint32_t i = 0; i < r.slots && !*(volatile int *)&meta_->ipc_broken; ++i) {
     if (__atomic_load_n(&r.busy[i], __ATOMIC_ACQUIRE) == 0) {  // single claimer per ring: no CAS needed
@@ -105,7 +112,7 @@ void *MemoryQueue::ClaimDeviceSlot(int ring, size_t key) {
       r.slot_key[i] = key;
       meta_->payload_loc[key % meta_->max_size] = ((uint32_t)(ring + 1) << 8) | i;
       ++r.sent_device;
-      return static_cast<char *>(local_ring_[ring]) + (size_t)i * meta_->mq_nbytes;
+      return local_slot_[ring][i];
     }
   }
   meta_->payload_loc[key % meta_->max_size] = 0;
@@ -122,43 +129,40 @@ const void *MemoryQueue::Payload(size_t key, const void *host_msg, bool *on_devi
   SAM_CHECK(ring >= 0 && ring < kMaxRings);
   RingInfo &r = meta_->rings[ring];
   SAM_CHECK(r.ready && slot < r.slots);
-  void *base = nullptr;
   if (r.pid == (int)getpid()) {
-    base = local_ring_[ring];
-  } else {
-    if (!mapped_ring_[ring] && !*(volatile int *)&meta_->ipc_broken) {
-      // SAMGRAPH_DEVICE_RING_FORCE_SPILL=1 (tests): behave as if the mapping had been refused
-      const char *force = getenv("SAMGRAPH_DEVICE_RING_FORCE_SPILL");
-      hipError_t e = (force && atoi(force)) ? hipErrorInvalidValue
-                                            : hipIpcOpenMemHandle(&mapped_ring_[ring], r.handle,
-                                                                  hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) {
-        (void)hipGetLastError();
-        mapped_ring_[ring] = nullptr;
-        SAM_LOG(kWarning) << "device ring " << ring << ": cannot map the sampler's HBM ring (" << hipGetErrorString(e)
-                          << "); messages go through the host ring from now on";
-        __atomic_store_n(&meta_->ipc_broken, 1, __ATOMIC_RELEASE);
-      }
-    }
-    if (!mapped_ring_[ring]) {
-      // ask the owner to copy this message into its host slot, then read it there
-      __atomic_store_n(&r.spill[slot], 1u, __ATOMIC_RELEASE);
-      Timer t;
-      while (__atomic_load_n(&r.spill[slot], __ATOMIC_ACQUIRE) != 2) {
-        SAM_CHECK(t.Passed() < 120.0) << "device ring " << ring << ": the sampler does not answer the spill request";
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-      }
-      *on_device = false;
-      return host_msg;
-    }
-    base = mapped_ring_[ring];
+    SAM_CHECK(local_slot_[ring][slot]);
+    return local_slot_[ring][slot];
   }
-  SAM_CHECK(base);
-  return static_cast<const char *>(base) + (size_t)slot * meta_->mq_nbytes;
+  if (!mapped_slot_[ring][slot] && !*(volatile int *)&meta_->ipc_broken) {
+    // SAMGRAPH_DEVICE_RING_FORCE_SPILL=1 (tests): behave as if the mapping had been refused
+    const char *force = getenv("SAMGRAPH_DEVICE_RING_FORCE_SPILL");
+    hipError_t e = (force && atoi(force)) ? hipErrorInvalidValue
+                                          : hipIpcOpenMemHandle(&mapped_slot_[ring][slot], r.handle[slot],
+                                                                hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      mapped_slot_[ring][slot] = nullptr;
+      SAM_LOG(kWarning) << "device ring " << ring << ": cannot map the sampler's HBM ring (" << hipGetErrorString(e)
+                        << "); messages go through the host ring from now on";
+      __atomic_store_n(&meta_->ipc_broken, 1, __ATOMIC_RELEASE);
+    }
+  }
+  if (!mapped_slot_[ring][slot]) {
+    // ask the owner to copy this message into its host slot, then read it there
+    __atomic_store_n(&r.spill[slot], 1u, __ATOMIC_RELEASE);
+    Timer t;
+    while (__atomic_load_n(&r.spill[slot], __ATOMIC_ACQUIRE) != 2) {
+      SAM_CHECK(t.Passed() < 120.0) << "device ring " << ring << ": the sampler does not answer the spill request";
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    *on_device = false;
+    return host_msg;
+  }
+  return mapped_slot_[ring][slot];
 }
 
 void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {
-  if (ring < 0 || ring >= kMaxRings || !local_ring_[ring]) return;
+  if (ring < 0 || ring >= kMaxRings || !owns_ring_[ring]) return;
   RingInfo &r = meta_->rings[ring];
   Timer t;
   for (;;) {
@@ -176,12 +180,18 @@ void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {
   if (svc_.joinable()) svc_.join();
   SAM_LOG(kInfo) << "device ring " << ring << ": " << r.sent_device << " messages through HBM, " << r.sent_host
                  << " through the host ring, " << r.spilled << " copied back on request";
-  (void)hipFree(local_ring_[ring]);
-  local_ring_[ring] = nullptr;
+  for (uint32_t i = 0; i < r.slots; ++i) {
+    (void)hipFree(local_slot_[ring][i]);
+    local_slot_[ring][i] = nullptr;
+  }
+  owns_ring_[ring] = false;
 }
 
 void MemoryQueue::PinMemory() {
   SAM_HIP(hipHostRegister(meta_, total_bytes_, hipHostRegisterPortable | hipHostRegisterMapped));
+  void *d = nullptr;
+  SAM_HIP(hipHostGetDevicePointer(&d, meta_, 0));
+  dev_base_ = static_cast<const char *>(d);
 }
 
 void *MemoryQueue::GetPtr(size_t *key) {

@@ -50,7 +50,9 @@ struct RingInfo {
   int device;
   int pid;                   // owner process: the same process uses the pointer directly (IPC cannot self-open)
   uint32_t slots;
-  hipIpcMemHandle_t handle;
+  // one allocation and one handle PER SLOT: mapping a single multi-GB allocation through hipIpcOpenMemHandle left the
+  // receiver hanging on this ROCm (80 slots x 46 MB in one piece; 16 x 46 MB worked), slot-sized pieces do not
+  hipIpcMemHandle_t handle[kMaxRingSlots];
   uint32_t busy[kMaxRingSlots];  // 1 while a published message lives in the slot
   size_t sent_device, sent_host;  // messages of this sampler by payload location
   // fallback when a receiver cannot map the ring (hipIpcOpenMemHandle refused): it asks the owner to copy the slot
@@ -81,7 +83,11 @@ class MemoryQueue {
   void Release(size_t key);                          // SharedData::~SharedData
   size_t SlotBytes() const { return meta_->mq_nbytes; }
   size_t NumSlots() const { return meta_->max_size; }
-  size_t Pending() const { return meta_->send_cnt - meta_->recv_cnt; }
+  size_t Pending() const { return *(volatile size_t *)&meta_->send_cnt - *(volatile size_t *)&meta_->recv_cnt; }
+  // device-visible address of a pointer into the (pinned) queue region, for kernels that read a host slot in place
+  const void *DeviceVisiblePtr(const void *host_ptr) const {
+    return dev_base_ + (static_cast<const char *>(host_ptr) - reinterpret_cast<const char *>(meta_));
+  }
 
   // ---- device ring (see RingInfo) ----
   // sampler process, after fork, current device = the sampler's: allocates `slots` message slots in HBM and exports
@@ -98,9 +104,11 @@ class MemoryQueue {
  private:
   QueueMeta *meta_;
   size_t total_bytes_;
+  const char *dev_base_ = nullptr;  // device-visible address of meta_ (set by PinMemory)
   void ServiceSpills(int ring);
-  void *local_ring_[kMaxRings] = {};   // rings this process owns
-  void *mapped_ring_[kMaxRings] = {};  // rings of other processes, opened through IPC
+  void *local_slot_[kMaxRings][kMaxRingSlots] = {};   // slots of the rings this process owns
+  void *mapped_slot_[kMaxRings][kMaxRingSlots] = {};  // slots of other processes' rings, opened through IPC on first use
+  bool owns_ring_[kMaxRings] = {};
   std::thread svc_;                    // answers spill requests for the ring this process owns
   std::atomic<bool> svc_stop_{false};
 };
@@ -123,5 +131,15 @@ struct PackArgs {
 };
 // enqueues the serialisation of one batch into `slot` (device-visible host memory)
 int LaunchPack(const PackArgs &a, hipStream_t stream);
+
+// receiver side: the arrays of a message that have to outlive the queue slot (ids, COO) are copied out by ONE kernel
+// (the reference issues one cudaMemcpyAsync per array, task_queue.cc:257-347); the cache index arrays are not copied
+// at all -- the gathers read them in place, from the sampler's HBM slot over xGMI or from the mapped host slot
+struct UnpackArgs {
+  static constexpr int kMaxSegments = 2 + 3 * FGNN_MAX_LAYERS;
+  int num_segments;
+  struct { uint32_t *dst; const uint32_t *src; size_t words; } seg[kMaxSegments];
+};
+int LaunchUnpack(const UnpackArgs &a, hipStream_t stream);
 
 }  // namespace sam

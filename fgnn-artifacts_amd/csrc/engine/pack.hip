@@ -83,7 +83,21 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
   }
 }
 
+__global__ __launch_bounds__(kPackBlock) void unpack_kernel(UnpackArgs a) {
+  for (int k = 0; k < a.num_segments; ++k) copy_words(a.seg[k].dst, a.seg[k].src, a.seg[k].words);
+}
+
 }  // namespace
+
+int LaunchUnpack(const UnpackArgs &a, hipStream_t stream) {
+  size_t words = 0;
+  for (int k = 0; k < a.num_segments; ++k) words += a.seg[k].words;
+  if (words == 0) return FGNN_OK;
+  size_t blocks = (words + kPackBlock * 4 - 1) / (kPackBlock * 4);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(kPackBlock), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
 
 int LaunchPack(const PackArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL(pack_kernel, dim3(256), dim3(kPackBlock), 0, stream, a);

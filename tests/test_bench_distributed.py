@@ -47,6 +47,7 @@ def _run(cmd, env=None):
 def test_plain_launch_spawns_ranks(gpus, samplers):
     """`python bench.py --gpus N` (how the driver ran it in round 1): bench.py starts the N rank processes itself"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    before = set(os.listdir("/dev/shm"))
     cmd = [sys.executable, "bench.py", "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--rehearse"]
     if samplers:
         cmd += ["--samplers", str(samplers)]
@@ -58,7 +59,7 @@ def test_plain_launch_spawns_ranks(gpus, samplers):
     assert round(out["edges_per_step"] * 20) == _expected_edges(gpus, S, 5, 20)
     assert out["input_nodes_per_step"] == 1.0  # every one of the 20 batches reached exactly one trainer
     assert out["scaling"] == "strong" and out["ms_per_step"] > 0
-    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fgnn_bench_")]  # rank 0 removed the job's names
+    assert not [f for f in set(os.listdir("/dev/shm")) - before if f.startswith("fgnn_bench_")]  # rank 0 cleaned up
 
 
 def test_torchrun_launch():
