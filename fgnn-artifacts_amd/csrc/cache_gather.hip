@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = scan_take_tile(scan, &sh_tile);
   if (tile >= ntiles) return;
   phase_mark(scan, tile, 0);
   const size_t chunk0 = (size_t)tile * chunk;
@@ -320,7 +320,7 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
       if (const char *e_g = getenv("FGNN_SPLIT_GRID")) grid = (size_t)atoi(e_g) < grid ? (size_t)atoi(e_g) : grid;
       hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid), dim3(kBlock), 0, s, table, nodes, num_nodes,
                          d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
-                         scan->next(2), ablate);
+                         scan->next(2, grid), ablate);
       return launch_status(__func__);
     }
   }
@@ -380,7 +380,7 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
     // tuning knobs (read per call: only used by profiles/ sweeps)
     const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
     const int unroll = e_u ? atoi(e_u) : 4;
-    const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4;
+    const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4, cus = (size_t)device_cu_count();
     // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
     // loads (profiles/r01_gather_sweep.csv)
     const bool nt = e_nt ? atoi(e_nt) != 0 : true;
@@ -391,7 +391,7 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
 #define FGNN_GATHER3(U, C, N)                                                                                    \
   do {                                                                                                           \
     size_t blocks = div_up(total, (size_t)kBlock * U);                                                           \
-    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;                                                      \
+    if (blocks > cus * wg_per_cu) blocks = cus * wg_per_cu;                                                      \
     if (nts) hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, true>), dim3(blocks), dim3(kBlock), 0, s,          \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
                        d_n, cap, cpr, src_row_mask);                                                             \
@@ -416,7 +416,7 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
   } else {
     const size_t total = cap * dim;
     size_t blocks = div_up(total, kBlock);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > (size_t)device_cu_count() * 16) blocks = (size_t)device_cu_count() * 16;
 #define FGNN_ELEM(T)                                                                                              \
   hipLaunchKernelGGL((gather_rows_elem_kernel<T>), dim3(blocks), dim3(kBlock), 0, s, static_cast<T *>(out),       \
                      static_cast<const T *>(src), src_index, dst_index, n, d_n, cap, dim, src_row_mask)

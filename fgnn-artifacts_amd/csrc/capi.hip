@@ -21,6 +21,19 @@ extern "C" size_t fgnn_debug_phase_log_bytes(void) {
 }
 extern "C" void fgnn_debug_phase_log(unsigned long long *d_buf) { fgnn::g_phase_log = d_buf; }
 
+// a foreign tenant for the co-residency stress test: `workgroups` x 256 threads that hold their wave slots for `usec`
+// microseconds of the 100 MHz wall clock and do nothing else (bounded: every wave exits by itself)
+__global__ __launch_bounds__(256) void debug_occupy_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream) {
+  if (workgroups == 0 || workgroups > (1u << 20) || usec > 2000000u) return FGNN_EINVAL;
+  hipLaunchKernelGGL(debug_occupy_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (unsigned long long)usec * 100ull);
+  return fgnn::launch_status(__func__);
+}
+
 extern "C" const char *fgnn_last_error(void) { return fgnn::g_last_error; }
 
 extern "C" const char *fgnn_version(void) { return "fgnn-hip 0.1 (gfx950)"; }

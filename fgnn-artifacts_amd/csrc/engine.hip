@@ -72,6 +72,12 @@ struct fgnn_batch {
 namespace fgnn {
 namespace {
 
+// a caller-chosen feat_rows_cap below the worst case (fgnn_batch_create): the gather clamps to the capacity, this
+// marks the batch so that the host does not take the truncated tensor for the whole one (fgnn_hip.h, `overflow`)
+__global__ void batch_rows_overflow_kernel(fgnn_batch_meta *m, uint32_t cap) {
+  if (m->num_input > cap) m->overflow = 1u;
+}
+
 size_t dtype_size(int dtype) {
   switch (dtype) {
     case FGNN_I8: case FGNN_U8: return 1;
@@ -260,7 +266,18 @@ namespace {
 struct SeqGuard {
   fgnn_sampler *s;
   uint64_t seq;
+  hipStream_t st;
   bool csr_marked = false;
+  bool finished = false;  // the success path has reset the slot's table and recorded its events itself
+  // An early error return leaves the slot's table with this batch's pending buckets and notes: the slot's next batch
+  // must not dedup against them, and must still find the slot's events recorded.
+  void abandon() {
+    fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+    (void)fgnn::hashtable_next_generation(sl.ht, st, false);
+    if (s->cfg.sample_type == FGNN_KHOP2 && !csr_marked) (void)hipEventRecord(sl.csr, st);
+    (void)hipEventRecord(sl.done, st);
+    sl.was_used = true;
+  }
   void mark_csr() {
     if (csr_marked) return;
     csr_marked = true;
@@ -273,6 +290,7 @@ struct SeqGuard {
     s->cv.notify_all();
   }
   ~SeqGuard() {
+    if (!finished) abandon();
     mark_csr();
     std::lock_guard<std::mutex> lk(s->mu);
     s->done_flag[seq % kSlots] = true;
@@ -303,7 +321,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return seq < s->returned + kSlots; })) return FGNN_EINVAL;
     if (seq < s->returned) return FGNN_EINVAL;
   }
-  SeqGuard guard{s, seq};
+  SeqGuard guard{s, seq, st};
   fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
   fgnn_hashtable *ht = sl.ht;
@@ -398,6 +416,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   if (rc != FGNN_OK) return rc;
   FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
   sl.was_used = true;
+  guard.finished = true;
   return launch_status(__func__);
 }
 
@@ -470,6 +489,8 @@ extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *l
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
   if (feat) {
+    if (b->feat_rows_cap < b->owner->max_nodes)
+      hipLaunchKernelGGL(batch_rows_overflow_kernel, dim3(1), dim3(1), 0, st, b->d_meta, (uint32_t)b->feat_rows_cap);
     if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
     rc = fgnn_gather_rows_masked(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
                                  b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
@@ -487,6 +508,8 @@ extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *l
 extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void *full_feat,
                                          const void *label, void *stream) {
   if (!b || !b->feat_dim) return FGNN_EINVAL;
+  // rows are scattered by destination index: a feature buffer below the worst case cannot be clamped, refuse it
+  if (b->feat_rows_cap < b->owner->max_nodes) return FGNN_EINVAL;
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
   const bool timing = b->timing && full_feat && cache_rows;

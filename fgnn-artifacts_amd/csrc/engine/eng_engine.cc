@@ -217,6 +217,8 @@ void Engine::InitSingleGPU(bool extract) {
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, aligned ? (int)RC().worker_id : 0, aligned ? (int)RC().num_worker : 1,
                                stream_, aligned));
+  // the aligned split pads the set with repeated ids and the reference's aligned shuffler has no check either
+  if (RC().option_sanity_check && !aligned) shuffler_->EnableSanityCheck(ds_.num_node);
   pool_.reset(new GraphPool(RC().max_copying_jobs));
   slots_.resize(RC().max_copying_jobs + 2);
   for (auto &s : slots_) {
@@ -254,6 +256,7 @@ void Engine::InitInProcess() {
   }
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, 0, 1, stream_));
+  if (RC().option_sanity_check) shuffler_->EnableSanityCheck(ds_.num_node);
   slots_.resize(dynamic ? 0 : 2);  // the dynamic-cache loop (eng_dynamic.cc) hands batches over in process, no messages
   for (auto &s : slots_) {
     int err = 0;
@@ -397,6 +400,7 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   // arch6: equal shares of the padded train set (DistAlignedShuffler, dist_engine.cc:276-281)
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_, arch6));
+  if (RC().option_sanity_check && !arch6) shuffler_->EnableSanityCheck(ds_.num_node);
   pool_.reset(new GraphPool(RC().max_copying_jobs));
   slots_.resize(3);  // batches in flight: enqueued by sample_once, published by the publisher thread
   for (auto &s : slots_) {

@@ -85,6 +85,17 @@ Shuffler::Shuffler(const uint32_t *train_set, size_t num_data, size_t num_epoch,
 
 Shuffler::~Shuffler() {
   if (d_data_) (void)hipFree(d_data_);
+  if (d_sanity_bits_) (void)hipFree(d_sanity_bits_);
+  if (d_sanity_flags_) (void)hipFree(d_sanity_flags_);
+}
+
+void Shuffler::EnableSanityCheck(size_t num_node) {
+  if (d_sanity_bits_ || num_node == 0) return;
+  sanity_num_node_ = num_node;
+  SAM_HIP(hipMalloc(&d_sanity_bits_, fgnn_sanity_map_bytes(num_node)));
+  SAM_HIP(hipMalloc(&d_sanity_flags_, sizeof(uint32_t)));
+  SAM_HIP(hipMemset(d_sanity_bits_, 0, fgnn_sanity_map_bytes(num_node)));
+  SAM_HIP(hipMemset(d_sanity_flags_, 0, sizeof(uint32_t)));
 }
 
 void Shuffler::ReShuffle() {
@@ -99,6 +110,8 @@ void Shuffler::ReShuffle() {
   ShuffleMinstd0(data_.data(), num_data_, cur_epoch_);  // seed = epoch: every sampler gets the same permutation
   SAM_HIP(hipMemcpyAsync(d_data_, data_.data() + dataset_offset_, local_size_ * sizeof(uint32_t),
                          hipMemcpyHostToDevice, stream_));
+  if (d_sanity_bits_)  // a new epoch may hand every id out again (dist_shuffler.cc:139-144)
+    SAM_HIP(hipMemsetAsync(d_sanity_bits_, 0, fgnn_sanity_map_bytes(sanity_num_node_), stream_));
   SAM_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -108,6 +121,17 @@ bool Shuffler::GetBatch(const uint32_t **d_batch, size_t *size) {
   if (cur_epoch_ >= num_epoch_) return false;
   *d_batch = d_data_ + cur_step_ * batch_size_;
   *size = cur_step_ == num_step_ - 1 ? last_batch_size_ : batch_size_;
+  if (d_sanity_bits_) {
+    uint32_t flags = 0;
+    SAM_CHECK(fgnn_sanity_check_batch(d_sanity_bits_, sanity_num_node_, *d_batch, *size, 0xFFFFFFFFu, d_sanity_flags_,
+                                      stream_) == FGNN_OK);
+    SAM_HIP(hipMemcpyAsync(&flags, d_sanity_flags_, sizeof(flags), hipMemcpyDeviceToHost, stream_));
+    SAM_HIP(hipStreamSynchronize(stream_));
+    SAM_CHECK((flags & 1u) == 0) << "sanity check: invalid id in the batch of epoch " << cur_epoch_ << " step " << Step();
+    SAM_CHECK((flags & 4u) == 0) << "sanity check: id beyond num_node in the batch of epoch " << cur_epoch_ << " step "
+                                 << Step();
+    SAM_CHECK((flags & 2u) == 0) << "duplicate batch input (epoch " << cur_epoch_ << " step " << Step() << ")";
+  }
   return true;
 }
 

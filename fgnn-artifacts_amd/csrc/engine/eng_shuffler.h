@@ -40,6 +40,9 @@ class Shuffler {
   size_t NumLocalStep() const { return num_step_; }   // steps of this sampler
   bool IsLastBatch() const { return cur_step_ == num_step_ - 1; }
   void Reset() { initialized_ = false; cur_step_ = num_step_; cur_epoch_ = 0; }
+  // SAMGRAPH_SANITY_CHECK (dist_shuffler.cc:139-144,169-176): every batch handed out is checked on the GPU for invalid
+  // ids and for ids already handed out in this epoch; a violation is fatal like the reference's device assert
+  void EnableSanityCheck(size_t num_node);
 
  private:
   void ReShuffle();
@@ -51,6 +54,9 @@ class Shuffler {
   size_t cur_step_;
   bool initialized_ = false;
   hipStream_t stream_;
+  size_t sanity_num_node_ = 0;
+  uint32_t *d_sanity_bits_ = nullptr;  // 1 bit per node, cleared at every reshuffle
+  uint32_t *d_sanity_flags_ = nullptr;
 };
 
 }  // namespace sam

@@ -309,17 +309,38 @@ __device__ __forceinline__ uint32_t block_exclusive_rank(bool pred, uint32_t *sh
 // 64-bit word {generation|status : value}, written and polled with relaxed agent-scope atomics: flag and
 // payload travel together, so no fence is needed (MI355X guide, inter-workgroup hand-off, single granule).
 // The generation (one per launch) makes stale descriptors of earlier launches read as "not ready": no reset
-// between launches.  A workgroup waits only for lower-numbered workgroups of its own launch, which its XCD
-// dispatched before it; hosts cap such grids at 1536 workgroups (192 per XCD) so that no launch can fill an XCD with
-// waiters.  Spins are bounded; on timeout an error word is set (the batch summary's `overflow` in the batch
-// driver) and the prefix is wrong but the kernel terminates.
+// between launches.
+// Forward progress: a workgroup does NOT take blockIdx.x as its tile -- it draws a TICKET at entry (scan_take_tile:
+// one relaxed atomicAdd per workgroup) and the ticket is its tile.  A workgroup therefore only ever waits for tiles
+// whose workgroups have already started, and a started workgroup publishes its aggregate before it waits for anything:
+// no assumption about dispatch order, about how many workgroups are resident, or about what other streams and
+// processes put on the GPU meanwhile (round 1 relied on in-order dispatch per XCD plus a residency cap computed for
+// an idle GPU).  The ticket counter is never reset: launches that share descriptors are stream-ordered, the host
+// knows every grid size, so launch i's tickets are [base_i, base_i + grid_i) modulo 2^32.
+// Spins stay bounded as a last line of defence (a wedged GPU, not a scheduling pattern): on timeout an error word is
+// set (the batch summary's `overflow` in the batch driver), the prefix is wrong, the kernel terminates.
 struct ScanWs {
   unsigned long long *desc;  // [max_tiles]
   uint32_t *error;           // [1] set to 1 if a spin timed out
   uint32_t gen;              // this launch's generation (1 .. 2^30-1)
   uint32_t max_tiles;
   unsigned long long *log;   // diagnostics (fgnn_debug_phase_log): [tile][8] wall-clock stamps per phase, or null
+  uint32_t *ticket;          // [1] running ticket counter (null: tile = blockIdx.x, for kernels that wait on nobody)
+  uint32_t ticket_base;      // counter value when this launch draws its first ticket
 };
+
+// tile of this workgroup = order in which it started among the workgroups of its launch.  EVERY workgroup of the
+// grid must call this exactly once, before any early exit (the host advances the base by the grid size).
+// `sh` = one LDS word; contains two barriers.
+__device__ __forceinline__ uint32_t scan_take_tile(const ScanWs &w, uint32_t *sh) {
+  if (!w.ticket) return blockIdx.x;
+  if (threadIdx.x == 0)
+    *sh = __hip_atomic_fetch_add(w.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - w.ticket_base;
+  __syncthreads();
+  const uint32_t t = *sh;
+  __syncthreads();
+  return t;
+}
 
 constexpr uint32_t kPhaseLogTiles = 4096, kPhaseLogKinds = 4;
 // phase timestamps of the single-pass kernels (100 MHz wall clock); a no-op unless a log buffer is installed
@@ -424,13 +445,13 @@ inline int device_cu_count() {
 
 // host side of ScanWs: owns the descriptors and hands out generations
 struct ScanWsHost {
-  ScanWs ws{nullptr, nullptr, 0, 0, nullptr};
+  ScanWs ws{nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   int create(size_t max_tiles);
   void destroy();
-  // descriptor view for the next launch
+  // descriptor view for the next launch of `grid` workgroups (all of which call scan_take_tile)
   // kind: which kernel family the launch belongs to (0 sampler, 1 dedup count+assign, 2 cache split) -- selects
   // the section of the diagnostic phase log
-  ScanWs next(uint32_t kind = 0) {
+  ScanWs next(uint32_t kind, size_t grid) {
     if (ws.gen >= 0x3FFFFFFEu) {
       // generations are about to repeat (once per 2^30 launches): descriptors stamped during the previous cycle
       // must not read as fresh, so start the new cycle from zeroed descriptors, fenced against everything in flight
@@ -441,6 +462,7 @@ struct ScanWsHost {
     }
     ws.gen += 1u;
     ScanWs v = ws;
+    ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
     if (uint32_t *sink = scan_error_sink()) v.error = sink;
     unsigned long long *log = phase_log_base();
     v.log = log ? log + (size_t)(kind % kPhaseLogKinds) * kPhaseLogTiles * 8 : nullptr;

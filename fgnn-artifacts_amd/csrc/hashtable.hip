@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = scan_take_tile(scan, &sh_tile);
   if (tile >= ntiles) return;  // whole workgroup; nobody looks back at an unused tile
   phase_mark(scan, tile, 0);
   const uint32_t old = d_num_items[1];
@@ -555,7 +555,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > 0) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(1), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
+                         scan->next(1, grid), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
       if (mapped)
         hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
                            mapped);

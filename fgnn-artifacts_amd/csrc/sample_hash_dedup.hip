@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void hash_dedup_kernel(const uint32_t *__re
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);
   const uint32_t ntiles = n ? (n - 1) / kBlock + 1 : 1u;
   const int tid = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = mode == 0 ? scan_take_tile(scan, &sh_tile) : blockIdx.x;
   if (tile >= ntiles) {
     if (mode == 1 && tid == 0) block_sums[tile] = 0;
     return;
@@ -121,14 +121,16 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
     sums = static_cast<uint32_t *>(ws);
     mode = 1;
   } else if (scan_host && nb <= scan_host->ws.max_tiles) {
-    scan = scan_host->next(0);
+    scan = scan_host->next(0, nb);
   } else {
-    // stateless entry point: descriptors in the caller's scratch, zeroed, generation 1
-    if (ws_bytes < nb * sizeof(unsigned long long)) return FGNN_ENOSPC;
-    FGNN_HIP_CHECK(hipMemsetAsync(ws, 0, nb * sizeof(unsigned long long), st));
+    // stateless entry point: descriptors and ticket counter in the caller's scratch, zeroed, generation 1
+    if (ws_bytes < (nb + 1) * sizeof(unsigned long long)) return FGNN_ENOSPC;
+    FGNN_HIP_CHECK(hipMemsetAsync(ws, 0, (nb + 1) * sizeof(unsigned long long), st));
     scan.desc = static_cast<unsigned long long *>(ws);
     scan.gen = 1;
     scan.max_tiles = (uint32_t)nb;
+    scan.ticket = reinterpret_cast<uint32_t *>(scan.desc + nb);
+    scan.ticket_base = 0;
   }
 #define FGNN_HD(MODE)                                                                                              \
   hipLaunchKernelGGL(hash_dedup_kernel, dim3(nb), dim3(kBlock), lds, st, indptr, indices, prob_table, alias_table, \

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   // edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
   __shared__ uint32_t sh_tile;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = scan_take_tile(scan, &sh_tile);  // start order, not blockIdx.x (fgnn_device.h)
   const size_t first = (size_t)tile * S;
   const uint32_t last_tile = n ? (uint32_t)((n - 1) / S) : 0u;  // tiles beyond it have no seeds and nobody waits for them
   if (tile > last_tile) return;  // whole workgroup exits together
@@ -411,10 +411,10 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));             \
       attr_done = true;                                                                                        \
     }                                                                                                          \
-    /* single pass (no count kernel, no scan kernel) for grids of up to 1536 workgroups: a workgroup waits only   */ \
-    /* for lower-numbered workgroups of its own launch, which each XCD dispatches before it, and 1536 workgroups   */ \
-    /* (192 per XCD) cannot fill an XCD with waiters, so the lowest unfinished tile always gets a slot             */ \
-    if (want_scan && nb <= 1536) scan = scan_host->next();                                                 \
+    /* single pass (no count kernel, no scan kernel) for grids of up to 1536 workgroups (every tile sums all its    */ \
+    /* predecessors' aggregates: O(tiles^2) descriptor reads); tiles are start-order tickets, so a workgroup only   */ \
+    /* waits for workgroups that are already running                                                               */ \
+    if (want_scan && nb <= 1536) scan = scan_host->next(0, nb);                                            \
     if (!scan.desc) {                                                                                          \
       scan.log = phase_log_base();                                                                             \
       hipLaunchKernelGGL((khop_count_kernel_s<SS>), dim3(nb), dim3(SS), 0, stream, indptr, input, num_input,   \

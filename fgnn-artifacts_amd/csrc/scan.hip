@@ -37,12 +37,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(uint32_t *s
 int ScanWsHost::create(size_t max_tiles) {
   if (max_tiles == 0) max_tiles = 1;
   if (hipMalloc(&ws.desc, max_tiles * sizeof(unsigned long long)) != hipSuccess) return FGNN_EHIP;
-  if (hipMalloc(&ws.error, sizeof(uint32_t)) != hipSuccess) return FGNN_EHIP;
+  if (hipMalloc(&ws.error, 2 * sizeof(uint32_t)) != hipSuccess) return FGNN_EHIP;  // {error, ticket counter}
+  ws.ticket = ws.error + 1;
+  ws.ticket_base = 0;
   ws.max_tiles = (uint32_t)max_tiles;
   ws.gen = 0;
   // generation 0 never matches a launch (generations start at 1)
   if (hipMemset(ws.desc, 0, max_tiles * sizeof(unsigned long long)) != hipSuccess) return FGNN_EHIP;
-  if (hipMemset(ws.error, 0, sizeof(uint32_t)) != hipSuccess) return FGNN_EHIP;
+  if (hipMemset(ws.error, 0, 2 * sizeof(uint32_t)) != hipSuccess) return FGNN_EHIP;
   return FGNN_OK;
 }
 
@@ -51,6 +53,7 @@ void ScanWsHost::destroy() {
   if (ws.error) (void)hipFree(ws.error);
   ws.desc = nullptr;
   ws.error = nullptr;
+  ws.ticket = nullptr;
 }
 
 int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *total32, const uint32_t *accum,

@@ -20,7 +20,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
          torch.int8: I8, torch.int64: I64}
 
 EXPORTS = [
-    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_scratch_bytes", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
@@ -292,6 +292,30 @@ def neighbourhood_expand(indptr, indices, frontier, stamp, mark, freq, nxt, d_nu
                                             C.c_int(1 if mark_frontier else 0), _stream()), "fgnn_neighbourhood_expand")
 
 
+class SanityChecker:
+    """SAMGRAPH_SANITY_CHECK's per-epoch net (GPUSanityCheckList + GPUBatchSanityCheck, cuda_sanity_check.cu:28-88):
+    check(batch) returns the flag word -- 0 = fine, 1 = an invalid id, 2 = an id seen before in this epoch (or twice in
+    the batch), 4 = an id >= num_node.  new_epoch() clears the seen-bitmap."""
+
+    def __init__(self, num_node, device, invalid_val=EMPTY):
+        L = load()
+        L.fgnn_sanity_map_bytes.restype = C.c_size_t
+        self.num_node, self.invalid = num_node, invalid_val
+        self.bits = torch.zeros(L.fgnn_sanity_map_bytes(C.c_size_t(num_node)) // 4, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def new_epoch(self):
+        self.bits.zero_()
+
+    def check(self, batch, no_duplicates=True):
+        _need_gpu(batch)
+        self.flags.zero_()
+        _check(load().fgnn_sanity_check_batch(_ptr(self.bits) if no_duplicates else None, C.c_size_t(self.num_node),
+                                              _ptr(batch), C.c_size_t(batch.numel()), C.c_uint32(self.invalid),
+                                              _ptr(self.flags), _stream()), "fgnn_sanity_check_batch")
+        return int(self.flags.item())
+
+
 def presample_count(freq, nodes, num_nodes=None, d_num_nodes=None):
     """PreSampler's counting step: freq[nodes[i]] += 1 (dist/pre_sampler.cc:117-131).  Asynchronous."""
     _need_gpu(freq, nodes)
@@ -511,6 +535,7 @@ class Batch:
         if not self.h:
             raise FgnnError(f"fgnn_batch_create failed with code {err.value} {L.fgnn_last_error().decode()}")
         self.feat_dim, self.feat_dtype, self.label_dtype = feat_dim, feat_dtype, label_dtype
+        self.feat_rows_cap = min(feat_rows_cap, sampler.max_nodes) if feat_rows_cap else sampler.max_nodes
         self.meta = None
 
     def __del__(self):
@@ -585,7 +610,9 @@ class Batch:
                             self.sampler.device)
 
     def feat(self):
-        return _wrap_device(load().fgnn_batch_feat(self.h), (int(self.meta.num_input), self.feat_dim),
+        # a batch larger than a caller-chosen feat_rows_cap carries meta.overflow and only the first cap rows
+        return _wrap_device(load().fgnn_batch_feat(self.h),
+                            (min(int(self.meta.num_input), self.feat_rows_cap), self.feat_dim),
                             self.feat_dtype, self.sampler.device)
 
     def label(self):

@@ -52,9 +52,22 @@ int fgnn_device_count(void);
  * their phase boundaries: u64[kind 0..3][tile 0..4095][phase 0..7].  NULL (the default) switches it off. */
 size_t fgnn_debug_phase_log_bytes(void);
 void fgnn_debug_phase_log(unsigned long long *d_buf);
+/* Diagnostics (tests/test_coresidency_gpu.py): a foreign tenant -- `workgroups` x 256 threads that keep their wave
+ * slots for `usec` microseconds (<= 2 s) on `stream` and do nothing else. */
+int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);
+
+/* ---- sanity checks (SAMGRAPH_SANITY_CHECK) --------------------------------------------------- */
+/* GPUSanityCheckList + GPUBatchSanityCheck (cuda/cuda_sanity_check.cu:28-88) in one launch: every id of `input` differs
+ * from invalid_val and -- when seen_bits != NULL, a bitmap of fgnn_sanity_map_bytes(num_node) bytes that the caller
+ * zeroes at the start of an epoch -- has not been seen before in this epoch (ids are marked as seen).  The outcome is
+ * OR-ed into *d_flags (a device word the caller zeroes): 1 = an invalid id, 2 = a duplicate, 4 = an id >= num_node.
+ * The reference assert()s inside the kernel; here the caller reads the word and decides. */
+size_t fgnn_sanity_map_bytes(size_t num_node);
+int fgnn_sanity_check_batch(uint32_t *seen_bits, size_t num_node, const uint32_t *input, size_t num_input,
+                            uint32_t invalid_val, uint32_t *d_flags, void *stream);
 
 /* ---- samplers ----------------------------------------------------------------------------- */
 

@@ -31,9 +31,14 @@ TRAINER_DEV = os.environ.get("FGNN_TEST_TRAINER_DEVICE", "cuda:0")
 
 def dataset(workdir, sample_type):
     from fgnn_hip import synth
-    return synth.write_dataset(workdir, "synth", NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN, 100, 100, seed=17,
-                               with_prefix=(sample_type == "weighted_khop_prefix"),
-                               with_alias=(sample_type in ("weighted_khop", "weighted_khop_hash_dedup")))
+    d = synth.write_dataset(workdir, "synth", NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN, 100, 100, seed=17,
+                            with_prefix=(sample_type == "weighted_khop_prefix"),
+                            with_alias=(sample_type in ("weighted_khop", "weighted_khop_hash_dedup")))
+    if os.environ.get("FGNN_TEST_DUP_SEED"):  # a corrupt train set: one id twice (SAMGRAPH_SANITY_CHECK must trip)
+        t = np.fromfile(os.path.join(d, "train_set.bin"), dtype=np.uint32)
+        t[-1] = t[0]
+        t.tofile(os.path.join(d, "train_set.bin"))
+    return d
 
 
 def base_config(path, arch, sample_type):

@@ -24,6 +24,23 @@ def test_arch1_single_gpu(tmp_path, sample_type):
     assert "ok" in _run(tmp_path, "arch1", sample_type)
 
 
+@pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch5", ["khop2", 2, 1, 0.25, "pipeline"])])
+def test_sanity_check_passes_on_a_clean_train_set(tmp_path, mode, args):
+    """SAMGRAPH_SANITY_CHECK=1 (run_config.cc:91, dist_shuffler.cc:169-176): every batch is checked on the GPU for
+    invalid ids and for ids already handed out in the epoch; a clean train set runs through, results unchanged."""
+    assert "ok" in _run(tmp_path, mode, *args, env={"SAMGRAPH_SANITY_CHECK": "1"})
+
+
+def test_sanity_check_trips_on_a_duplicated_seed(tmp_path):
+    """a train set holding one id twice: fatal at the batch that hands the id out again, like the reference's device
+    assert "duplicate batch input" (cuda_sanity_check.cu:37-40); without the flag the same run goes through the engine
+    unnoticed (the duplicate only shows in the comparison with the oracle's replay, which is why the flag exists)"""
+    p = subprocess.run([sys.executable, RUNNER, "arch1", "khop2", str(tmp_path)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, SAMGRAPH_SANITY_CHECK="1", FGNN_TEST_DUP_SEED="1"))
+    assert p.returncode != 0
+    assert "duplicate batch input" in p.stderr, p.stderr[-3000:]
+
+
 @pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch3", ["khop2", 0.25, "inline"]),
                                        ("arch5", ["khop2", 1, 1, 0.25, "pipeline"])])
 def test_empty_feat_mock_extraction(tmp_path, mode, args):

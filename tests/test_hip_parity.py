@@ -974,3 +974,32 @@ def test_run_batch_cached_matches_oracle(hip, oracle):
         ms = bt.extract_cached_ms()
         assert ms[0] >= 0 and ms[1] >= 0
         np.testing.assert_array_equal(host_u32(bt.d_num_input()), [m.num_input])
+
+
+@pytest.mark.gpu
+def test_sanity_check_kernel(hip):
+    """GPUSanityCheckList + GPUBatchSanityCheck (cuda_sanity_check.cu:28-88) as one launch reporting through a flag
+    word: clean batches pass, an id handed out twice in an epoch (in another batch or inside one batch), the invalid
+    value and an id beyond the graph are each reported; a new epoch may hand every id out again."""
+    num_node = 100_000
+    rs = np.random.default_rng(3)
+    perm = rs.permutation(num_node).astype(np.uint32)
+    chk = hip.SanityChecker(num_node, torch.device("cuda", 0))
+    for b in range(10):
+        assert chk.check(dev(perm[b * 8000:(b + 1) * 8000])) == 0
+    again = perm[80000:88000].copy()
+    again[4321] = perm[17]                      # handed out in batch 0
+    assert chk.check(dev(again)) == 2
+    twice = perm[88000:96000].copy()
+    twice[7000] = twice[12]                     # twice inside one batch
+    assert chk.check(dev(twice)) == 2
+    bad = perm[96000:99000].copy()
+    bad[5] = 0xFFFFFFFF
+    assert chk.check(dev(bad)) == 1
+    assert chk.check(dev(np.array([num_node + 5], dtype=np.uint32))) == 4
+    assert chk.check(dev(np.array([0xFFFFFFFF, perm[0]], dtype=np.uint32))) == 3
+    assert chk.check(dev(perm[:100]), no_duplicates=False) == 0  # list check only: repeats are not its business
+    chk.new_epoch()
+    for b in range(12):
+        assert chk.check(dev(perm[b * 8000:(b + 1) * 8000])) == 0
+    assert chk.check(dev(np.zeros(0, dtype=np.uint32))) == 0
