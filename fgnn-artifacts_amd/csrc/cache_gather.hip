@@ -107,44 +107,60 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
                                                                    uint32_t *__restrict__ d_counts, ScanWs scan,
                                                                    uint32_t ablate) {
   __shared__ uint32_t sh[kWavesPerBlock];
-  __shared__ uint32_t sh_tile;
+  __shared__ uint32_t sh_tile[2];
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);  // cap < 2^32 (host check)
   const uint32_t per_round = kBlock * gridDim.x;
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
-  const uint32_t tile = scan_take_tile(scan, &sh_tile);
+  const uint32_t tile = scan_take_tile(scan, sh_tile);
   if (tile >= ntiles) return;
   phase_mark(scan, tile, 0);
   const size_t chunk0 = (size_t)tile * chunk;
-  uint32_t miss_mask = 0, cnt = 0;
-  // four rounds at a time: their loads are independent, keep them all in flight
-  for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
-    uint32_t nd[4], sv[4];
-    bool ok[4];
+  // misses among the nodes of tile `tl` (bit r of *mask: this thread's node of round r is one).  own = true: this
+  // workgroup's tile -- the looked-up slots are kept for the split below.  own = false: another tile's count,
+  // recomputed by a waiter that helps (scan_prefix_help): same reads, no writes.
+  auto count_chunk = [&](uint32_t tl, bool own, uint32_t *mask) -> uint32_t {
+    const size_t c0 = (size_t)tl * chunk;
+    uint32_t mm = 0, cn = 0;
+    // four rounds at a time: their loads are independent, keep them all in flight
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
+      uint32_t nd[4], sv[4];
+      bool ok[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
-      ok[u] = r0 + u < rounds && i < n;
-      nd[u] = ok[u] ? nodes[i] : 0u;
-    }
+      for (int u = 0; u < 4; ++u) {
+        const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+        ok[u] = r0 + u < rounds && i < n;
+        nd[u] = ok[u] ? nodes[i] : 0u;
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sv[u] = ok[u] && !(ablate & 1u) ? table[nd[u]] : 0u;
+      for (int u = 0; u < 4; ++u) sv[u] = ok[u] && !(ablate & 1u) ? table[nd[u]] : 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (ok[u]) {
-        if (!(ablate & 2u)) slot[chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x] = sv[u];
-        if (sv[u] == FGNN_EMPTY_KEY) {
-          miss_mask |= 1u << (r0 + u);
-          ++cnt;
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          if (own && !(ablate & 2u)) slot[c0 + (size_t)(r0 + u) * kBlock + threadIdx.x] = sv[u];
+          if (sv[u] == FGNN_EMPTY_KEY) {
+            mm |= 1u << (r0 + u);
+            ++cn;
+          }
         }
       }
     }
-  }
+    *mask = mm;
+    return cn;
+  };
+  uint32_t miss_mask = 0;
+  const uint32_t cnt = count_chunk(tile, true, &miss_mask);
   uint32_t tot;
   (void)block_exclusive_scan<kWavesPerBlock>(cnt, sh, &tot);
   phase_mark(scan, tile, 1);
-  uint32_t miss_before = (ablate & 8u) ? 0u : scan_lookback(scan, tile, tot, &sh_tile);
+  scan_publish_aggregate(scan, tile, tot);
+  uint32_t miss_before = (ablate & 8u) ? 0u : scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+    uint32_t mask_m, tot_m;
+    const uint32_t cm = count_chunk(m, false, &mask_m);
+    (void)block_exclusive_scan<kWavesPerBlock>(cm, sh, &tot_m);
+    return tot_m;
+  });
   phase_mark(scan, tile, 2);
   if (tile == ntiles - 1 && threadIdx.x == 0) {
     d_counts[0] = miss_before + tot;

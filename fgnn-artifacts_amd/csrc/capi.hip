@@ -14,6 +14,19 @@ uint32_t *&scan_error_sink() {
 }
 static unsigned long long *g_phase_log = nullptr;
 unsigned long long *phase_log_base() { return g_phase_log; }
+// one device word per (process, device 0..15) counting the aggregates that waiting workgroups recomputed for tiles that
+// had not published in time (scan_prefix_help); never freed
+unsigned long long *scan_help_counter() {
+  static unsigned long long *g_helps[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_helps[dev]) {
+    unsigned long long *p = nullptr;
+    if (hipMalloc(&p, sizeof(*p)) != hipSuccess || hipMemset(p, 0, sizeof(*p)) != hipSuccess) return nullptr;
+    g_helps[dev] = p;
+  }
+  return g_helps[dev];
+}
 }  // namespace fgnn
 
 extern "C" size_t fgnn_debug_phase_log_bytes(void) {
@@ -32,6 +45,12 @@ extern "C" int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream)
   hipLaunchKernelGGL(debug_occupy_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
                      (unsigned long long)usec * 100ull);
   return fgnn::launch_status(__func__);
+}
+
+extern "C" unsigned long long fgnn_debug_scan_helps(void) {
+  unsigned long long v = 0, *p = fgnn::scan_help_counter();
+  if (!p || hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return v;
 }
 
 extern "C" const char *fgnn_last_error(void) { return fgnn::g_last_error; }

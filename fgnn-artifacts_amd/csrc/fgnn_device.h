@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "fgnn_hip.h"
 
 namespace fgnn { struct ScanWsHost; }
@@ -310,28 +312,38 @@ __device__ __forceinline__ uint32_t block_exclusive_rank(bool pred, uint32_t *sh
 // payload travel together, so no fence is needed (MI355X guide, inter-workgroup hand-off, single granule).
 // The generation (one per launch) makes stale descriptors of earlier launches read as "not ready": no reset
 // between launches.
-// Forward progress: a workgroup does NOT take blockIdx.x as its tile -- it draws a TICKET at entry (scan_take_tile:
-// one relaxed atomicAdd per workgroup) and the ticket is its tile.  A workgroup therefore only ever waits for tiles
-// whose workgroups have already started, and a started workgroup publishes its aggregate before it waits for anything:
-// no assumption about dispatch order, about how many workgroups are resident, or about what other streams and
-// processes put on the GPU meanwhile (round 1 relied on in-order dispatch per XCD plus a residency cap computed for
-// an idle GPU).  The ticket counter is never reset: launches that share descriptors are stream-ordered, the host
-// knows every grid size, so launch i's tickets are [base_i, base_i + grid_i) modulo 2^32.
-// Spins stay bounded as a last line of defence (a wedged GPU, not a scheduling pattern): on timeout an error word is
-// set (the batch summary's `overflow` in the batch driver), the prefix is wrong, the kernel terminates.
+// Forward progress (the three kernels of the papers100M chain: k-hop sampler, dedup count+assign, cache split):
+// tile = blockIdx.x, and a workgroup that has polled a predecessor's descriptor for longer than any healthy launch
+// takes stops waiting and HELPS -- it recomputes the missing tile's aggregate itself (scan_prefix_help: an aggregate is
+// a pure function of the launch's read-only inputs), publishes it on the missing tile's behalf and moves on.  So a
+// resident workgroup always terminates, whatever the dispatch order, however few workgroups are resident and whatever
+// other streams or processes put on the GPU meanwhile; the fast path costs nothing extra.  (Round 1 relied on in-order
+// dispatch per XCD plus a residency cap computed for an idle GPU and flagged the batch after a seconds-long spin.)
+// Tried first and measured: drawing the tile as a start-order TICKET (one atomicAdd per workgroup at entry) gives the
+// same guarantee by construction, but same-address device-scope atomics complete at ~29 ns each on MI355X, i.e. 900
+// tiles serialise for 26 us: layer-0 sampler 50.6 -> 76.8 us, count+assign 10.0 -> 26.9, cache split 16.6 -> 31.5,
+// whole step 0.134 -> 0.198 ms (profiles/r02_ticket_ab.txt).  Tickets remain for hash_dedup_kernel only (<= 350 tiles
+// on a 270 us kernel; its aggregate is the outcome of a rejection loop that a helper could not redo without the LDS
+// the waiting tile's own selections occupy).
+// Spins there stay bounded as a last line of defence: on timeout an error word is set (the batch summary's `overflow`
+// in the batch driver), the prefix is wrong, the kernel terminates.
 struct ScanWs {
   unsigned long long *desc;  // [max_tiles]
   uint32_t *error;           // [1] set to 1 if a spin timed out
   uint32_t gen;              // this launch's generation (1 .. 2^30-1)
   uint32_t max_tiles;
   unsigned long long *log;   // diagnostics (fgnn_debug_phase_log): [tile][8] wall-clock stamps per phase, or null
-  uint32_t *ticket;          // [1] running ticket counter (null: tile = blockIdx.x, for kernels that wait on nobody)
+  uint32_t *ticket;          // [1] running ticket counter (null: tile = blockIdx.x)
   uint32_t ticket_base;      // counter value when this launch draws its first ticket
+  uint32_t help_after;       // scan_prefix_help: polls of one descriptor before the waiter starts helping
+  unsigned long long *helps; // diagnostics: aggregates recomputed by helpers, process-wide (fgnn_debug_scan_helps), or null
 };
 
-// tile of this workgroup = order in which it started among the workgroups of its launch.  EVERY workgroup of the
-// grid must call this exactly once, before any early exit (the host advances the base by the grid size).
-// `sh` = one LDS word; contains two barriers.
+// tile of this workgroup = order in which it started among the workgroups of its launch (w.ticket != null), so that it
+// only ever waits for workgroups that are already running.  EVERY workgroup of the grid must call this exactly once,
+// before any early exit (the host advances the base by the grid size).  The counter is never reset: launches that share
+// descriptors are stream-ordered and the host knows every grid size, so launch i's tickets are
+// [base_i, base_i + grid_i) modulo 2^32.  `sh` = one LDS word; contains two barriers.
 __device__ __forceinline__ uint32_t scan_take_tile(const ScanWs &w, uint32_t *sh) {
   if (!w.ticket) return blockIdx.x;
   if (threadIdx.x == 0)
@@ -348,6 +360,7 @@ __device__ __forceinline__ void phase_mark(const ScanWs &w, uint32_t tile, int p
   if (w.log && threadIdx.x == 0 && tile < kPhaseLogTiles) w.log[(size_t)tile * 8 + phase] = wall_clock64();
 }
 unsigned long long *phase_log_base();  // capi.hip
+unsigned long long *scan_help_counter();  // capi.hip: device word counting helped tiles (allocated on first use)
 // Where a timed-out cross-workgroup wait is reported for launches made by this host thread: the batch driver points
 // it at the batch summary's `overflow` word (so the host sees it with the batch), otherwise the descriptors' own word.
 uint32_t *&scan_error_sink();           // capi.hip (thread-local)
@@ -410,6 +423,95 @@ __device__ __forceinline__ uint32_t scan_lookback(const ScanWs &w, uint32_t tile
   return scan_prefix(w, tile, sh);
 }
 
+// polls of one descriptor before a waiter starts helping: ~1 us per poll (load round trip + sleep) -- an order of
+// magnitude above the longest wait of a healthy launch (predecessors publish within microseconds of starting), so the
+// helping path only runs when predecessors are not resident
+constexpr uint32_t kScanHelpAfterPolls = 192;
+
+__device__ __forceinline__ bool scan_desc_ready(const ScanWs &w, uint32_t j, uint32_t *value) {
+  const unsigned long long word = __hip_atomic_load(&w.desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t tag = (uint32_t)(word >> 32);
+  *value = (uint32_t)word;
+  return (tag >> 2) == w.gen && (tag & 3u) != 0;
+}
+
+// scan_prefix that cannot starve.  `agg(m)` recomputes the aggregate of tile m: called by ALL threads of the workgroup
+// together (it may contain barriers), returns the value to every thread, must not disturb LDS the caller still needs,
+// and must be a pure function of inputs that do not change while the kernel runs -- or of inputs that only change
+// AFTER tile m has published (then `acquire_recheck` makes the published value win, see ht_count_assign_kernel).
+// `sh` = two LDS words.  Fast path (every predecessor publishes within the poll budget): identical to scan_prefix.
+template <typename AggFn>
+__device__ __forceinline__ uint32_t scan_prefix_help(const ScanWs &w, uint32_t tile, uint32_t *sh, AggFn agg,
+                                                     bool acquire_recheck = false) {
+  if (threadIdx.x == 0) {
+    sh[0] = 0;
+    sh[1] = 0;
+  }
+  __syncthreads();
+  uint32_t part = 0;
+  bool gave_up = false;
+  for (uint32_t j = threadIdx.x; j < tile && !gave_up; j += blockDim.x) {
+    uint32_t spins = 0, v;
+    for (;;) {
+      if (scan_desc_ready(w, j, &v)) {
+        part += v;
+        break;
+      }
+      if (++spins > w.help_after) {
+        gave_up = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (gave_up) sh[1] = 1u;  // benign race: every writer stores 1
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, kWave);
+  if (lane_id() == 0 && part) atomicAdd(&sh[0], part);
+  __syncthreads();
+  uint32_t r = sh[0];
+  const bool help = sh[1] != 0;
+  __syncthreads();
+  if (!help) return r;
+  // ---- helping path (rare): start over; whatever is published is taken, whatever is not is recomputed here --------
+  __shared__ uint32_t s_missing[256];
+  __shared__ uint32_t s_nmiss, s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  part = 0;
+  for (uint32_t base = 0; base < tile; base += 256) {
+    if (threadIdx.x == 0) s_nmiss = 0;
+    __syncthreads();
+    const uint32_t j = base + threadIdx.x;
+    if (threadIdx.x < 256 && j < tile) {
+      uint32_t v;
+      if (scan_desc_ready(w, j, &v)) part += v;
+      else s_missing[atomicAdd(&s_nmiss, 1u)] = j;
+    }
+    __syncthreads();
+    const uint32_t nm = s_nmiss;
+    for (uint32_t q = 0; q < nm; ++q) {
+      const uint32_t m = s_missing[q];  // uniform across the workgroup
+      uint32_t a = agg(m);
+      if (threadIdx.x == 0) {
+        uint32_t v;
+        if (acquire_recheck) __atomic_thread_fence(__ATOMIC_ACQUIRE);  // inputs read above, descriptor read below
+        if (scan_desc_ready(w, m, &v)) a = v;                // the tile itself got there meanwhile: its word rules
+        else scan_publish(w, m, kScanAggregate, a);          // same value the tile will store: spares other waiters
+        part += a;
+        if (w.helps) atomicAdd(w.helps, 1ull);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, kWave);
+  if (lane_id() == 0 && part) atomicAdd(&s_sum, part);
+  __syncthreads();
+  r = s_sum;
+  __syncthreads();
+  return r;
+}
+
 __device__ __forceinline__ size_t resolve_count(size_t n_host, const uint32_t *d_n, size_t cap) {
   size_t n = d_n ? (size_t)(*d_n) : n_host;
   return n < cap ? n : cap;
@@ -445,13 +547,15 @@ inline int device_cu_count() {
 
 // host side of ScanWs: owns the descriptors and hands out generations
 struct ScanWsHost {
-  ScanWs ws{nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+  ScanWs ws{nullptr, nullptr, 0, 0, nullptr, nullptr, 0, kScanHelpAfterPolls, nullptr};
   int create(size_t max_tiles);
   void destroy();
   // descriptor view for the next launch of `grid` workgroups (all of which call scan_take_tile)
   // kind: which kernel family the launch belongs to (0 sampler, 1 dedup count+assign, 2 cache split) -- selects
   // the section of the diagnostic phase log
-  ScanWs next(uint32_t kind, size_t grid) {
+  // use_ticket: the kernel draws its tiles with scan_take_tile (hash_dedup_kernel); otherwise tile = blockIdx.x and
+  // waiters help (scan_prefix_help)
+  ScanWs next(uint32_t kind, size_t grid, bool use_ticket = false) {
     if (ws.gen >= 0x3FFFFFFEu) {
       // generations are about to repeat (once per 2^30 launches): descriptors stamped during the previous cycle
       // must not read as fresh, so start the new cycle from zeroed descriptors, fenced against everything in flight
@@ -462,7 +566,14 @@ struct ScanWsHost {
     }
     ws.gen += 1u;
     ScanWs v = ws;
-    ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
+    // FGNN_SCAN_TICKETS=1: tickets in every single-pass kernel (the A/B of profiles/r02_ticket_ab.txt)
+    static const bool all_tickets = [] { const char *e = getenv("FGNN_SCAN_TICKETS"); return e && atoi(e) != 0; }();
+    // FGNN_SCAN_HELP_AFTER=<polls>: 0 makes every wait that is not satisfied at once take the helping path (tests)
+    static const int help_after = [] { const char *e = getenv("FGNN_SCAN_HELP_AFTER"); return e ? atoi(e) : -1; }();
+    if (help_after >= 0) v.help_after = (uint32_t)help_after;
+    v.helps = scan_help_counter();
+    if (use_ticket || all_tickets) ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
+    else v.ticket = nullptr;
     if (uint32_t *sink = scan_error_sink()) v.error = sink;
     unsigned long long *log = phase_log_base();
     v.log = log ? log + (size_t)(kind % kPhaseLogKinds) * kPhaseLogTiles * 8 : nullptr;

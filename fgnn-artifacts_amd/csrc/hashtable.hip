@@ -212,60 +212,80 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
   // disp != null (implies final_fill): pos[] holds the OUTCOMES of a resolving insert (fgnn_device.h), not buckets --
   // the value the bucket read below would have returned, up to take-overs noted in disp[]: no table access at all
   __shared__ uint32_t sh[kWavesPerBlock];
-  __shared__ uint32_t sh_tile;
+  __shared__ uint32_t sh_tile[2];
   const uint32_t n = (uint32_t)resolve_count64(n_host, d_n, cap);  // cap < 2^31 (host check)
   const uint32_t per_round = kBlock * gridDim.x;
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
-  const uint32_t tile = scan_take_tile(scan, &sh_tile);
+  const uint32_t tile = scan_take_tile(scan, sh_tile);
   if (tile >= ntiles) return;  // whole workgroup; nobody looks back at an unused tile
   phase_mark(scan, tile, 0);
   const uint32_t old = d_num_items[1];
-  const size_t chunk0 = (size_t)tile * chunk;
-  uint32_t owner_mask = 0, cnt = 0;
-  // four rounds at a time: their loads are independent, keep them all in flight
-  for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
-    uint32_t bk[4], v[4];
-    bool ok[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
-      ok[u] = r0 + u < rounds && i < n;
-      bk[u] = ok[u] ? pos[i] : kNoBucket;
-    }
-    if (disp) {
+  // owners among the items of tile `tl` (bit r of *mask: this thread's item of round r is one).  own = true: this
+  // workgroup's tile -- the remap entries of non-owners are written on the way.  own = false: another tile's count,
+  // recomputed by a waiter that helps (scan_prefix_help): same reads, no writes.
+  auto count_chunk = [&](uint32_t tl, bool own, uint32_t *mask) -> uint32_t {
+    const size_t c0 = (size_t)tl * chunk;
+    uint32_t om = 0, cn = 0;
+    // four rounds at a time: their loads are independent, keep them all in flight
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 4) {
+      uint32_t bk[4], v[4];
+      bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
-        v[u] = ok[u] ? bk[u] : FGNN_EMPTY_KEY;
-        if (ok[u] && v[u] == (t.pend | (uint32_t)i)) {  // held the key when it inserted: still?
-          const uint32_t note = disp[i] ^ t.gen_base;   // this generation's note: pend|item that took the key over
-          if ((note >> t.vp1) == 0u && (note & t.pend)) v[u] = note;
-        }
-        bk[u] = 0;  // "has a bucket"
+        const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+        ok[u] = r0 + u < rounds && i < n;
+        bk[u] = ok[u] ? pos[i] : kNoBucket;
       }
-    } else {
+      if (disp) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
-    }
+        for (int u = 0; u < 4; ++u) {
+          const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+          v[u] = ok[u] ? bk[u] : FGNN_EMPTY_KEY;
+          if (ok[u] && v[u] == (t.pend | (uint32_t)i)) {  // held the key when it inserted: still?
+            const uint32_t note = disp[i] ^ t.gen_base;   // this generation's note: pend|item that took the key over
+            if ((note >> t.vp1) == 0u && (note & t.pend)) v[u] = note;
+          }
+          bk[u] = 0;  // "has a bucket"
+        }
+      } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (ok[u]) {
-        const size_t i = chunk0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
-        if (bk[u] != kNoBucket && v[u] == (t.pend | (uint32_t)i)) {
-          owner_mask |= 1u << (r0 + u);
-          ++cnt;
-        } else if (mapped) {
-          mapped[i] = v[u];  // final local id, or pend|owner (fixed up later), or EMPTY (no bucket)
+        for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+          if (bk[u] != kNoBucket && v[u] == (t.pend | (uint32_t)i)) {
+            om |= 1u << (r0 + u);
+            ++cn;
+          } else if (own && mapped) {
+            mapped[i] = v[u];  // final local id, or pend|owner (fixed up later), or EMPTY (no bucket)
+          }
         }
       }
     }
-  }
+    *mask = om;
+    return cn;
+  };
+  const size_t chunk0 = (size_t)tile * chunk;
+  uint32_t owner_mask = 0;
+  const uint32_t cnt = count_chunk(tile, true, &owner_mask);
   uint32_t tot;
   (void)block_exclusive_scan<kWavesPerBlock>(cnt, sh, &tot);
   phase_mark(scan, tile, 1);
-  const uint32_t before = scan_lookback(scan, tile, tot, &sh_tile);
+  scan_publish_aggregate(scan, tile, tot);
+  // Buckets of this tile's owners change (pend|i -> local id) further down, i.e. only after the aggregate has been
+  // published: a helper that recounts this tile either still sees the pending values or -- release here, acquire +
+  // descriptor re-check there -- finds the published word and takes that
+  if (!final_fill && threadIdx.x == 0) __atomic_thread_fence(__ATOMIC_RELEASE);
+  const uint32_t before = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+    uint32_t mask_m, tot_m;
+    const uint32_t cm = count_chunk(m, false, &mask_m);
+    (void)block_exclusive_scan<kWavesPerBlock>(cm, sh, &tot_m);
+    return tot_m;
+  }, /*acquire_recheck=*/!final_fill);
   phase_mark(scan, tile, 2);
   if (tile == ntiles - 1 && threadIdx.x == 0) {
     const uint32_t now = old + before + tot;

@@ -113,7 +113,7 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
   const uint32_t tag = ((uint32_t)FGNN_WEIGHTED_KHOP_HASH_DEDUP << 8) | (layer & 0xffu);
   const size_t lds = (size_t)F * kBlock * sizeof(uint32_t);
   const size_t nb = div_up(cap, (size_t)kBlock);
-  ScanWs scan{nullptr, nullptr, 0, 0, nullptr};
+  ScanWs scan{nullptr, nullptr, 0, 0, nullptr, nullptr, 0, kScanHelpAfterPolls, nullptr};
   uint32_t *sums = nullptr;
   int mode = 0;
   if (nb > kMaxScanTiles) {
@@ -121,7 +121,7 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
     sums = static_cast<uint32_t *>(ws);
     mode = 1;
   } else if (scan_host && nb <= scan_host->ws.max_tiles) {
-    scan = scan_host->next(0, nb);
+    scan = scan_host->next(0, nb, /*use_ticket=*/true);
   } else {
     // stateless entry point: descriptors and ticket counter in the caller's scratch, zeroed, generation 1
     if (ws_bytes < (nb + 1) * sizeof(unsigned long long)) return FGNN_ENOSPC;

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   // single-pass mode (scan.desc != null): the output offset comes from the prefix over the earlier workgroups'
   // edge counts -- no count kernel, no scan kernel
   const bool single_pass = scan.desc != nullptr;
-  __shared__ uint32_t sh_tile;
-  const uint32_t tile = scan_take_tile(scan, &sh_tile);  // start order, not blockIdx.x (fgnn_device.h)
+  __shared__ uint32_t sh_tile[2];
+  const uint32_t tile = scan_take_tile(scan, sh_tile);  // blockIdx.x unless the ticket A/B switch is on
   const size_t first = (size_t)tile * S;
   const uint32_t last_tile = n ? (uint32_t)((n - 1) / S) : 0u;  // tiles beyond it have no seeds and nobody waits for them
   if (tile > last_tile) return;  // whole workgroup exits together
@@ -273,7 +273,20 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
   size_t base;
   if (single_pass) {
-    base = scan_prefix(scan, tile, &sh_tile);
+    // a waiter that outlasts the poll budget recomputes a missing tile's edge count itself (forward progress without
+    // assumptions about dispatch, fgnn_device.h): min(deg, F) over the tile's seeds, from immutable inputs
+    base = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+      uint32_t cm = 0;
+      const size_t im = (size_t)m * S + tid;
+      if (tid < S && im < n) {
+        const uint32_t r = input[im];
+        const uint32_t l = indptr[r + 1] - indptr[r];
+        cm = l < F ? l : F;
+      }
+      uint32_t tot_m;
+      (void)block_exclusive_scan<NW>(cm, sh_scan, &tot_m);
+      return tot_m;
+    });
     phase_mark(scan, tile, 2);
     if (tile == last_tile && tid == 0 && d_num_out) *d_num_out = base + total;
   } else {
@@ -400,7 +413,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     return FGNN_ENOSPC;
   }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
-  ScanWs scan{nullptr, nullptr, 0, 0, nullptr};
+  ScanWs scan{nullptr, nullptr, 0, 0, nullptr, nullptr, 0, kScanHelpAfterPolls, nullptr};
   bool want_scan = scan_host && nb <= scan_host->ws.max_tiles;
 
 #define FGNN_LAUNCH_KHOP2(SS, FM)                                                                              \
@@ -412,8 +425,8 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
       attr_done = true;                                                                                        \
     }                                                                                                          \
     /* single pass (no count kernel, no scan kernel) for grids of up to 1536 workgroups (every tile sums all its    */ \
-    /* predecessors' aggregates: O(tiles^2) descriptor reads); tiles are start-order tickets, so a workgroup only   */ \
-    /* waits for workgroups that are already running                                                               */ \
+    /* predecessors' aggregates: O(tiles^2) descriptor reads); a waiter that outlasts its poll budget recomputes    */ \
+    /* the missing aggregates itself, so residency and dispatch order are not assumed                              */ \
     if (want_scan && nb <= 1536) scan = scan_host->next(0, nb);                                            \
     if (!scan.desc) {                                                                                          \
       scan.log = phase_log_base();                                                                             \

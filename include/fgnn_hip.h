@@ -55,6 +55,9 @@ void fgnn_debug_phase_log(unsigned long long *d_buf);
 /* Diagnostics (tests/test_coresidency_gpu.py): a foreign tenant -- `workgroups` x 256 threads that keep their wave
  * slots for `usec` microseconds (<= 2 s) on `stream` and do nothing else. */
 int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream);
+/* Diagnostics: how many tile aggregates of the single-pass kernels were recomputed by a waiting workgroup instead of
+ * being read from the tile itself (current device, since the process started; synchronises).  0 on an idle GPU. */
+unsigned long long fgnn_debug_scan_helps(void);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);

@@ -12,14 +12,18 @@
  * Supported run architectures (RunArch, common.h:70-79): arch1 (one GPU samples and extracts,
  * cuda/cuda_loops_arch1.cc), arch2 / arch3 / arch4 (one process, sampler context + trainer context, optional
  * background threads via samgraph_start; arch3 is the default of the reference's single-process scripts;
- * cuda/cuda_loops_arch{2,3,4}.cc -- without arch4's dynamic-cache prototype), arch5 (FGNN: sampler processes +
+ * cuda/cuda_loops_arch{2,3,4}.cc -- including arch4's dynamic-cache prototype, DoGPUSampleDyCache +
+ * DoDynamicCacheFeatureCopy, selected by _cache_policy = dynamic_cache), arch5 (FGNN: sampler processes +
  * trainer processes linked by the pinned host queue, dist/dist_engine.cc, dist/dist_loops_arch5.cc), arch6 (the
  * reference's SGNN baseline: samgraph_data_init in the parent, samgraph_sample_init + samgraph_train_init in every
  * worker process, each worker samples and extracts its equal share of the train set, dist/dist_loops_arch6.cc,
  * dist/dist_shuffler_aligned.cc) and arch7 (a sample-only engine per worker: samgraph_config with worker_id /
  * num_worker + samgraph_init in every worker, cuda/cuda_loops_arch7.cc).  Sample types: all seven (khop0,
- * khop1, khop2, weighted_khop, weighted_khop_hash_dedup, weighted_khop_prefix, random_walk).  Cache policies: pre_sample (computed at sample_init,
- * dist/pre_sampler.cc) and the file-backed rankings (cache_by_*.bin, engine.cc:216-256).
+ * khop1, khop2, weighted_khop, weighted_khop_hash_dedup, weighted_khop_prefix, random_walk).  Cache policies: every
+ * _cache_policy value of the reference -- pre_sample (computed at sample_init, dist/pre_sampler.cc), presample_static
+ * (whole-neighbourhood frequencies, cuda/pre_sampler.cc:69-71; refused by the multi-process engine like
+ * dist/pre_sampler.cc:87-88), dynamic_cache (arch4) and the file-backed rankings (cache_by_*.bin, engine.cc:216-256).
+ * SAMGRAPH_SANITY_CHECK=1 checks every batch of seeds on the GPU (cuda/cuda_sanity_check.cu:28-88).
  */
 #ifndef SAMGRAPH_H
 #define SAMGRAPH_H
@@ -91,7 +95,12 @@ int samgraph_wait_one_child(void);                           /* operation.h:108 
  * The reference exposes these through pybind11 as torch tensors built with torch::from_blob
  * (samgraph/torch/adapter.h:29-42, adapter.cc:48-192).  Here they are plain C: a device (or host)
  * pointer plus element count, which samgraph/torch/adapter.py wraps without copying.  All check
- * key == current batch key (adapter.cc:52) and abort on mismatch. */
+ * key == current batch key (adapter.cc:52) and abort on mismatch.
+ * The library is ALSO the Python extension module the reference's adapter.py imports (`from samgraph.torch import c_lib`,
+ * adapter.py:26): PyInit_c_lib (csrc/engine/eng_pymodule.cc) registers samgraph_torch_get_graph_feat(key), ..._label,
+ * ..._row(key, layer), ..._col, ..._data, ..._get_dataset_feat(), ..._get_dataset_label(), ..._graph_input_nodes(key),
+ * ..._graph_output_nodes(key) -- the names of adapter.cc:177-189 -- as zero-copy wrappers over the getters below,
+ * without linking libpython or libtorch (the entry points are resolved with dlsym when an interpreter imports it). */
 const void *samgraph_torch_get_graph_feat_ptr(uint64_t key, size_t *num_rows, size_t *dim, int *dtype, int *device);
 const void *samgraph_torch_get_graph_label_ptr(uint64_t key, size_t *num, int *dtype, int *device);
 const uint32_t *samgraph_torch_get_graph_row_ptr(uint64_t key, int layer, size_t *num, int *device);

@@ -164,6 +164,28 @@ def check_batch(sam, key, seeds, task, rep, what="", with_feat=True):
     inp = sam.get_graph_input_nodes(key)
     if inp.numel():
         np.testing.assert_array_equal(u32(inp), task["input_nodes"], err_msg=what)
+    # the reference's own getter names (the pybind module of adapter.cc:48-192, `from samgraph.torch import c_lib`):
+    # same memory as the ctypes path above, no copy
+    from samgraph.torch import c_lib
+    import torch
+    for li in range(nl):
+        for name, mine in (("row", sam.get_graph_row), ("col", sam.get_graph_col)):
+            a, b = getattr(c_lib, "samgraph_torch_get_graph_" + name)(key, li), mine(key, li)
+            assert a.dtype == torch.int32 and a.device == b.device and a.shape == b.shape, (what, name)
+            assert a.numel() == 0 or (a.data_ptr() == b.data_ptr() and torch.equal(a, b)), (what, name)
+        if task["graphs"][li]["data"] is not None:
+            np.testing.assert_array_equal(u32(c_lib.samgraph_torch_get_graph_data(key, li)), task["graphs"][li]["data"])
+    np.testing.assert_array_equal(u32(c_lib.samgraph_torch_get_graph_output_nodes(key)), seeds, err_msg=what)
+    if inp.numel():
+        assert c_lib.samgraph_torch_get_graph_input_nodes(key).data_ptr() == inp.data_ptr()
+    if with_feat:
+        f2, l2 = c_lib.samgraph_torch_get_graph_feat(key), c_lib.samgraph_torch_get_graph_label(key)
+        assert f2.dtype == torch.float32 and tuple(f2.shape) == tuple(feat.shape) and f2.data_ptr() == feat.data_ptr()
+        assert l2.dtype == torch.int64 and torch.equal(l2, label)
+    else:
+        df, dl = c_lib.samgraph_torch_get_dataset_feat(), c_lib.samgraph_torch_get_dataset_label()
+        assert df.device.type == "cpu" and tuple(df.shape) == (NUM_NODE, DIM) and dl.dtype == torch.int64
+        assert df.data_ptr() == sam.get_dataset_feat().data_ptr() and torch.equal(dl, sam.get_dataset_label())
 
 
 def run_arch1(sample_type, workdir):

@@ -72,3 +72,53 @@ def test_product_never_imports_oracle():
                              txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+ENGINE_LIB = os.path.join(ROOT, "fgnn-artifacts_amd", "samgraph", "torch", "c_lib.so")
+
+
+def test_engine_library_is_also_the_reference_named_python_module():
+    """The reference's c_lib is ONE shared object: the samgraph_* C ABI for ctypes plus a Python module with the nine
+    tensor getters (samgraph/torch/adapter.cc:177-189, imported by adapter.py:26).  Same here -- and without making the
+    C-ABI library depend on libpython: no undefined Py* symbol, the CPython entry points are looked up when the
+    interpreter calls PyInit_c_lib."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+    from samgraph.torch import c_lib
+    want = ["samgraph_torch_get_graph_feat", "samgraph_torch_get_graph_label", "samgraph_torch_get_graph_row",
+            "samgraph_torch_get_graph_col", "samgraph_torch_get_graph_data", "samgraph_torch_get_dataset_feat",
+            "samgraph_torch_get_dataset_label", "samgraph_torch_get_graph_input_nodes",
+            "samgraph_torch_get_graph_output_nodes"]
+    assert all(callable(getattr(c_lib, n, None)) for n in want)
+    assert os.path.samefile(c_lib.__file__, ENGINE_LIB)
+    undefined = subprocess.run(["nm", "-D", "-u", ENGINE_LIB], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\b_?Py[A-Z_]", undefined), undefined
+    # the zero-copy host wrapper used by get_dataset_feat / get_dataset_label
+    import numpy as np
+    a = np.arange(12, dtype=np.float32)
+    t = c_lib._wrap(a.ctypes.data, 3, 4, 0, -1)
+    assert t.shape == (3, 4) and t.data_ptr() == a.ctypes.data and float(t[2, 3]) == 11.0
+    assert c_lib._wrap(0, 0, -1, 6, -1).shape == (0,)
+
+
+def test_engine_library_loads_into_a_plain_c_host(tmp_path):
+    """a C program (no Python in the process) dlopen()s c_lib.so with RTLD_NOW and finds the boundary's entry points"""
+    src = tmp_path / "host.c"
+    src.write_text("""
+#include <dlfcn.h>
+#include <stdio.h>
+int main(int argc, char **argv) {
+  void *h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "%s\\n", dlerror()); return 1; }
+  const char *names[] = {"samgraph_config", "samgraph_init", "samgraph_get_next_batch", "samgraph_sample_once",
+                         "samgraph_torch_get_graph_feat_ptr", "PyInit_c_lib"};
+  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]); ++i)
+    if (!dlsym(h, names[i])) { fprintf(stderr, "missing %s\\n", names[i]); return 2; }
+  puts("ok");
+  return 0;
+}
+""")
+    exe = tmp_path / "host"
+    subprocess.check_call(["gcc", "-O0", "-o", str(exe), str(src), "-ldl"])
+    p = subprocess.run([str(exe), ENGINE_LIB], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr
