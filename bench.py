@@ -167,14 +167,18 @@ def local_step_range(steps_per_epoch, rank, world):
 
 
 def pmc_traffic():
-    """HBM bytes / algorithmic bytes per kernel from the committed rocprofv3 PMC passes of this round
-    (profiles/r02_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, separate
-    --pmc passes of this command); falls back to round 1's file.  Returns (gather ratio or None, per-kernel dict)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    """HBM bytes / algorithmic bytes from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json,
+    written by tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, separate
+    --pmc passes of this command).  Returns (gather ratio or None, per-stage dict with every kernel family's
+    traffic_over_algorithmic or None, file name)."""
+    import glob
+    names = sorted((os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))),
+                   reverse=True)  # newest round / tag first
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            return d.get("traffic_over_algorithmic"), d.get("per_kernel"), name
+            return d.get("traffic_over_algorithmic"), d.get("per_stage") or d.get("per_kernel"), name
         except Exception:
             continue
     return None, None, None
@@ -196,7 +200,7 @@ def algorithmic_bytes(metas, feat_dim, batch_size):
     return dict(sample=sample, dedup_remap=dedup, cache_split=split, gather=gather)
 
 
-def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="khop2"):
+def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="khop2", cands=None):
     """The reference's CPU sampling path (CPUSampleKHop0/2 + CPUHashTable2 + CPUExtract driven as DoCPUSample /
     DoFeatureExtract, cpu/cpu_loops.cc:55-227) timed on this host on a bounded number of batches of the same
     workload, multi-threaded (OpenMP, a few thread counts) and single-threaded.  kind "reference": the reference's own
@@ -221,6 +225,8 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="kh
     # EPYC 9575F), so a few counts are tried and the best is reported
     if "FGNN_CPU_BASELINE_THREADS" in os.environ:
         cands = [int(os.environ["FGNN_CPU_BASELINE_THREADS"])]
+    elif cands:
+        cands = sorted({min(t, os.cpu_count() or 1) for t in cands})
     else:
         cands = sorted({t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)} or {1})
     use_ref = oracle.RefBaseline.available()
@@ -279,6 +285,30 @@ def cpu_baseline(w, indptr, indices, feat, train, budget_s=12.0, sample_type="kh
         "all_runs": res,
         "host_cpus": os.cpu_count(),
     }
+
+
+def cpu_baseline_products(dev, budget_s=5.0):
+    """BASELINE.json config 1 as a recorded number: the reference's arch0 path (CPU sample + CPU extract,
+    cpu/cpu_loops.cc:55-227 -- here the reference's own CPU sources in oracle/_ref, never the product) on the
+    ogbn-products shape, 2-layer GraphSAGE fanout 10/5 (example/samgraph/train_graphsage.py with --fanout 5 10).  The
+    graph is the same R-MAT generator at the products shape, built on `dev` (the GPU when there is one)."""
+    from fgnn_hip import rmat
+    w = dict(**synth.DATASET_SHAPES["products"], fanout=[10, 5], batch_size=8000)
+    t0 = time.time()
+    indptr, indices, _ = rmat.rmat_csr(w["num_node"], w["num_edge"], 42, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    feat = torch.rand((1 << 21, w["feat_dim"]), generator=g, device=dev, dtype=torch.float32)  # masked: 2^21 rows
+    train = rmat.train_set(w["num_node"], w["num_train"], 1, dev)
+    gen_s = time.time() - t0
+    r = cpu_baseline(w, indptr, indices, feat, train, budget_s=budget_s, cands=[16])
+    r["config"] = ("BASELINE.json configs[0]: ogbn-products-shaped R-MAT graph (N=%d, E=%d, feat f32[.,%d]), 2-layer "
+                   "GraphSAGE fanout 10/5, batch 8000, CPU sample + CPU extract (arch0), graph generated in %.1fs on %s"
+                   % (w["num_node"], w["num_edge"], w["feat_dim"], gen_s, dev))
+    best = r["all_runs"].get("omp%d" % r["cores"]) or r["all_runs"]["single"]
+    steps_per_epoch = (w["num_train"] + w["batch_size"] - 1) // w["batch_size"]
+    r["epoch_time_s"] = best["seconds"] / max(best["batches"], 1) * steps_per_epoch  # sample + extract, no training
+    return r
 
 
 def cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train, budget_s=12.0):
@@ -610,6 +640,14 @@ def run_single(args):
             out["cpu_baseline"] = cpu_baseline(w, indptr, indices, feat, train, sample_type=args.sample_type)
         else:
             out["cpu_baseline"] = cpu_baseline_generic(w, args, indptr, indices, prefix, feat, train)
+        if args.workload == "papers100M":
+            # every BASELINE.json config has a recorded line: configs[0] is the reference's CPU-runnable case
+            del indptr, indices, feat, label, table, sampler, batches
+            torch.cuda.empty_cache()
+            try:
+                out["cpu_baseline_products"] = cpu_baseline_products(dev)
+            except Exception as e:
+                out["cpu_baseline_products"] = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps(out), flush=True)
 
 
@@ -1155,11 +1193,21 @@ def parse_args(argv=None):
                     help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
                          "multi_gpu/train_graphsage.py:75)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="BASELINE.json configs[0] only: the reference's CPU path (oracle/_ref) on the products shape, "
+                         "fanout 10/5; needs no GPU and measures nothing of the product")
     return ap.parse_args(argv)
 
 
 def main():
     args = parse_args()
+    if args.cpu_only:
+        dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+        r = cpu_baseline_products(dev, budget_s=10.0)
+        print(json.dumps({"metric": "sampled-edges/sec (reference CPU path, products fanout 10/5)", "value": r["value"],
+                          "unit": "edges/s", "n_gpus": 0, "higher_is_better": True, "data": "synthetic", "dtype": "u32",
+                          "config": {"workload": r["config"]}, "cpu_baseline": r}), flush=True)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
         if args.gpus > 1:

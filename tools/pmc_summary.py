@@ -46,4 +46,29 @@ if len(sys.argv) > 3:
     out["traffic_over_algorithmic"] = hbm / alg
 out["all_kernels_KB_per_launch"] = {k: {"launches": fetch[k][1], "FETCH_SIZE": fetch[k][0],
                                         "WRITE_SIZE": write.get(k, (0, 0))[0]} for k in sorted(fetch)}
+# every kernel of the chain against the algorithmic bytes of the stage it implements (SURVEY.md 8(d) figures as
+# bench.algorithmic_bytes computes them, per batch): the sampler launches carry the dedup's insert, so sampling and
+# dedup/remap are one stage here.  FETCH_SIZE is doubled only for the wide coalesced reads of the row gather; the
+# random 4/8-byte reads of the other kernels are 64-B requests and count as reported.
+STAGES = {"sample_dedup_remap": ("khop_sample_kernel", "ht_count_assign_kernel", "ht_map_fix_kernel", "ht_insert_kernel",
+                                 "weighted_", "rank_", "hash_dedup_kernel", "random_walk_topk_kernel", "rw_emit_kernel"),
+          "cache_split": ("cache_split_fused_kernel", "cache_count_kernel", "cache_split_kernel"),
+          "gather": ("gather_rows16_kernel", "gather_rows_elem_kernel")}
+if len(sys.argv) > 3:
+    batches = fetch[gk][1]
+    ab = j.get("algorithmic_bytes_per_step", {})
+    alg = {"sample_dedup_remap": ab.get("sample", 0) + ab.get("dedup_remap", 0), "cache_split": ab.get("cache_split", 0),
+           "gather": ab.get("gather", 0)}
+    per_kernel, per_stage = {}, {}
+    for k in sorted(fetch):
+        wide = 2.0 if k.startswith("gather_rows16_kernel") else 1.0
+        b = (wide * fetch[k][0] + write.get(k, (0, 0))[0]) * 1024.0 * fetch[k][1] / batches
+        stage = next((s for s, pre in STAGES.items() if k.startswith(pre)), None)
+        per_kernel[k] = {"stage": stage, "launches_per_batch": fetch[k][1] / batches, "hbm_bytes_per_batch": b}
+        if stage:
+            per_stage.setdefault(stage, 0.0)
+            per_stage[stage] += b
+    out["per_kernel"] = per_kernel
+    out["per_stage"] = {s: {"hbm_bytes_per_batch": v, "algorithmic_bytes_per_batch": alg[s],
+                            "traffic_over_algorithmic": v / alg[s] if alg[s] else None} for s, v in per_stage.items()}
 print(json.dumps(out, indent=1))
