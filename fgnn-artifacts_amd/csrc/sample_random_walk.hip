@@ -7,8 +7,9 @@
 // counts are broken by first visit position (a legal outcome of the reference's CAS race).
 //
 // MI355X design: a seed's whole multiset of visits is tiny (num_walks * walk_len <= a few hundred
-// entries), so the frequency count and the top-K selection never leave the CU: one wavefront owns one
-// seed, lanes walk in parallel (lane = walk), the visited ids go to LDS, each lane then ranks one
+// entries), so the frequency count and the top-K selection never leave the CU: a group of W lanes of a
+// wavefront owns one seed (W = num_walks rounded up to a power of two: 16 seeds per wave at 4 walks, 2 at 25,
+// one at > 32), lanes walk in parallel (lane = walk), the visited ids go to LDS, each lane then ranks one
 // visit entry against the others by broadcast LDS reads -- no global hash table, no sort, no
 // atomics, no reset pass.  Edge offsets come from per-seed counts + one scan; the padded top-K
 // records are compacted by a second small kernel.
@@ -17,32 +18,40 @@
 namespace fgnn {
 namespace {
 
-constexpr int kRwWaves = 4;  // seeds per workgroup (one wave each)
+constexpr int kRwWaves = 4;  // waves per workgroup
 
 __device__ __forceinline__ double uniform_double(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
 
-// Dynamic LDS: kRwWaves * 2P words (P = num_walks * walk_len): visited ids + representative counts.
+// lanes a seed gets: the smallest power of two >= num_walks (64 when num_walks is larger: lanes then loop over walks)
+inline uint32_t rw_group_width(size_t num_walks) {
+  uint32_t w = 1;
+  while (w < num_walks && w < (uint32_t)kWave) w <<= 1;
+  return w;
+}
+
+// A wavefront owns G = 64 / W seeds, W = rw_group_width(num_walks): PinSAGE's reference default of 4 walks per seed
+// (multi_gpu/train_pinsage.py:130-134) puts 16 seeds into a wave instead of idling 60 of its 64 lanes, 25 walks put 2.
+// Dynamic LDS: kRwWaves * G * 2P words (P = num_walks * walk_len): per seed its visited ids + representative counts.
 __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
     const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ input,
     size_t n_host, const uint32_t *d_n, size_t cap, uint32_t walk_len, double restart_prob, uint32_t num_walks,
-    uint32_t K, uint32_t *__restrict__ pad_dst, uint32_t *__restrict__ pad_cnt, uint32_t *__restrict__ seed_cnt,
-    uint64_t seed, uint64_t batch_key, uint32_t tag) {
+    uint32_t K, uint32_t W, uint32_t *__restrict__ pad_dst, uint32_t *__restrict__ pad_cnt,
+    uint32_t *__restrict__ seed_cnt, uint64_t seed, uint64_t batch_key, uint32_t tag) {
   extern __shared__ uint32_t dyn[];
   const uint32_t P = num_walks * walk_len;
-  uint32_t *visited = dyn + (size_t)wave_id() * 2 * P;
+  const uint32_t G = (uint32_t)kWave / W;
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t g = lane / W, sl = lane % W;  // seed of the wave, lane within the seed's group
+  uint32_t *visited = dyn + ((size_t)wave_id() * G + g) * 2 * P;
   uint32_t *repcnt = visited + P;
   const size_t n = resolve_count(n_host, d_n, cap);
-  const size_t i = (size_t)blockIdx.x * kRwWaves + wave_id();
-  if (i >= cap) return;  // wave-uniform
-  if (i >= n) {
-    if (lane_id() == 0) seed_cnt[i] = 0;
-    return;
-  }
-  const uint32_t start = input[i];
-  const int lane = lane_id();
+  const size_t i = ((size_t)blockIdx.x * kRwWaves + wave_id()) * G + g;
+  const bool valid = i < n;
+  const unsigned long long gmask = (W == (uint32_t)kWave ? ~0ull : ((1ull << W) - 1ull)) << (g * W);
+  const uint32_t start = valid ? input[i] : FGNN_EMPTY_KEY;
 
-  // ---- walks: lane = walk (cuda_sampling_random_walk.cu:57-101) ----
-  for (uint32_t walk = lane; walk < num_walks; walk += kWave) {
+  // ---- walks: one lane per walk (cuda_sampling_random_walk.cu:57-101) ----
+  for (uint32_t walk = sl; walk < num_walks; walk += W) {
     uint32_t node = start;
     for (uint32_t step = 0; step < walk_len; ++step) {
       const uint32_t pos = step * num_walks + walk;
@@ -68,11 +77,11 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
 
-  // ---- frequency: lane = visit entry; repcnt[p] = visit count if p is the FIRST visit of its
+  // ---- frequency: one lane per visit entry; repcnt[p] = visit count if p is the FIRST visit of its
   //      destination (its representative), else 0 ----
   uint32_t kept = 0;
-  for (uint32_t p0 = 0; p0 < P; p0 += kWave) {
-    const uint32_t p = p0 + lane;
+  for (uint32_t p0 = 0; p0 < P; p0 += W) {
+    const uint32_t p = p0 + sl;
     uint32_t c = 0;
     if (p < P) {
       const uint32_t me = visited[p];
@@ -87,15 +96,15 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
       }
       repcnt[p] = c;
     }
-    kept += (uint32_t)__popcll(__ballot(c != 0));
+    kept += (uint32_t)__popcll(__ballot(c != 0) & gmask);
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
 
   // ---- top-K: rank of a representative by (count desc, first position asc) ----
-  for (uint32_t p0 = 0; p0 < P; p0 += kWave) {
-    const uint32_t p = p0 + lane;
-    if (p >= P) continue;
+  for (uint32_t p0 = 0; p0 < P; p0 += W) {
+    const uint32_t p = p0 + sl;
+    if (p >= P || !valid) continue;
     const uint32_t count = repcnt[p];
     if (count == 0) continue;
     uint32_t rank = 0;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
       pad_cnt[i * K + rank] = count;
     }
   }
-  if (lane == 0) seed_cnt[i] = kept < K ? kept : K;
+  if (sl == 0 && i < cap) seed_cnt[i] = valid ? (kept < K ? kept : K) : 0u;
 }
 
 __global__ __launch_bounds__(kBlock) void rw_sums_kernel(const uint32_t *__restrict__ seed_cnt, size_t cap,
@@ -164,7 +173,7 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
   size_t cap = d_num_input ? num_input_cap : num_input;
   if (walk_len == 0 || num_walks == 0 || K == 0) return FGNN_EINVAL;
   const size_t P = walk_len * num_walks;
-  if (P > 4096 || K > 0xffff) return FGNN_EINVAL;  // 4 seeds * 2P words of LDS per workgroup
+  if (P > 4096 || K > 0xffff) return FGNN_EINVAL;  // seeds per workgroup * 2P words of LDS (<= 128 KiB)
   if (cap == 0) {
     if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), st));
     return FGNN_OK;
@@ -178,16 +187,19 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
   uint32_t *seed_cnt = pad_cnt + cap * K;
   uint32_t *sums = seed_cnt + cap;
   const size_t nb = div_up(cap, kBlock);
-  const size_t lds = (size_t)kRwWaves * 2 * P * sizeof(uint32_t);
+  uint32_t W = rw_group_width(num_walks);
+  while (W < (uint32_t)kWave && (size_t)kRwWaves * (kWave / W) * 2 * P * sizeof(uint32_t) > 128 * 1024) W <<= 1;  // long walks
+  const size_t seeds_per_wg = (size_t)kRwWaves * (kWave / W);
+  const size_t lds = seeds_per_wg * 2 * P * sizeof(uint32_t);
   static bool attr_done = false;
   if (!attr_done) {
     FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&random_walk_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(random_walk_topk_kernel, dim3(div_up(cap, kRwWaves)), dim3(kRwWaves * kWave), lds, st, indptr,
+  hipLaunchKernelGGL(random_walk_topk_kernel, dim3(div_up(cap, seeds_per_wg)), dim3(kRwWaves * kWave), lds, st, indptr,
                      indices, input, num_input, d_num_input, cap, (uint32_t)walk_len, restart_prob, (uint32_t)num_walks,
-                     (uint32_t)K, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag);
+                     (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag);
   hipLaunchKernelGGL(rw_sums_kernel, dim3(nb), dim3(kBlock), 0, st, seed_cnt, cap, sums);
   if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
   hipLaunchKernelGGL(rw_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, seed_cnt, cap, (uint32_t)K, pad_dst, pad_cnt,

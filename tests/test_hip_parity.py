@@ -338,14 +338,16 @@ def test_weighted_prefix_matches_oracle(hip, oracle, fanout):
 
 
 @pytest.mark.parametrize("walk_len,num_walks,K,restart", [(3, 4, 5, 0.5), (3, 25, 5, 0.5), (2, 70, 3, 0.0),
-                                                          (4, 3, 20, 0.9)])
+                                                          (4, 3, 20, 0.9), (3, 1, 2, 0.3), (5, 32, 8, 0.2),
+                                                          (2, 33, 4, 0.5), (600, 2, 6, 0.01)])
 def test_random_walk_matches_oracle(hip, oracle, walk_len, num_walks, K, restart):
     from fgnn_hip import synth
     num_node = 3000
     indptr, indices = synth.powerlaw_csr(num_node, 40000, seed=33)
     d_indptr, d_indices = dev(indptr), dev(indices)
     rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
-    for call, n in enumerate([1000, 3, 0]):
+    # seed counts that do not fill the last wavefront's seed groups (16 seeds per wave at 4 walks, 2 at 25)
+    for call, n in enumerate([1000, 3, 0, 37]):
         inp = _seeds(n, num_node, seed=50 + call)
         d_inp = dev(inp) if n else torch.empty(0, dtype=torch.int32, device="cuda")
         o = oracle.sample_random_walk(indptr, indices, inp, walk_len, restart, num_walks, K, rng, 3 + call, 1)
