@@ -33,6 +33,8 @@ struct fgnn_sampler {
     hipEvent_t done = nullptr, csr = nullptr;
     bool was_used = false;
     fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
+    uint32_t *rank_bitmap = nullptr;      // with-replacement samplers: seed ranking bitmap over the node ids (all zero
+                                          // between batches), fgnn::RankWs
   } slot[kSlots];
   // host-side sequencing (calls may come from several threads, one per stream): call `seq` may start once
   // call seq - kSlots has returned; for khop2 (which swaps CSR entries in place) the sampler kernels of call
@@ -145,7 +147,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     size_t need = 0;
     if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX || cfg->sample_type == FGNN_KHOP1 ||
         cfg->sample_type == FGNN_WEIGHTED_KHOP)
-      need = fgnn::weighted_scratch_bytes_ex(s->in_cap[l], cfg->fanout[l], cfg->num_node);
+      need = fgnn_weighted_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
@@ -158,6 +160,11 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     for (hipEvent_t *e : {&sl.done, &sl.csr})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     ok = ok && sl.scan_sample.create(s->max_nodes / 64 + 2) == FGNN_OK;
+    if (cfg->num_node && (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX || cfg->sample_type == FGNN_KHOP1 ||
+                          cfg->sample_type == FGNN_WEIGHTED_KHOP)) {
+      const size_t bytes = fgnn::rank_ws_bytes(cfg->num_node);
+      ok = ok && hipMalloc(&sl.rank_bitmap, bytes) == hipSuccess && hipMemset(sl.rank_bitmap, 0, bytes) == hipSuccess;
+    }
     if (!ok) {
       fgnn_sampler_destroy(s);
       return fail(err != FGNN_OK ? err : FGNN_EHIP);
@@ -173,6 +180,7 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
     if (sl.ht) fgnn_hashtable_destroy(sl.ht);
     sl.scan_sample.destroy();
     if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
+    if (sl.rank_bitmap) (void)hipFree(sl.rank_bitmap);
     if (sl.ws) (void)hipFree(sl.ws);
     for (hipEvent_t e : {sl.done, sl.csr})
       if (e) (void)hipEventDestroy(e);
@@ -314,6 +322,13 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   static const bool unordered = [] { const char *e = getenv("FGNN_KHOP2_UNORDERED"); return e && atoi(e) != 0; }();
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
   const bool ordered = mutates && !unordered;
+  // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one (FGNN_KHOP_SPLIT_L0=0: fused).
+  // khop2 rewrites CSR rows, so the sampler kernels of consecutive batches form ONE chain however the batches overlap:
+  // layer-(L-1) sampler -> its dedup -> ... -> layer-0 sampler -> next batch.  The layer-0 launch is the long one, and
+  // half of it is the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's
+  // sampling starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more
+  // launch and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt)
+  static const int split_env = [] { const char *e = getenv("FGNN_KHOP_SPLIT_L0"); return e ? atoi(e) : -1; }();
   {
     // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
     std::unique_lock<std::mutex> lk(s->mu);
@@ -358,19 +373,19 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   for (long l = (long)L - 1; l >= 0 && num_seeds; --l) {
     const size_t fan = s->cfg.fanout[l];
     const size_t ecap = in_cap * fan;
-    bool resolved = false;
+    bool resolved = false, split = false;
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
     if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX || s->cfg.sample_type == FGNN_KHOP1 ||
         s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
-      // the frontier is a list of unique node ids: seed order by bitmap ranking instead of a sort
+    {
+      // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
+      const fgnn::RankWs rank{sl.rank_bitmap, &sl.scan_sample};
       rc = fgnn::sample_with_replacement_ex(
           s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
           s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX ? s->cfg.prob_prefix : s->cfg.prob_table, s->cfg.alias_table,
           cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key,
-          (uint32_t)l, ws, s->ws_bytes, stream,
-          // the bitmap passes cost O(nodes / 32), the sort O(seeds): worth it for frontiers of >= nodes / 64 seeds
-          // (measured: twitter layer 0 183 -> ~80 us; papers100M-shaped [25,10] frontiers are too small and stay sorted)
-          in_cap * 64 >= s->cfg.num_node ? s->cfg.num_node : 0);
+          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, sl.rank_bitmap ? &rank : nullptr);
+    }
     else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
       rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
                                    cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
@@ -387,17 +402,24 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       const bool first = start_in_sampler && l == (long)L - 1;
       // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
       // (not when this launch also inserts the seeds: their local ids would replace pending edges without a note)
+      split = ordered && l == 0 && !first && split_env != 0;
+      if (split)
+        rc = fgnn::sample_khop_plain(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
+                                     out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
+                                     stream, &sl.scan_sample);
+      else {
       resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
       rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
                              tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
                              &sl.scan_sample, first ? &start : nullptr, resolved);
+      }
     }
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
       FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
       guard.mark_csr();
     }
-    const bool inserted = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
+    const bool inserted = (s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0) && !split;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],

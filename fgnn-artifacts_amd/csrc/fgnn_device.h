@@ -619,14 +619,20 @@ struct BatchStart {
   uint32_t layer;  // this launch's layer: its num_edge entry is written by the launch itself, not by the header init
 };
 // the three with-replacement samplers (khop1 / weighted_khop / weighted_khop_prefix by sample_type; table_f = prob or
-// prefix table) for callers that know the number of graph nodes and guarantee unique seeds: the seed order then comes
-// from a bitmap over the id space instead of a radix sort.  Scratch: weighted_scratch_bytes_ex.
-size_t weighted_scratch_bytes_ex(size_t num_input_cap, size_t fanout, size_t num_node);
+// prefix table) for callers that know the number of graph nodes, guarantee unique seeds and own a RankWs: the seed
+// order then comes from a bitmap over the id space instead of a radix sort (sample_weighted.hip) -- no library call.
+// rank == null: as the C entry points (rocPRIM sorts the seeds).  Scratch: fgnn_weighted_scratch_bytes.
+struct RankWs {
+  uint32_t *bitmap;   // rank_ws_bytes(num_node) bytes, ALL ZERO between calls (the call restores that): bitmap | pre | sums
+  ScanWsHost *scan;   // look-back descriptors for the two single-pass launches
+};
+size_t rank_ws_bytes(size_t num_node);
 int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const uint32_t *indices, const float *table_f,
                                const uint32_t *alias, const uint32_t *input, size_t num_input,
                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                                uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
-                               uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node);
+                               uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node,
+                               const RankWs *rank);
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).
@@ -635,6 +641,10 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
                       void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr,
                       bool resolve = false);
+int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                      const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                      size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
+                      void *stream, ScanWsHost *scan);
 // resolve: the fill is the batch's last (hashtable_fill_duplicates_ex(..., final_fill, resolved = true) must follow):
 // ws[e] receives the insert's OUTCOME (ht_insert_resolve) instead of the bucket.  Needs ht->disp.
 

@@ -474,6 +474,19 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
                                     resolve);
 }
 
+// the same sampler without the fused insert, but with the slot's look-back descriptors (one launch): the engine's
+// split last layer -- khop2's CSR-order chain then ends with this kernel, the dedup insert runs behind it
+int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
+                      const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
+                      size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
+                      void *stream, ScanWsHost *scan) {
+  auto st = static_cast<hipStream_t>(stream);
+  return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan)
+               : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
+                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan);
+}
+
 }  // namespace fgnn
 
 extern "C" int fgnn_sample_khop0(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(kBlock) void weighted_count_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tmp_dst,
                                                                 uint32_t *__restrict__ keys,
                                                                 uint32_t *__restrict__ vals,
-                                                                uint32_t *__restrict__ cnt) {
+                                                                uint32_t *__restrict__ cnt, uint32_t *bitmap,
+                                                                uint32_t *__restrict__ order) {
+  // bitmap != null (batch driver): this launch is also the first step of the seed ranking -- one bit per seed id
+  // into a bitmap that is all zero on entry, order[] starts as "no seed at this rank"
   const size_t n = resolve_count(n_host, d_n, cap);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= cap) return;
@@ -105,6 +108,10 @@ __global__ __launch_bounds__(kBlock) void weighted_count_kernel(const uint32_t *
   keys[i] = key;
   vals[i] = (uint32_t)i;
   cnt[i] = c;
+  if (bitmap) {
+    order[i] = FGNN_EMPTY_KEY;
+    if (key != FGNN_EMPTY_KEY) atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+  }
 }
 
 // per-workgroup sums of cnt in sorted-seed order
@@ -156,14 +163,15 @@ __global__ __launch_bounds__(kBlock) void weighted_emit_kernel(const uint32_t *_
 constexpr int kWordsPerThread = 16;
 constexpr int kWordsPerBlock = kBlock * kWordsPerThread;  // bitmap words one workgroup of the popcount passes covers
 
-// one bit per seed id; order[] starts as "no seed at this rank" everywhere
-__global__ __launch_bounds__(kBlock) void rank_setbits_kernel(const uint32_t *__restrict__ keys, size_t cap,
-                                                              uint32_t *bitmap, uint32_t *__restrict__ order) {
+constexpr size_t kSinglePassTiles = 1536;  // grids whose workgroups sum all their predecessors' aggregates (fgnn_device.h)
+
+// back to all zero (only where the single-pass emit kernel, which does this on the way, cannot be used)
+__global__ __launch_bounds__(kBlock) void rank_clear_kernel(const uint32_t *__restrict__ keys, size_t cap,
+                                                            uint32_t *bitmap) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= cap) return;
-  order[i] = FGNN_EMPTY_KEY;
-  const uint32_t key = keys[i];  // EMPTY for empty rows and for the padding beyond the seed count
-  if (key != FGNN_EMPTY_KEY) atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
+  const uint32_t key = keys[i];
+  if (key != FGNN_EMPTY_KEY) bitmap[key >> 5] = 0u;
 }
 
 // mode 0: block_sums[b] = set bits in the workgroup's words; mode 1: pre[w] = set bits before word w (block_sums
@@ -208,6 +216,106 @@ __global__ __launch_bounds__(kBlock) void rank_scatter_kernel(const uint32_t *__
   order[pre[w] + (uint32_t)__popc(bitmap[w] & ((1u << b) - 1u))] = (uint32_t)i;
 }
 
+// pre[w] = set bits before word w in ONE launch: a workgroup popcounts its kWordsPerBlock words, publishes the sum and
+// adds up what the workgroups before it published (fgnn_device.h, single-pass prefix; a waiter that outlasts its
+// poll budget recounts the missing tile from the bitmap, which nothing writes while this kernel runs)
+__global__ __launch_bounds__(kBlock) void rank_prefix_kernel(const uint32_t *__restrict__ bitmap, size_t words,
+                                                             uint32_t *__restrict__ pre, ScanWs scan) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  __shared__ uint32_t sh_tile[2];
+  const uint32_t tile = blockIdx.x;
+  auto count_tile = [&](uint32_t tl, uint32_t (*local)[kWordsPerThread]) -> uint32_t {
+    const size_t w0 = (size_t)tl * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kWordsPerThread; ++k) {
+      const uint32_t c = w0 + k < words ? (uint32_t)__popc(bitmap[w0 + k]) : 0u;
+      if (local) (*local)[k] = c;
+      sum += c;
+    }
+    return sum;
+  };
+  uint32_t local[kWordsPerThread];
+  const uint32_t sum = count_tile(tile, &local);
+  uint32_t tot;
+  const uint32_t ex = block_exclusive_scan<kWavesPerBlock>(sum, sh, &tot);
+  scan_publish_aggregate(scan, tile, tot);
+  const uint32_t before = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+    uint32_t tot_m;
+    (void)block_exclusive_scan<kWavesPerBlock>(count_tile(m, nullptr), sh, &tot_m);
+    return tot_m;
+  });
+  const size_t w0 = (size_t)tile * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+  uint32_t run = before + ex;
+#pragma unroll
+  for (int k = 0; k < kWordsPerThread; ++k) {
+    if (w0 + k < words) pre[w0 + k] = run;
+    run += local[k];
+  }
+}
+
+// weighted_sorted_sums_kernel -> scan -> weighted_emit_kernel in ONE launch: a workgroup owns 256 x IPT consecutive ranks
+// (IPT consecutive ranks per lane), its output offset is the prefix over the earlier workgroups' edge counts.  Also
+// restores the ranking bitmap to all zero for the next call (every seed clears its own word; the ranking is done).
+template <int IPT>
+__global__ __launch_bounds__(kBlock) void weighted_emit_sp_kernel(const uint32_t *__restrict__ input,
+                                                                  const uint32_t *__restrict__ order,
+                                                                  const uint32_t *__restrict__ cnt,
+                                                                  const uint32_t *__restrict__ keys, size_t cap,
+                                                                  uint32_t F, const uint32_t *__restrict__ tmp_dst,
+                                                                  uint32_t *__restrict__ out_src,
+                                                                  uint32_t *__restrict__ out_dst, int src_mode,
+                                                                  ScanWs scan, size_t *d_num_out, uint32_t *bitmap) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  __shared__ uint32_t sh_tile[2];
+  const uint32_t tile = blockIdx.x;
+  auto tile_sum = [&](uint32_t tl, uint32_t *oi, uint32_t *c) -> uint32_t {
+    const size_t r0 = ((size_t)tl * kBlock + threadIdx.x) * IPT;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const uint32_t o = r0 + q < cap ? order[r0 + q] : FGNN_EMPTY_KEY;  // EMPTY: no seed at this rank
+      const uint32_t cc = o != FGNN_EMPTY_KEY ? cnt[o] : 0u;
+      if (oi) {
+        oi[q] = o;
+        c[q] = cc;
+      }
+      sum += cc;
+    }
+    return sum;
+  };
+  uint32_t oi[IPT], c[IPT];
+  const uint32_t sum = tile_sum(tile, oi, c);
+  uint32_t tot;
+  const uint32_t lo = block_exclusive_scan<kWavesPerBlock>(sum, sh, &tot);
+  scan_publish_aggregate(scan, tile, tot);
+  const uint32_t before = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+    uint32_t tot_m;
+    (void)block_exclusive_scan<kWavesPerBlock>(tile_sum(m, nullptr, nullptr), sh, &tot_m);
+    return tot_m;
+  });
+  if (tile == gridDim.x - 1 && threadIdx.x == 0 && d_num_out) *d_num_out = (size_t)before + tot;
+  size_t w = (size_t)before + lo;
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    if (c[q] == 0) continue;
+    const uint32_t i = oi[q];
+    if (bitmap) bitmap[keys[i] >> 5] = 0u;  // c != 0 <=> the seed has a key, i.e. a bit in the bitmap
+    const uint32_t src = src_mode == FGNN_SRC_LOCAL ? i : input[i];
+    const uint32_t *d = tmp_dst + (size_t)i * F;
+    uint32_t cur = d[0];
+    for (uint32_t j = 0; j < F; ++j) {
+      const uint32_t nxt = (j + 1 < F) ? d[j + 1] : ~cur;  // ~cur != cur: last one always kept
+      if (cur != nxt) {
+        out_src[w] = src;
+        out_dst[w] = cur;
+        ++w;
+      }
+      cur = nxt;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace fgnn
 
@@ -215,14 +323,9 @@ using namespace fgnn;
 
 // scratch layout for cap seeds, fanout F (all uint32 unless noted):
 //   tmp_dst[cap*F] | keys[cap] | vals[cap] | keys_out[cap] | order[cap] | cnt[cap] | sums[nb+1] | rocprim temp
-static size_t rank_bitmap_bytes(size_t num_node) {
+size_t fgnn::rank_ws_bytes(size_t num_node) {
   const size_t words = fgnn::div_up(num_node, (size_t)32);
   return (2 * words + fgnn::div_up(words, (size_t)fgnn::kWordsPerBlock) + 16) * sizeof(uint32_t);  // bitmap | pre | sums
-}
-
-size_t fgnn::weighted_scratch_bytes_ex(size_t num_input_cap, size_t fanout, size_t num_node) {
-  const size_t base = fgnn_weighted_scratch_bytes(num_input_cap, fanout);
-  return num_node ? base + rank_bitmap_bytes(num_node) : base;
 }
 
 extern "C" size_t fgnn_weighted_scratch_bytes(size_t num_input_cap, size_t fanout) {
@@ -240,9 +343,10 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
                             const float *table_f, const uint32_t *alias, const uint32_t *input, size_t num_input,
                             const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                             uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
-                            uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node = 0) {
-  // num_node != 0: the caller guarantees unique seeds below num_node (the batch driver's frontier) and has sized
-  // the scratch with weighted_scratch_bytes_ex
+                            uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node = 0,
+                            const RankWs *rank = nullptr) {
+  // rank != null: the caller guarantees unique seeds below num_node (the batch driver's frontier) and owns an all-zero
+  // bitmap over the id space: the seeds are ordered by counting bits, nothing is sorted and no library is called
   auto st = static_cast<hipStream_t>(stream);
   size_t cap = d_num_input ? num_input_cap : num_input;
   if (fanout == 0 || fanout > 0xffffu) return FGNN_EINVAL;
@@ -252,7 +356,8 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
   }
   if (!indptr || !indices || !input || cap * fanout >= 0x7fffffffull) return FGNN_EINVAL;
   if ((mode != 1 && !table_f) || (mode == 2 && !alias)) return FGNN_EINVAL;
-  if (ws_bytes < weighted_scratch_bytes_ex(cap, fanout, num_node)) return FGNN_ENOSPC;
+  if (ws_bytes < fgnn_weighted_scratch_bytes(cap, fanout)) return FGNN_ENOSPC;
+  if (rank && (!rank->bitmap || !rank->scan || num_node == 0)) return FGNN_EINVAL;
   const uint32_t F = (uint32_t)fanout;
   const uint32_t tag = ((uint32_t)sample_type << 8) | (layer & 0xffu);
   const size_t nb = div_up(cap, kBlock);
@@ -275,21 +380,37 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
   else if (mode == 2) FGNN_DRAW(2);
   else FGNN_DRAW(0);
 #undef FGNN_DRAW
+  uint32_t *bitmap = rank ? rank->bitmap : nullptr;
   hipLaunchKernelGGL(weighted_count_kernel, dim3(nb), dim3(kBlock), 0, st, indptr, input, num_input, d_num_input, cap, F,
-                     tmp_dst, keys, vals, cnt);
-  if (num_node) {
-    // order by counting bits below each seed id (see the file header)
+                     tmp_dst, keys, vals, cnt, bitmap, order);
+  if (rank) {
+    // order by counting bits below each seed id (see the file header): 5 launches per layer in all
     const size_t words = div_up(num_node, (size_t)32);
     const size_t nb2 = div_up(words, (size_t)kWordsPerBlock);
-    uint32_t *bitmap = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + fgnn_weighted_scratch_bytes(cap, fanout));
     uint32_t *pre = bitmap + words;
-    uint32_t *sums2 = pre + words;
-    FGNN_HIP_CHECK(hipMemsetAsync(bitmap, 0, words * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(rank_setbits_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap, order);
-    hipLaunchKernelGGL((rank_popcount_kernel<0>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
-    if (launch_scan_block_sums(sums2, nb2, nullptr, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
-    hipLaunchKernelGGL((rank_popcount_kernel<1>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
+    if (nb2 <= kSinglePassTiles && nb2 <= rank->scan->ws.max_tiles) {
+      hipLaunchKernelGGL(rank_prefix_kernel, dim3(nb2), dim3(kBlock), 0, st, bitmap, words, pre,
+                         rank->scan->next(0, nb2));
+    } else {  // graphs beyond ~200 M nodes: per-workgroup sums -> scan -> prefixes
+      uint32_t *sums2 = pre + words;
+      hipLaunchKernelGGL((rank_popcount_kernel<0>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
+      if (launch_scan_block_sums(sums2, nb2, nullptr, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
+      hipLaunchKernelGGL((rank_popcount_kernel<1>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
+    }
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap, pre, order);
+    const int ipt = nb <= kSinglePassTiles ? 1 : nb <= 4 * kSinglePassTiles ? 4 : nb <= 16 * kSinglePassTiles ? 16 : 0;
+    const size_t grid = ipt ? div_up(cap, (size_t)kBlock * ipt) : 0;
+    if (ipt && grid <= rank->scan->ws.max_tiles) {
+#define FGNN_EMIT(I)                                                                                                  \
+  hipLaunchKernelGGL((weighted_emit_sp_kernel<I>), dim3(grid), dim3(kBlock), 0, st, input, order, cnt, keys, cap, F, \
+                     tmp_dst, out_src, out_dst, src_mode, rank->scan->next(0, grid), d_num_out, bitmap)
+      if (ipt == 1) FGNN_EMIT(1);
+      else if (ipt == 4) FGNN_EMIT(4);
+      else FGNN_EMIT(16);
+#undef FGNN_EMIT
+      return launch_status(__func__);
+    }
+    hipLaunchKernelGGL(rank_clear_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap);
   } else {
     FGNN_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, vals, order, cap, 0, 32, st));
   }
@@ -308,11 +429,11 @@ int fgnn::sample_with_replacement_ex(int sample_type, const uint32_t *indptr, co
                                      size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
                                      uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
                                      uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                                     void *stream, size_t num_node) {
+                                     void *stream, size_t num_node, const RankWs *rank) {
   const int mode = sample_type == FGNN_KHOP1 ? 1 : sample_type == FGNN_WEIGHTED_KHOP ? 2 : 0;
   return launch_with_replacement(mode, sample_type, indptr, indices, table_f, alias, input, num_input, d_num_input,
                                  num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed, batch_key, layer,
-                                 ws, ws_bytes, stream, num_node);
+                                 ws, ws_bytes, stream, num_node, rank);
 }
 
 extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,
