@@ -195,14 +195,32 @@ struct alignas(16) chunk16 { uint32_t a, b, c, d; };
 // at a few workgroups per CU: enough loads in flight to saturate HBM while leaving wave slots for the
 // latency-bound sampling kernels of the next batch that run concurrently on another stream.
 // CPR > 0 fixes chunks-per-row at compile time (the index division becomes a multiply/shift).
+// `tail` (batch driver): the batch's label rows and its 128-byte summary ride along with the feature gather instead of
+// taking a launch each (a 4 us element gather and a 4 us copyBuffer behind 6 us event gaps, per batch)
 template <int UNROLL, int CPR, bool NT, bool NTS>
 __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restrict__ out,
                                                                const chunk16 *__restrict__ src,
                                                                const uint32_t *__restrict__ src_index,
                                                                const uint32_t *__restrict__ dst_index, size_t n_host,
                                                                const uint32_t *d_n, size_t cap, uint32_t cpr_rt,
-                                                               uint32_t src_mask) {
+                                                               uint32_t src_mask, GatherTail tail) {
   const uint32_t cpr = CPR ? (uint32_t)CPR : cpr_rt;
+  if (tail.label_out) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < tail.num_label; i += stride) {
+      const size_t r = tail.label_index[i];
+      switch (tail.label_esz) {
+        case 1: static_cast<uint8_t *>(tail.label_out)[i] = static_cast<const uint8_t *>(tail.label_src)[r]; break;
+        case 2: static_cast<uint16_t *>(tail.label_out)[i] = static_cast<const uint16_t *>(tail.label_src)[r]; break;
+        case 4: static_cast<uint32_t *>(tail.label_out)[i] = static_cast<const uint32_t *>(tail.label_src)[r]; break;
+        default:
+          static_cast<unsigned long long *>(tail.label_out)[i] = static_cast<const unsigned long long *>(tail.label_src)[r];
+      }
+    }
+  }
+  // the summary is final before this launch starts (every kernel that writes it is earlier in the stream)
+  if (tail.meta_dst && blockIdx.x == gridDim.x - 1 && threadIdx.x < tail.meta_words)
+    tail.meta_dst[threadIdx.x] = tail.meta_src[threadIdx.x];
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);
   const uint32_t total = n * cpr;  // host guarantees cap * cpr < 2^32
   constexpr uint32_t tile = kBlock * UNROLL;
@@ -366,7 +384,21 @@ extern "C" int fgnn_gather_rows(void *out, const void *src, const uint32_t *src_
 extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_index,
                                        const uint32_t *dst_index, size_t n, const uint32_t *d_n, size_t n_cap,
                                        size_t dim, int dtype, uint32_t src_row_mask, void *stream) {
+  return fgnn::gather_rows_ex(out, src, src_index, dst_index, n, d_n, n_cap, dim, dtype, src_row_mask, stream, nullptr);
+}
+
+bool fgnn::gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype) {
+  const size_t row_bytes = dim * dtype_bytes(dtype);
+  return row_bytes && row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(src) % 16 == 0 && n_cap > 0 && n_cap * (row_bytes / 16) < 0xffffffffull;
+}
+
+int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
+                         const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
+                         void *stream, const GatherTail *tail_in) {
   auto s = static_cast<hipStream_t>(stream);
+  const GatherTail tail = tail_in ? *tail_in : GatherTail{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+  if (tail_in && !gather_takes_tail(out, src, d_n ? n_cap : n, dim, dtype)) return FGNN_EINVAL;
   const size_t esz = dtype_bytes(dtype);
   size_t cap = d_n ? n_cap : n;
   if (esz == 0 || dim == 0) return FGNN_EINVAL;
@@ -387,7 +419,7 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
         const int rc = fgnn_gather_rows_masked(
             dst_index ? out : static_cast<char *>(out) + r0 * row_bytes,
             src_index ? src : static_cast<const char *>(src) + r0 * row_bytes, src_index ? src_index + r0 : nullptr,
-            dst_index ? dst_index + r0 : nullptr, m, nullptr, m, dim, dtype, src_row_mask, stream);
+            dst_index ? dst_index + r0 : nullptr, m, nullptr, m, dim, dtype, src_row_mask, stream);  // (no tail here)
         if (rc != FGNN_OK) return rc;
       }
       return FGNN_OK;
@@ -410,10 +442,10 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
     if (blocks > cus * wg_per_cu) blocks = cus * wg_per_cu;                                                      \
     if (nts) hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, true>), dim3(blocks), dim3(kBlock), 0, s,          \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
-                       d_n, cap, cpr, src_row_mask);                                                             \
+                       d_n, cap, cpr, src_row_mask, tail);                                                       \
     else hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, false>), dim3(blocks), dim3(kBlock), 0, s,             \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
-                       d_n, cap, cpr, src_row_mask);                                                             \
+                       d_n, cap, cpr, src_row_mask, tail);                                                       \
   } while (0)
 #define FGNN_GATHER2(U, C) do { if (nt) FGNN_GATHER3(U, C, true); else FGNN_GATHER3(U, C, false); } while (0)
 #define FGNN_GATHER(U)                                  \

@@ -67,6 +67,7 @@ struct fgnn_batch {
                                           // t1..t2 the cached-row gather
   bool timed2;
   bool timing, timed;
+  bool meta_copied;                       // the last extract launch of this batch also copied the summary to h_meta
   fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
   uint32_t feat_row_mask;                 // SAMGRAPH_EMPTY_FEAT mock extraction (all ones = off)
 };
@@ -343,6 +344,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   uint32_t *tmp_dst = sl.tmp_dst;
   void *ws = sl.ws;
   out->num_output = num_seeds;
+  out->meta_copied = false;
   // the slot's scratch was last used kSlots batches ago, possibly on another stream
   if (sl.was_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
   if (ordered && seq > 0) {
@@ -379,12 +381,14 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
         s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
     {
       // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
-      const fgnn::RankWs rank{sl.rank_bitmap, &sl.scan_sample};
+      // FGNN_RANK_BITMAP=0 (A/B only): order the seeds with rocPRIM's radix sort like the stateless C entry points
+      static const bool use_rank = [] { const char *e = getenv("FGNN_RANK_BITMAP"); return !(e && atoi(e) == 0); }();
+      const fgnn::RankWs rank{use_rank ? sl.rank_bitmap : nullptr, &sl.scan_sample};
       rc = fgnn::sample_with_replacement_ex(
           s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
           s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX ? s->cfg.prob_prefix : s->cfg.prob_table, s->cfg.alias_table,
           cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key,
-          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, sl.rank_bitmap ? &rank : nullptr);
+          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, rank.bitmap ? &rank : nullptr);
     }
     else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
       rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
@@ -466,6 +470,7 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
 
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
   if (!b || !cache_table) return FGNN_EINVAL;
+  b->meta_copied = false;
   fgnn::ScanErrorSink sink(&b->d_meta->overflow);
   // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
   return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
@@ -506,22 +511,45 @@ extern "C" int fgnn_batch_set_feat_row_mask(fgnn_batch *b, uint32_t mask) {
   return FGNN_OK;
 }
 
+namespace {
+
+// label rows + summary copy as a tail of the batch's last feature gather (cache_gather.hip), where that gather can carry one
+bool make_tail(fgnn_batch *b, const void *src, const void *label, fgnn::GatherTail *t) {
+  if (!fgnn::gather_takes_tail(b->feat, src, b->feat_rows_cap, b->feat_dim, b->feat_dtype)) return false;
+  *t = fgnn::GatherTail{nullptr, nullptr, nullptr, 0, 0, reinterpret_cast<uint32_t *>(b->h_meta),
+                        reinterpret_cast<const uint32_t *>(b->d_meta), (uint32_t)(sizeof(fgnn_batch_meta) / 4)};
+  if (label && b->num_output) {
+    t->label_out = b->label;
+    t->label_src = label;
+    t->label_index = b->output_nodes;
+    t->num_label = (uint32_t)b->num_output;
+    t->label_esz = (uint32_t)dtype_size(b->label_dtype);
+  }
+  return true;
+}
+
+}  // namespace
+
 extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *label, void *stream) {
   if (!b || !b->feat_dim) return FGNN_EINVAL;
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
+  bool tailed = false;
   if (feat) {
     if (b->feat_rows_cap < b->owner->max_nodes)
       hipLaunchKernelGGL(batch_rows_overflow_kernel, dim3(1), dim3(1), 0, st, b->d_meta, (uint32_t)b->feat_rows_cap);
+    fgnn::GatherTail tail;
+    tailed = make_tail(b, feat, label, &tail);
     if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
-    rc = fgnn_gather_rows_masked(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
-                                 b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
+    rc = fgnn::gather_rows_ex(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
+                              b->feat_dim, b->feat_dtype, b->feat_row_mask, stream, tailed ? &tail : nullptr);
     if (b->timing) {
       FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
       b->timed = true;
     }
+    if (rc == FGNN_OK && tailed) b->meta_copied = true;
   }
-  if (rc == FGNN_OK && label && b->num_output)
+  if (rc == FGNN_OK && !tailed && label && b->num_output)
     rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
                           b->label_dtype, stream);
   return rc;
@@ -535,19 +563,25 @@ extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, 
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
   const bool timing = b->timing && full_feat && cache_rows;
+  // the tail rides on the LAST gather of the batch
+  fgnn::GatherTail tail;
+  const void *last_src = cache_rows ? cache_rows : full_feat;
+  const bool tailed = last_src && make_tail(b, last_src, label, &tail);
   if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
   if (full_feat)  // CombineMissData with the row fetch fused in
-    rc = fgnn_gather_rows_masked(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss,
-                                 b->feat_rows_cap, b->feat_dim, b->feat_dtype, b->feat_row_mask, stream);
+    rc = fgnn::gather_rows_ex(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss, b->feat_rows_cap,
+                              b->feat_dim, b->feat_dtype, b->feat_row_mask, stream,
+                              tailed && !cache_rows ? &tail : nullptr);
   if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
   if (rc == FGNN_OK && cache_rows)  // CombineCacheData
-    rc = fgnn_gather_rows(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,
-                          b->feat_dim, b->feat_dtype, stream);
+    rc = fgnn::gather_rows_ex(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,
+                              b->feat_dim, b->feat_dtype, 0xFFFFFFFFu, stream, tailed ? &tail : nullptr);
   if (timing) {
     FGNN_HIP_CHECK(hipEventRecord(b->t2, st));
     b->timed2 = true;
   }
-  if (rc == FGNN_OK && label && b->num_output)
+  if (rc == FGNN_OK && tailed) b->meta_copied = true;
+  if (rc == FGNN_OK && !tailed && label && b->num_output)
     rc = fgnn_gather_rows(b->label, label, b->output_nodes, nullptr, b->num_output, nullptr, b->num_output, 1,
                           b->label_dtype, stream);
   return rc;
@@ -570,7 +604,10 @@ extern "C" int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, cons
 extern "C" int fgnn_batch_finish(fgnn_batch *b, void *stream) {
   if (!b) return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
-  FGNN_HIP_CHECK(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(fgnn_batch_meta), hipMemcpyDeviceToHost, st));
+  // unless the batch's last extract launch has written the summary to h_meta itself (GatherTail)
+  if (!b->meta_copied)
+    FGNN_HIP_CHECK(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(fgnn_batch_meta), hipMemcpyDeviceToHost, st));
+  b->meta_copied = false;
   FGNN_HIP_CHECK(hipEventRecord(b->done, st));
   return FGNN_OK;
 }

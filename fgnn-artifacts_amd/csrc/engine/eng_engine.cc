@@ -568,11 +568,13 @@ void Engine::SampleOnceArch5() {
   const uint64_t key = BatchKey(shuffler_->Epoch(), shuffler_->Step());
   const int cur = (int)(next_slot_++ % slots_.size());
   Slot &s = slots_[cur];
+  Timer t_wait;
   {  // the slot's previous batch (slots_.size() batches ago) must have been published
     std::unique_lock<std::mutex> lk(pub_mu_);
     pub_cv_.wait(lk, [&] { return !s.pending; });
     if (!publish_thread_.joinable()) publish_thread_ = std::thread([this] { PublisherLoop(); });
   }
+  sstat_.slot_wait += t_wait.Passed();
   s.started = Timer();
   s.key = key;
   SAM_HIP(hipEventRecord(s.e0, s.st));
@@ -608,6 +610,8 @@ void Engine::SampleOnceArch5() {
     pub_q_.push_back(cur);
   }
   pub_cv_.notify_all();
+  sstat_.enqueue += s.started.Passed();
+  ++sstat_.n;
   // the next call reshuffles the seed array on the device: every batch reading it must be through (the reference
   // flushes at the same point, dist_loops_arch5.cc:131-137)
   if (shuffler_->IsLastBatch()) PublishPending();
@@ -999,6 +1003,10 @@ void Engine::Shutdown() {
   for (auto &sl : slots_)
     if (sl.st) (void)hipStreamSynchronize(sl.st);
   if (tstream_) (void)hipStreamSynchronize(tstream_);
+  if (sstat_.n)
+    SAM_LOG(kInfo) << "sampler: " << sstat_.n << " batches; per batch: waiting for the slot's previous batch to be "
+                   << "published " << sstat_.slot_wait / sstat_.n * 1e3 << " ms, enqueueing (host) "
+                   << sstat_.enqueue / sstat_.n * 1e3 << " ms";
   if (xstat_.n)
     SAM_LOG(kInfo) << "extraction thread: " << xstat_.n << " batches; per batch: waiting for a message "
                    << xstat_.recv / xstat_.n * 1e3 << " ms, parsing + enqueueing copies and gathers "
@@ -1015,7 +1023,9 @@ void Engine::Shutdown() {
   if (mq_ && ring_id_ >= 0) {
     // messages published into this sampler's HBM ring must stay readable until their receivers have copied them
     // (the in-process engines read their own ring and their threads have been joined: nothing to wait for)
-    mq_->DrainDeviceRing(ring_id_, RC().run_arch == kArch5 ? 120.0 : 0.0);
+    // SAMGRAPH_DEVICE_RING_DRAIN_S: tools that run a sampler with nobody reading (tools/sampler_timeline.py)
+    const char *e_drain = getenv("SAMGRAPH_DEVICE_RING_DRAIN_S");
+    mq_->DrainDeviceRing(ring_id_, RC().run_arch != kArch5 ? 0.0 : e_drain ? atof(e_drain) : 120.0);
     ring_id_ = -1;
   }
   if (current_) {

@@ -162,6 +162,8 @@ class Engine {
   ExtractCtx xctx_[kExtractDepth];
   // where the extraction thread's time goes (reported at shutdown, log level info)
   struct { double recv = 0, issue = 0, pool_wait = 0, sync = 0; size_t n = 0; } xstat_;
+  // the same for an arch5 sampler's sample_once calls
+  struct { double slot_wait = 0, enqueue = 0; size_t n = 0; } sstat_;
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;

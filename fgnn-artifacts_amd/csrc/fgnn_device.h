@@ -596,6 +596,22 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
 bool hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts
 int hashtable_next_generation(fgnn_hashtable *ht, void *stream, bool zero_counts);
+// small jobs of a batch that ride along with its feature gather launch (gather_rows16_kernel): the label rows of the
+// seeds and the copy of the batch summary into pinned host memory
+struct GatherTail {
+  void *label_out;              // null: no label job
+  const void *label_src;
+  const uint32_t *label_index;  // output_nodes
+  uint32_t num_label, label_esz;
+  uint32_t *meta_dst;           // null: no summary copy (else host-mapped, 4-byte words)
+  const uint32_t *meta_src;
+  uint32_t meta_words;          // <= 256
+};
+// can this gather carry a tail (16-byte row path, one launch)?
+bool gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype);
+int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
+                   const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask, void *stream,
+                   const GatherTail *tail);
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,

@@ -20,6 +20,8 @@ rows.sort()
 # a batch ends with the D2H copy of its summary; the setup copies come before the first sampler kernel
 first = next(i for i, r in enumerate(rows) if r[2].startswith("khop_sample") or r[2].startswith("ht_start_batch"))
 ends = [i for i, r in enumerate(rows) if i > first and r[2] == "__amd_rocclr_copyBuffer"]
+if len(ends) < 4:  # the summary copy rides on the feature gather (GatherTail): that launch closes a batch
+    ends = [i for i, r in enumerate(rows) if i > first and r[2] in ("gather_rows16_kernel", "pack_kernel")]
 b = ends[which - 1] + 1
 e = ends[which] + 1
 t0 = rows[b][0]
