@@ -1200,6 +1200,9 @@ def parse_args(argv=None):
 
 
 def main():
+    # the HIP runtime's hardware queues per process (read at its first call): an arch5 rank runs five streams
+    # (samgraph_config sets the same default; here it also covers the torch side of a trainer rank)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args = parse_args()
     if args.cpu_only:
         dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")

@@ -612,6 +612,13 @@ extern "C" int fgnn_batch_finish(fgnn_batch *b, void *stream) {
   return FGNN_OK;
 }
 
+extern "C" fgnn_batch_meta *fgnn_batch_host_meta(const fgnn_batch *b) { return b ? b->h_meta : nullptr; }
+extern "C" int fgnn_batch_meta_copied(fgnn_batch *b) {
+  if (!b) return FGNN_EINVAL;
+  b->meta_copied = true;
+  return FGNN_OK;
+}
+
 extern "C" int fgnn_batch_wait(fgnn_batch *b, fgnn_batch_meta *h_meta) {
   if (!b) return FGNN_EINVAL;
   FGNN_HIP_CHECK(hipEventSynchronize(b->done));

@@ -163,7 +163,7 @@ class Engine {
   // where the extraction thread's time goes (reported at shutdown, log level info)
   struct { double recv = 0, issue = 0, pool_wait = 0, sync = 0; size_t n = 0; } xstat_;
   // the same for an arch5 sampler's sample_once calls
-  struct { double slot_wait = 0, enqueue = 0; size_t n = 0; } sstat_;
+  struct { double slot_wait = 0, enqueue = 0, pub_wait = 0, pub_rest = 0; size_t n = 0; } sstat_;
 
   // device copies
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
@@ -188,7 +188,8 @@ class Engine {
     fgnn_batch *fb = nullptr;
     bool busy = false;           // arch1: handed to the trainer
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    hipStream_t st = nullptr;    // arch2-6: the slot's own stream
+    hipStream_t st = nullptr;    // arch2-6: the slot's stream (arch5 sampler: shared by the slots i, i + streams, ...)
+    bool owns_st = true;
     // arch5: message being written
     bool pending = false;
     size_t mq_key = 0;

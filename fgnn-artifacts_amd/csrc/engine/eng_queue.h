@@ -128,6 +128,7 @@ struct PackArgs {
   void *slot;            // host slot: headers (and the arrays too when `payload` is null)
   void *payload;         // device-ring slot for the arrays (same layout and offsets as the host slot), or null
   size_t slot_bytes;
+  uint32_t *h_meta;      // pinned copy of the batch summary the pack kernel fills on the way (fgnn_batch_host_meta), or null
 };
 // enqueues the serialisation of one batch into `slot` (device-visible host memory)
 int LaunchPack(const PackArgs &a, hipStream_t stream);

@@ -349,6 +349,11 @@ int fgnn_batch_enable_timing(fgnn_batch *b, int on);
 float fgnn_batch_gather_ms(fgnn_batch *b);
 /* async copy of the summary to pinned host memory + event */
 int fgnn_batch_finish(fgnn_batch *b, void *stream);
+/* A caller whose own kernel runs last on the batch's stream anyway (the engine's message pack kernel) can let that
+ * kernel copy the summary: write sizeof(fgnn_batch_meta) bytes from fgnn_batch_device_meta() to this pinned,
+ * device-visible address, call fgnn_batch_meta_copied(), then fgnn_batch_finish() -- which then only records the event. */
+fgnn_batch_meta *fgnn_batch_host_meta(const fgnn_batch *b);
+int fgnn_batch_meta_copied(fgnn_batch *b);
 /* blocks until the batch's event; copies the summary to *h_meta (may be NULL) */
 int fgnn_batch_wait(fgnn_batch *b, fgnn_batch_meta *h_meta);
 

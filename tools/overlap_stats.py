@@ -10,14 +10,16 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    m = re.search(r"fgnn::(?:\(anonymous namespace\)::)?(\w+)", n) or re.search(r"(__amd_rocclr_copyBuffer)", n)
+    m = re.search(r"(?:fgnn|sam)::(?:\(anonymous namespace\)::)?(\w+)", n) or re.search(r"(__amd_rocclr_copyBuffer)", n)
     if not m:
         continue
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1), r.get("Stream_Id", r.get("Queue_Id"))))
 rows.sort()
 first = next(i for i, r in enumerate(rows) if r[2].startswith("khop_sample"))
 starts = [i for i, r in enumerate(rows) if i > first and r[2] == "__amd_rocclr_copyBuffer"]  # one per batch (its end)
-a, b = starts[30], starts[150]  # inside the timed two-stream region
+if len(starts) < 151:  # the summary copy rides on the batch's last kernel (GatherTail / pack kernel)
+    starts = [i for i, r in enumerate(rows) if i > first and r[2] in ("gather_rows16_kernel", "pack_kernel")]
+a, b = starts[30], starts[150]  # inside the timed region
 seg = rows[a:b]
 t0, t1 = seg[0][0], max(r[1] for r in seg)
 ev = []
