@@ -584,6 +584,10 @@ def run_single(args):
     achieved = gather_feat_bytes / len(metas) / (gather_avg_ms * 1e-3) / 1e9
 
     ratio, per_kernel, pmc_file = pmc_traffic()
+    if (args.workload, args.sample_type, args.graph) != ("papers100M", "khop2", "rmat"):
+        # the PMC passes were taken on the default workload: the gather's ratio (a property of the kernel: rows are
+        # whole cache lines) carries over, the sampler-side per-stage ratios do not
+        per_kernel = None
     # reference point next to the 8 TB/s spec peak the fraction is quoted against: what torch's plain device-to-device
     # copy of 2 GiB reaches on this GPU right now (read + write bytes per second; ordinary loads/stores -- the gather's
     # non-temporal accesses beat it)

@@ -402,6 +402,45 @@ def test_batch_driver_other_samplers(hip, oracle, mode):
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
 
 
+@pytest.mark.parametrize("kind", ["weighted_khop_prefix", "khop1"])
+@pytest.mark.parametrize("batch", [150, 8000, 10000])
+def test_batch_driver_bitmap_seed_ranking(hip, oracle, kind, batch):
+    """The with-replacement samplers of the batch driver order their seeds by counting bits in a bitmap over the node ids
+    (sample_weighted.hip; the reference radix-sorts all pairs, cuda_sampling_weighted_khop_prefix.cu:148-255).  Shapes that
+    reach every variant: a graph of several bitmap tiles (rank_prefix_kernel's cross-workgroup prefix), and worst-case
+    frontier capacities of 1.4 M and 1.76 M seeds (weighted_emit_sp_kernel with 4 and 16 ranks per lane; batch 150: 1)."""
+    from fgnn_hip import synth
+    num_node = 400000  # 12 500 bitmap words = 4 tiles of 4096
+    indptr, indices = synth.powerlaw_csr(num_node, 4000000, seed=36)
+    fanouts = [5, 10, 15]
+    if kind == "khop1":
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.KHOP1, seed=SEED)
+        okw, ost = {}, oracle.KHOP1
+    else:
+        prefix = synth.prob_prefix_table(indptr, indices)
+        sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.WEIGHTED_KHOP_PREFIX,
+                              seed=SEED, prob_prefix=dev(prefix))
+        okw, ost = dict(prob_prefix=prefix), oracle.WEIGHTED_KHOP_PREFIX
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    for b in range(2):  # the second batch finds the bitmap as the first one left it: all zero
+        seeds = _seeds(batch - 13 * b, num_node, seed=70 + b)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht, **okw)
+        assert m.overflow == 0
+        for li in range(3):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
 @pytest.mark.parametrize("kind", ["khop1", "weighted_khop", "weighted_khop_hash_dedup"])
 @pytest.mark.parametrize("fanout", [1, 6, 15, 50])
 def test_with_replacement_samplers_match_oracle(hip, oracle, kind, fanout):

@@ -17,11 +17,13 @@ for r in csv.DictReader(open(f)):
         continue
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1), r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
-# a batch ends with the D2H copy of its summary; the setup copies come before the first sampler kernel
+# a batch ends with its feature gather (bench; the label rows and the summary copy ride on that launch) or with the pack
+# kernel (an arch5 sampler); traces of older builds end a batch with the D2H copy of its summary
 first = next(i for i, r in enumerate(rows) if r[2].startswith("khop_sample") or r[2].startswith("ht_start_batch"))
-ends = [i for i, r in enumerate(rows) if i > first and r[2] == "__amd_rocclr_copyBuffer"]
-if len(ends) < 4:  # the summary copy rides on the feature gather (GatherTail): that launch closes a batch
-    ends = [i for i, r in enumerate(rows) if i > first and r[2] in ("gather_rows16_kernel", "pack_kernel")]
+names = {r[2] for r in rows}
+last = "gather_rows16_kernel" if "gather_rows16_kernel" in names else "pack_kernel" if "pack_kernel" in names \
+    else "__amd_rocclr_copyBuffer"
+ends = [i for i, r in enumerate(rows) if i > first and r[2] == last]
 b = ends[which - 1] + 1
 e = ends[which] + 1
 t0 = rows[b][0]
