@@ -395,6 +395,8 @@ def run_single(args):
     dev = torch.device("cuda", 0)
     lib.load()
     w = WORKLOADS[args.workload]
+    if args.num_walks and "num_walks" in w:
+        w = dict(w, num_walks=args.num_walks)
     if args.sample_type is None:
         args.sample_type = w["sample_type"]
     t_setup = time.time()
@@ -610,7 +612,9 @@ def run_single(args):
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"{args.workload}-shaped synthetic graph: {graph_desc}; N={w['num_node']}, "
                                f"E={num_edge}, train set {w['num_train']} uniform random ids (seed 1), feat "
-                               f"f32[N,{w['feat_dim']}] resident in HBM, {args.sample_type} fanout {w['fanout']}, batch "
+                               f"f32[N,{w['feat_dim']}] resident in HBM, {args.sample_type} fanout {w['fanout']}"
+                               + (f" ({w['num_walks']} walks x {w['walk_len']} steps, restart {w['restart_prob']})"
+                                  if args.sample_type == "random_walk" else "") + ", batch "
                                f"{bs}, cache table ratio {args.cache_ratio}, 1 GPU samples and extracts",
                    "global_batch": bs, "parallelism": "1 GPU (sampler + extractor)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -917,6 +921,8 @@ def run_pipeline_rank(args, rank, world):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     dev_id = local_rank % max(n_dev, 1)  # more ranks than GPUs (a functional check on one GPU): they share
     w = WORKLOADS[args.workload]
+    if args.num_walks and "num_walks" in w:
+        w = dict(w, num_walks=args.num_walks)
     if args.sample_type is None:
         args.sample_type = w["sample_type"]
     bs = w["batch_size"]
@@ -1196,6 +1202,9 @@ def parse_args(argv=None):
     ap.add_argument("--sample-type", default=None, choices=list(SAMPLE_TYPES),
                     help="default: the workload's (khop2 = the reference's default for GraphSAGE, "
                          "multi_gpu/train_graphsage.py:75)")
+    ap.add_argument("--num-walks", type=int, default=0,
+                    help="random_walk workloads: walks per seed (default: the workload's 25; the reference's PinSAGE "
+                         "scripts default to 4, multi_gpu/train_pinsage.py:130-134)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
     ap.add_argument("--cpu-only", action="store_true",
                     help="BASELINE.json configs[0] only: the reference's CPU path (oracle/_ref) on the products shape, "

@@ -248,23 +248,32 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     if (seed_lane)
       for (uint32_t q = 0; q < F; ++q) sh_o[q * S + k] = q;
     __syncthreads();
-    // wave-parallel over each long row of this workgroup (rows can be millions long)
-    for (int k = wave_id(); k < S; k += NW) {
-      const uint32_t klen = sh_len[k];
-      if (klen <= F) continue;  // wave-uniform
-      const uint32_t item = (uint32_t)(first + k);
-      // lane handles 4 consecutive j (one Philox block): j4 = 4*(F/4 + lane + 64*it)
-      for (uint32_t jb = (F >> 2) + lane_id(); (jb << 2) < klen; jb += kWave) {
+    // One draw per row ELEMENT beyond the fanout (khop0.cu:41-90): rows can be millions long (R-MAT hubs), and the
+    // reference walks each with ONE thread.  Rows up to kHugeRow elements: a wave per row; longer ones: the whole
+    // workgroup per row, one after the other (a hub in a tile used to keep one wave busy for the others' idle time).
+    constexpr uint32_t kHugeRow = 4096;
+    auto reservoir = [&](int row, uint32_t klen, uint32_t first_lane, uint32_t lanes) {
+      const uint32_t item = (uint32_t)(first + row);
+      // a lane handles 4 consecutive j (one Philox block): j4 = 4*(F/4 + lane + lanes*it)
+      for (uint32_t jb = (F >> 2) + first_lane; (jb << 2) < klen; jb += lanes) {
         const u32x4 blk = philox_block(seed, batch_key, tag, item, jb);
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
           const uint32_t j = (jb << 2) + u;
           if (j >= F && j < klen) {
             const uint32_t kk = pick_word(blk, u) % (j + 1);
-            if (kk < F) atomicMax(&sh_o[kk * S + k], j);
+            if (kk < F) atomicMax(&sh_o[kk * S + row], j);
           }
         }
       }
+    };
+    for (int row = wave_id(); row < S; row += NW) {
+      const uint32_t klen = sh_len[row];
+      if (klen > F && klen <= kHugeRow) reservoir(row, klen, (uint32_t)lane_id(), kWave);  // wave-uniform
+    }
+    for (int row = 0; row < S; ++row) {
+      const uint32_t klen = sh_len[row];
+      if (klen > kHugeRow) reservoir(row, klen, (uint32_t)tid, T);  // workgroup-uniform
     }
   }
   __syncthreads();

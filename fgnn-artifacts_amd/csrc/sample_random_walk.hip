@@ -13,6 +13,8 @@
 // visit entry against the others by broadcast LDS reads -- no global hash table, no sort, no
 // atomics, no reset pass.  Edge offsets come from per-seed counts + one scan; the padded top-K
 // records are compacted by a second small kernel.
+#include <cstdlib>
+
 #include "fgnn_device.h"
 
 namespace fgnn {
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
     const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ input,
     size_t n_host, const uint32_t *d_n, size_t cap, uint32_t walk_len, double restart_prob, uint32_t num_walks,
     uint32_t K, uint32_t W, uint32_t *__restrict__ pad_dst, uint32_t *__restrict__ pad_cnt,
-    uint32_t *__restrict__ seed_cnt, uint64_t seed, uint64_t batch_key, uint32_t tag) {
+    uint32_t *__restrict__ seed_cnt, uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t ablate) {
   extern __shared__ uint32_t dyn[];
   const uint32_t P = num_walks * walk_len;
   const uint32_t G = (uint32_t)kWave / W;
@@ -76,6 +78,10 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
+  if (ablate & 1u) {  // profiling only (FGNN_RW_ABLATE): walks without the counting / ranking phases
+    if (sl == 0 && i < cap) seed_cnt[i] = 0u;
+    return;
+  }
 
   // ---- frequency: one lane per visit entry; repcnt[p] = visit count if p is the FIRST visit of its
   //      destination (its representative), else 0 ----
@@ -197,9 +203,10 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
+  const char *e_ab = getenv("FGNN_RW_ABLATE");  // profiling only; results are wrong when set
   hipLaunchKernelGGL(random_walk_topk_kernel, dim3(div_up(cap, seeds_per_wg)), dim3(kRwWaves * kWave), lds, st, indptr,
                      indices, input, num_input, d_num_input, cap, (uint32_t)walk_len, restart_prob, (uint32_t)num_walks,
-                     (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag);
+                     (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag, e_ab ? (uint32_t)atoi(e_ab) : 0u);
   hipLaunchKernelGGL(rw_sums_kernel, dim3(nb), dim3(kBlock), 0, st, seed_cnt, cap, sums);
   if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
   hipLaunchKernelGGL(rw_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, seed_cnt, cap, (uint32_t)K, pad_dst, pad_cnt,

@@ -73,6 +73,36 @@ def test_sampler_matches_oracle(hip, oracle, graph, kind, fanout):
 
 
 @pytest.mark.parametrize("kind", ["khop0", "khop2"])
+@pytest.mark.parametrize("fanout", [5, 25])
+def test_sampler_hub_rows(hip, oracle, kind, fanout):
+    """Rows of tens of thousands of entries next to short ones (R-MAT hubs): khop0 draws once per row element
+    (cuda_sampling_khop0.cu:41-90) -- rows beyond 4096 entries are walked by the whole workgroup, shorter ones by a wave."""
+    rng_np = np.random.default_rng(11)
+    num_node = 3000
+    deg = rng_np.integers(0, 40, size=num_node)
+    deg[[7, 8, 1500]] = [30000, 4097, 4096]  # two rows on the workgroup path, one exactly at the wave path's limit
+    deg[2999] = 100000
+    indptr = np.zeros(num_node + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng_np.integers(0, num_node, size=int(indptr[-1])).astype(np.uint32)
+    d_indptr, d_indices = dev(indptr), dev(indices.copy())
+    o_indices = indices.copy()
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    ofn = oracle.sample_khop0 if kind == "khop0" else oracle.sample_khop2
+    for call in range(2):
+        inp = np.concatenate([np.array([7, 2999, 8, 1500], dtype=np.uint32), _seeds(300, num_node - 1, seed=call)])
+        inp = np.unique(inp)[rng_np.permutation(len(np.unique(inp)))].astype(np.uint32)
+        out_src, out_dst, d_num = hip.sample_khop(kind, d_indptr, d_indices, dev(inp), fanout, SEED, 5 + call, 0,
+                                                  hip.SRC_GLOBAL)
+        o_src, o_dst = ofn(indptr, o_indices, inp, fanout, rng, 5 + call, 0)
+        ne = int(d_num.cpu()[0])
+        assert ne == len(o_dst)
+        np.testing.assert_array_equal(host_u32(out_dst, ne), o_dst)
+        np.testing.assert_array_equal(host_u32(out_src, ne), o_src)
+        np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.parametrize("kind", ["khop0", "khop2"])
 def test_sampler_edge_cases(hip, oracle, kind):
     # rows: 0,3,0,1,5,0,6 neighbours -- isolated nodes, rows shorter / equal / longer than the fanout
     indptr = np.array([0, 0, 3, 3, 4, 9, 9, 15], dtype=np.uint32)
@@ -263,10 +293,13 @@ def test_layered_pipeline_matches_oracle(hip, oracle, kind, fanouts, batch):
 
 
 @pytest.mark.parametrize("kind,fanouts,batch,dim", [("khop2", [25, 10], 3000, 128), ("khop0", [5, 10, 15], 200, 100),
-                                                    ("khop2", [3], 17, 4)])
+                                                    ("khop2", [3], 17, 4), ("khop2", [10, 5], 500, 25),
+                                                    ("khop2", [4, 4], 300, 3)])
 def test_batch_driver_matches_oracle(hip, oracle, kind, fanouts, batch, dim):
     """fgnn_sampler_sample + cache_index + extract (the C++ per-batch driver) against
-    oracle do_sample + get_miss_cache_index + extract, three batches in a row, last one short."""
+    oracle do_sample + get_miss_cache_index + extract, three batches in a row, last one short.
+    Row widths: multiples of 16 bytes (the label rows and the summary copy ride on the feature gather launch) and
+    100 / 12 bytes (element gather: label gather and summary copy are launches of their own)."""
     from fgnn_hip import synth
     num_node = 120000
     indptr, indices = synth.powerlaw_csr(num_node, 2000000, seed=6)
