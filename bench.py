@@ -768,6 +768,17 @@ def split_count(total, parts, index):
     return total // parts + (1 if index < total % parts else 0)
 
 
+def train_region_batches(steps, train_steps, trainers):
+    """(warm-up, timed) batches of the region with a training step per batch.  The trainers all-reduce their gradients
+    every step, so each of them must take the SAME number of batches -- a remainder would leave the trainers with one
+    batch more waiting for the others' all-reduce forever: both counts are multiples of the trainer count (the
+    reference pads the train set to equal shares for the same reason, dist_shuffler_aligned.cc:50-59)."""
+    t = max(trainers, 1)
+    timed = max(min(steps, train_steps) // t, 1) * t
+    warm = max(min(8, timed) // t, 1) * t
+    return warm, timed
+
+
 def pipeline_roles(world, samplers=None):
     s = samplers if samplers else default_samplers(world)
     if not (0 < s < world):
@@ -927,8 +938,7 @@ def run_pipeline_rank(args, rank, world):
         args.sample_type = w["sample_type"]
     bs = w["batch_size"]
     W, K = args.warmup, args.steps
-    K2 = 0 if (args.no_train_leg or args.rehearse) else min(K, args.train_steps)
-    K2W = min(8, K2)  # warm-up batches of the training region
+    K2W, K2 = (0, 0) if (args.no_train_leg or args.rehearse) else train_region_batches(K, args.train_steps, T)
     # ---- job-wide names from rank 0: shared-memory prefix (the processes have no common forking parent) and the
     # dataset directory
     obj = [None]

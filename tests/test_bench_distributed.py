@@ -91,6 +91,17 @@ def test_roles_and_shares():
             assert sum(bench.split_count(total, parts, i) for i in range(parts)) == total
 
 
+def test_training_region_gives_every_trainer_the_same_number_of_batches():
+    """gradient all-reduce per step: an uneven share deadlocks the trainers (seen with 1S+3T: 40 batches = 14+13+13)"""
+    import bench
+    for steps, train_steps in ((151, 40), (20, 40), (5, 40), (1, 40), (60, 20)):
+        for trainers in (1, 2, 3, 5, 6, 7):
+            warm, timed = bench.train_region_batches(steps, train_steps, trainers)
+            assert warm % trainers == 0 and timed % trainers == 0 and warm >= trainers and timed >= trainers
+            assert {bench.split_count(timed, trainers, i) for i in range(trainers)} == {timed // trainers}
+            assert timed <= max(min(steps, train_steps), trainers)
+
+
 def test_step_ranges_cover_epoch():
     import bench
     assert bench.local_step_range(151, 0, 2) == (0, 75) and bench.local_step_range(151, 1, 2) == (75, 76)
