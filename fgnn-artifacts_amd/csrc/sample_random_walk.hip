@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
     const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ input,
     size_t n_host, const uint32_t *d_n, size_t cap, uint32_t walk_len, double restart_prob, uint32_t num_walks,
     uint32_t K, uint32_t W, uint32_t *__restrict__ pad_dst, uint32_t *__restrict__ pad_cnt,
-    uint32_t *__restrict__ seed_cnt, uint64_t seed, uint64_t batch_key, uint32_t tag, uint32_t ablate) {
+    uint32_t *__restrict__ seed_cnt, uint64_t seed, uint64_t batch_key, uint32_t tag) {
   extern __shared__ uint32_t dyn[];
   const uint32_t P = num_walks * walk_len;
   const uint32_t G = (uint32_t)kWave / W;
@@ -78,28 +78,36 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
-  if (ablate & 1u) {  // profiling only (FGNN_RW_ABLATE): walks without the counting / ranking phases
-    if (sl == 0 && i < cap) seed_cnt[i] = 0u;
-    return;
+
+  // ---- compaction: walks end early (restart, dead ends), so about half of the P slots hold no visit; the two all-pairs
+  //      phases below cost O(m^2) on the m real visits instead of O(P^2).  Stable (first-visit order is the tie-break of
+  //      the top-K), in place: a round reads its W slots before it writes, and writes land at or below what it read ----
+  uint32_t m = 0;
+  for (uint32_t p0 = 0; p0 < P; p0 += W) {
+    const uint32_t p = p0 + sl;
+    const uint32_t v = p < P ? visited[p] : FGNN_EMPTY_KEY;
+    const unsigned long long live = __ballot(v != FGNN_EMPTY_KEY) & gmask;
+    if (v != FGNN_EMPTY_KEY) visited[m + (uint32_t)__popcll(live & ((1ull << lane) - 1ull))] = v;
+    m += (uint32_t)__popcll(live);
   }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
 
   // ---- frequency: one lane per visit entry; repcnt[p] = visit count if p is the FIRST visit of its
   //      destination (its representative), else 0 ----
   uint32_t kept = 0;
-  for (uint32_t p0 = 0; p0 < P; p0 += W) {
+  for (uint32_t p0 = 0; p0 < m; p0 += W) {
     const uint32_t p = p0 + sl;
     uint32_t c = 0;
-    if (p < P) {
+    if (p < m) {
       const uint32_t me = visited[p];
-      if (me != FGNN_EMPTY_KEY) {
-        bool rep = true;
-        for (uint32_t q = 0; q < P; ++q) {
-          const bool eq = visited[q] == me;
-          c += eq;
-          if (eq && q < p) rep = false;
-        }
-        if (!rep) c = 0;
+      bool rep = true;
+      for (uint32_t q = 0; q < m; ++q) {
+        const bool eq = visited[q] == me;
+        c += eq;
+        if (eq && q < p) rep = false;
       }
+      if (!rep) c = 0;
       repcnt[p] = c;
     }
     kept += (uint32_t)__popcll(__ballot(c != 0) & gmask);
@@ -108,13 +116,13 @@ __global__ __launch_bounds__(kRwWaves *kWave) void random_walk_topk_kernel(
   __threadfence_block();
 
   // ---- top-K: rank of a representative by (count desc, first position asc) ----
-  for (uint32_t p0 = 0; p0 < P; p0 += W) {
+  for (uint32_t p0 = 0; p0 < m; p0 += W) {
     const uint32_t p = p0 + sl;
-    if (p >= P || !valid) continue;
+    if (p >= m || !valid) continue;
     const uint32_t count = repcnt[p];
     if (count == 0) continue;
     uint32_t rank = 0;
-    for (uint32_t q = 0; q < P; ++q) {
+    for (uint32_t q = 0; q < m; ++q) {
       const uint32_t qc = repcnt[q];
       rank += (qc > count) || (qc == count && q < p);
     }
@@ -203,10 +211,9 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_done = true;
   }
-  const char *e_ab = getenv("FGNN_RW_ABLATE");  // profiling only; results are wrong when set
   hipLaunchKernelGGL(random_walk_topk_kernel, dim3(div_up(cap, seeds_per_wg)), dim3(kRwWaves * kWave), lds, st, indptr,
                      indices, input, num_input, d_num_input, cap, (uint32_t)walk_len, restart_prob, (uint32_t)num_walks,
-                     (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag, e_ab ? (uint32_t)atoi(e_ab) : 0u);
+                     (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag);
   hipLaunchKernelGGL(rw_sums_kernel, dim3(nb), dim3(kBlock), 0, st, seed_cnt, cap, sums);
   if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
   hipLaunchKernelGGL(rw_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, seed_cnt, cap, (uint32_t)K, pad_dst, pad_cnt,
