@@ -149,7 +149,7 @@ class Engine {
   int tdevice_ = -1;            // trainer-side device (arch5 trainer process, arch2-4 extractor)
   hipStream_t tstream_ = nullptr;
   // trainer: a batch being received / extracted (eng_engine.cc: TrainerIssue / TrainerComplete)
-  static constexpr int kExtractDepth = 3;
+  static constexpr int kExtractDepth = 4;
   struct ExtractCtx {
     hipStream_t st = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // brackets of the miss-row and cached-row gathers

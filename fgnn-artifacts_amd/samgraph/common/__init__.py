@@ -12,6 +12,11 @@ import sys
 
 _THIS = sys.modules[__name__]
 
+# The engine runs up to five HIP streams per process; the HIP runtime maps a process's streams onto 4 hardware queues
+# unless told otherwise, and reads the variable at its first call -- usually after this import (samgraph_config sets the
+# same default for C callers; a value set by the user wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def _enum(names, start=0):
     for i, n in enumerate(names):

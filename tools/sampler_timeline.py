@@ -11,6 +11,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as samgraph_config would, had this process not touched the GPU before it
 os.environ.setdefault("SAMGRAPH_DEVICE_RING_SLOTS", "170")
 os.environ.setdefault("SAMGRAPH_DEVICE_RING_DRAIN_S", "0.01")
 os.environ.setdefault("SAMGRAPH_EMPTY_FEAT", "24")
