@@ -396,10 +396,10 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
                                    s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream, &sl.scan_sample);
     else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
       // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
-      rc = fgnn_sample_random_walk(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
-                                   s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
-                                   d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
-                                   stream);
+      rc = fgnn::sample_random_walk_ex(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
+                                       s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
+                                       d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
+                                       stream, &sl.scan_sample);
     else {
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};

@@ -649,6 +649,13 @@ int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const ui
                                uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                                uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node,
                                const RankWs *rank);
+// fgnn_sample_random_walk with look-back descriptors: the edge offsets and the compacted output come from one launch
+// (scan == null: per-workgroup sums -> scan -> emit, as the C entry point)
+int sample_random_walk_ex(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,
+                          const uint32_t *d_num_input, size_t num_input_cap, size_t walk_len, double restart_prob,
+                          size_t num_walks, size_t K, uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data,
+                          size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
+                          size_t ws_bytes, void *stream, ScanWsHost *scan);
 // k-hop sampling with the dedup insert fused into the sampler (the engine's path): as fgnn_sample_khop0/2
 // with FGNN_SRC_LOCAL, and every emitted edge e is inserted into `ht` with value PENDING|e; its bucket goes
 // to ws[e] (the pos[] array hashtable_fill_duplicates_ex(already_inserted = true) expects at ws).

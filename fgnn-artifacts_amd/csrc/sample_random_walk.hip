@@ -167,6 +167,57 @@ __global__ __launch_bounds__(kBlock) void rw_emit_kernel(const uint32_t *__restr
   }
 }
 
+// rw_sums_kernel -> scan -> rw_emit_kernel in ONE launch (batch driver): a workgroup owns 256 x IPT consecutive seeds, its
+// output offset is the prefix over the earlier workgroups' edge counts (fgnn_device.h, single-pass prefix with helping:
+// a missing tile's count is re-summed from seed_cnt, which nothing writes while this kernel runs)
+template <int IPT>
+__global__ __launch_bounds__(kBlock) void rw_emit_sp_kernel(const uint32_t *__restrict__ input,
+                                                            const uint32_t *__restrict__ seed_cnt, size_t cap, uint32_t K,
+                                                            const uint32_t *__restrict__ pad_dst,
+                                                            const uint32_t *__restrict__ pad_cnt,
+                                                            uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
+                                                            uint32_t *__restrict__ out_data, int src_mode, ScanWs scan,
+                                                            size_t *d_num_out) {
+  __shared__ uint32_t sh[kWavesPerBlock];
+  __shared__ uint32_t sh_tile[2];
+  const uint32_t tile = blockIdx.x;
+  auto tile_sum = [&](uint32_t tl, uint32_t *c) -> uint32_t {
+    const size_t i0 = ((size_t)tl * kBlock + threadIdx.x) * IPT;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const uint32_t cc = i0 + q < cap ? seed_cnt[i0 + q] : 0u;
+      if (c) c[q] = cc;
+      sum += cc;
+    }
+    return sum;
+  };
+  uint32_t c[IPT];
+  const uint32_t sum = tile_sum(tile, c);
+  uint32_t tot;
+  const uint32_t lo = block_exclusive_scan<kWavesPerBlock>(sum, sh, &tot);
+  scan_publish_aggregate(scan, tile, tot);
+  const uint32_t before = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
+    uint32_t tot_m;
+    (void)block_exclusive_scan<kWavesPerBlock>(tile_sum(m, nullptr), sh, &tot_m);
+    return tot_m;
+  });
+  if (tile == gridDim.x - 1 && threadIdx.x == 0 && d_num_out) *d_num_out = (size_t)before + tot;
+  size_t w = (size_t)before + lo;
+  const size_t i0 = ((size_t)tile * kBlock + threadIdx.x) * IPT;
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    const size_t i = i0 + q;
+    const uint32_t src = src_mode == FGNN_SRC_LOCAL ? (uint32_t)i : (c[q] ? input[i] : 0u);
+    for (uint32_t k = 0; k < c[q]; ++k) {
+      out_src[w + k] = src;
+      out_dst[w + k] = pad_dst[i * K + k];
+      out_data[w + k] = pad_cnt[i * K + k];
+    }
+    w += c[q];
+  }
+}
+
 }  // namespace
 }  // namespace fgnn
 
@@ -183,6 +234,16 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
                                        uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data, size_t *d_num_out,
                                        int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
                                        size_t ws_bytes, void *stream) {
+  return fgnn::sample_random_walk_ex(indptr, indices, input, num_input, d_num_input, num_input_cap, walk_len,
+                                     restart_prob, num_walks, K, out_src, out_dst, out_data, d_num_out, src_mode, seed,
+                                     batch_key, layer, ws, ws_bytes, stream, nullptr);
+}
+
+int fgnn::sample_random_walk_ex(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,
+                                const uint32_t *d_num_input, size_t num_input_cap, size_t walk_len, double restart_prob,
+                                size_t num_walks, size_t K, uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data,
+                                size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer,
+                                void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan) {
   auto st = static_cast<hipStream_t>(stream);
   size_t cap = d_num_input ? num_input_cap : num_input;
   if (walk_len == 0 || num_walks == 0 || K == 0) return FGNN_EINVAL;
@@ -214,6 +275,21 @@ extern "C" int fgnn_sample_random_walk(const uint32_t *indptr, const uint32_t *i
   hipLaunchKernelGGL(random_walk_topk_kernel, dim3(div_up(cap, seeds_per_wg)), dim3(kRwWaves * kWave), lds, st, indptr,
                      indices, input, num_input, d_num_input, cap, (uint32_t)walk_len, restart_prob, (uint32_t)num_walks,
                      (uint32_t)K, W, pad_dst, pad_cnt, seed_cnt, seed, batch_key, tag);
+  if (scan) {  // batch driver: counts -> offsets -> compacted COO in one launch
+    constexpr size_t kSinglePassTiles = 1536;
+    const int ipt = nb <= kSinglePassTiles ? 1 : nb <= 4 * kSinglePassTiles ? 4 : nb <= 16 * kSinglePassTiles ? 16 : 0;
+    const size_t grid = ipt ? div_up(cap, (size_t)kBlock * ipt) : 0;
+    if (ipt && grid <= scan->ws.max_tiles) {
+#define FGNN_RW_EMIT(I)                                                                                              \
+  hipLaunchKernelGGL((rw_emit_sp_kernel<I>), dim3(grid), dim3(kBlock), 0, st, input, seed_cnt, cap, (uint32_t)K, pad_dst, \
+                     pad_cnt, out_src, out_dst, out_data, src_mode, scan->next(0, grid), d_num_out)
+      if (ipt == 1) FGNN_RW_EMIT(1);
+      else if (ipt == 4) FGNN_RW_EMIT(4);
+      else FGNN_RW_EMIT(16);
+#undef FGNN_RW_EMIT
+      return launch_status(__func__);
+    }
+  }
   hipLaunchKernelGGL(rw_sums_kernel, dim3(nb), dim3(kBlock), 0, st, seed_cnt, cap, sums);
   if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
   hipLaunchKernelGGL(rw_emit_kernel, dim3(nb), dim3(kBlock), 0, st, input, seed_cnt, cap, (uint32_t)K, pad_dst, pad_cnt,

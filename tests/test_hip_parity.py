@@ -435,6 +435,36 @@ def test_batch_driver_other_samplers(hip, oracle, mode):
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
 
 
+@pytest.mark.parametrize("batch", [12000, 44000])
+def test_batch_driver_random_walk_large_capacities(hip, oracle, batch):
+    """PinSAGE walks through the batch driver at worst-case frontier capacities of 432 K and 1.58 M seeds: the one-launch
+    emit (rw_emit_sp_kernel) then gives a lane 4 / 16 consecutive seeds (150-seed batches elsewhere: one)."""
+    from fgnn_hip import synth
+    num_node = 60000
+    indptr, indices = synth.powerlaw_csr(num_node, 600000, seed=37)
+    fanouts = [5, 5, 5]
+    sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.RANDOM_WALK, seed=SEED,
+                          walk_len=3, num_walks=4, restart_prob=0.5)
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    seeds = _seeds(batch, num_node, seed=80)
+    sampler.sample(dev(seeds), 3, bt)
+    bt.finish()
+    m = bt.wait()
+    want = oracle.do_sample(indptr, indices.copy(), seeds, fanouts, oracle.RANDOM_WALK, rng, 3, oht, walk_len=3,
+                            num_walks=4, num_neighbor=5, restart_prob=0.5)
+    assert m.overflow == 0
+    for li in range(3):
+        row, col, nsrc, ndst = bt.graph(li)
+        g = want["graphs"][li]
+        assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+        np.testing.assert_array_equal(host_u32(row), g["row"])
+        np.testing.assert_array_equal(host_u32(col), g["col"])
+        np.testing.assert_array_equal(host_u32(bt.graph_data(li)), g["data"])
+    np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
 @pytest.mark.parametrize("kind", ["weighted_khop_prefix", "khop1"])
 @pytest.mark.parametrize("batch", [150, 8000, 10000])
 def test_batch_driver_bitmap_seed_ranking(hip, oracle, kind, batch):
