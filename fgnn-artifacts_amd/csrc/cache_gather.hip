@@ -105,9 +105,10 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
                                                                    uint32_t *__restrict__ cache_src,
                                                                    uint32_t *__restrict__ cache_dst,
                                                                    uint32_t *__restrict__ d_counts, ScanWs scan,
-                                                                   uint32_t ablate) {
+                                                                   uint32_t ablate, unsigned long long *stamp) {
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile[2];
+  if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = wall_clock64();  // fgnn_batch_meta::t_sampled
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);  // cap < 2^32 (host check)
   const uint32_t per_round = kBlock * gridDim.x;
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
@@ -315,13 +316,14 @@ extern "C" int fgnn_get_miss_cache_index(const uint32_t *table, const uint32_t *
                                          uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst,
                                          uint32_t *d_counts, void *ws, size_t ws_bytes, void *stream) {
   return fgnn::get_miss_cache_index_ex(table, nodes, num_nodes, d_num_nodes, num_nodes_cap, miss_src, miss_dst,
-                                       cache_src, cache_dst, d_counts, ws, ws_bytes, stream, nullptr);
+                                       cache_src, cache_dst, d_counts, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                                   const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
                                   uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts,
-                                  void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan) {
+                                  void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan,
+                                  unsigned long long *stamp) {
   auto s = static_cast<hipStream_t>(stream);
   size_t cap = d_num_nodes ? num_nodes_cap : num_nodes;
   if (!d_counts) return FGNN_EINVAL;
@@ -354,7 +356,7 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
       if (const char *e_g = getenv("FGNN_SPLIT_GRID")) grid = (size_t)atoi(e_g) < grid ? (size_t)atoi(e_g) : grid;
       hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid), dim3(kBlock), 0, s, table, nodes, num_nodes,
                          d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
-                         scan->next(2, grid), ablate);
+                         scan->next(2, grid), ablate, stamp);
       return launch_status(__func__);
     }
   }

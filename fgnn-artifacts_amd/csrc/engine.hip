@@ -475,7 +475,8 @@ extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table
   // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
   return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
                                        b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
-                                       b->ws_bytes, stream, b->scan);
+                                       b->ws_bytes, stream, b->scan,
+                                       reinterpret_cast<unsigned long long *>(&b->d_meta->t_sampled));
 }
 
 extern "C" int fgnn_batch_enable_timing(fgnn_batch *b, int on) {

@@ -553,9 +553,12 @@ void Engine::PublishSlot(int slot) {
   Timer t_pub;
   SAM_CHECK_EQ(m.overflow, 0u) << "batch exceeded its buffers";
   mq_->SimpleSend(s.mq_key);
+  // sample / cache-index times from the kernels' own time stamps in the summary (10 ns ticks): three event records and
+  // their bubbles per batch less on the sampler's streams
   float ms_sample = 0, ms_index = 0, ms_send = 0;
-  (void)hipEventElapsedTime(&ms_sample, s.e0, s.e1);
-  (void)hipEventElapsedTime(&ms_index, s.e1, s.e2);
+  const uint64_t t_end_sample = m.t_sampled ? m.t_sampled : m.t_closed;
+  if (m.t_start && t_end_sample > m.t_start) ms_sample = (float)((t_end_sample - m.t_start) * 1e-5);
+  if (m.t_sampled && m.t_closed > m.t_sampled) ms_index = (float)((m.t_closed - m.t_sampled) * 1e-5);
   auto &P = Profiler::Get();
   size_t edges = 0;
   for (uint32_t l = 0; l < m.num_layers; ++l) edges += m.num_edge[l];
@@ -592,12 +595,9 @@ void Engine::SampleOnceArch5() {
   sstat_.slot_wait += t_wait.Passed();
   s.started = Timer();
   s.key = key;
-  SAM_HIP(hipEventRecord(s.e0, s.st));
   SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, s.st));
-  SAM_HIP(hipEventRecord(s.e1, s.st));
   const bool use_cache = RC().UseGPUCache();
   if (use_cache) SAM_FGNN(fgnn_batch_cache_index(s.fb, d_cache_table_, s.st));
-  SAM_HIP(hipEventRecord(s.e2, s.st));
   // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
   void *slot = mq_->GetPtr(&s.mq_key);
   PackArgs a;

@@ -75,9 +75,9 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
   // number lives in scratch memory (168 bytes per lane), and a launch that needs scratch costs ~15 us of set-up on top
   // of its work -- that, not the copy, was this kernel's duration (16-19 us for a 5.5 MB message)
   const fgnn_batch_meta *m = a.d_meta;
-  // the summary for the host (every kernel that writes it is earlier in the stream): no copy command behind this launch
-  if (a.h_meta && blockIdx.x == gridDim.x - 1 && threadIdx.x < sizeof(fgnn_batch_meta) / 4)
-    a.h_meta[threadIdx.x] = reinterpret_cast<const uint32_t *>(m)[threadIdx.x];
+  // this kernel closes the batch: its start time goes into the summary (t_closed) ...
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    const_cast<fgnn_batch_meta *>(m)->t_closed = wall_clock64();
   if (threadIdx.x == 0) {
     const uint32_t num_layers = m->num_layers, num_input = m->num_input, num_output = m->num_output, num_miss = m->num_miss;
     // total size first: an oversized message is flagged, never written past the slot
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
     hn = n;
   }
   __syncthreads();
+  // ... and the summary goes to the host from here (every other kernel that writes it is earlier in the stream; the
+  // stamp above is this workgroup's own store, ordered by the barrier): no copy command behind this launch
+  if (a.h_meta && blockIdx.x == gridDim.x - 1 && threadIdx.x < sizeof(fgnn_batch_meta) / 4)
+    a.h_meta[threadIdx.x] = reinterpret_cast<const volatile uint32_t *>(m)[threadIdx.x];
   if (blockIdx.x == 0 && (int)threadIdx.x < hn) {
     // the host slot always gets the headers (the receiver's CPU parses them there); the device-ring slot gets them
     // too: it is a complete message (copied back to the host slot as it is when a receiver cannot map the ring)

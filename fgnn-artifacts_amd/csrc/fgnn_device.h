@@ -616,7 +616,7 @@ int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const 
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,
                             uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts, void *ws, size_t ws_bytes,
-                            void *stream, ScanWsHost *scan);
+                            void *stream, ScanWsHost *scan, unsigned long long *stamp = nullptr);
 // fgnn_sample_weighted_khop_hash_dedup with the slot's look-back descriptors (scan == null: descriptors in ws)
 int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
                       const uint32_t *alias_table, const uint32_t *input, size_t num_input, const uint32_t *d_num_input,

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void ht_start_batch_kernel(HtView t, const 
       m.num_layers = num_layers;
       m.num_output = (uint32_t)n;
       m.num_input = (uint32_t)n;
+      m.t_start = wall_clock64();
       *meta = m;
     }
   }

@@ -113,6 +113,9 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         m->num_miss = 0;
         m->num_cache = 0;
         m->overflow = 0;
+        m->t_start = wall_clock64();
+        m->t_sampled = 0;
+        m->t_closed = 0;
       }
     } else {
       fuse.d_num_items[1] = fuse.d_num_items[0];

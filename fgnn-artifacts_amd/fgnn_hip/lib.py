@@ -423,7 +423,7 @@ class BatchMeta(C.Structure):
     _fields_ = [("key", C.c_uint64), ("num_edge", C.c_uint64 * MAX_LAYERS), ("num_src", C.c_uint32 * MAX_LAYERS),
                 ("num_dst", C.c_uint32 * MAX_LAYERS), ("num_layers", C.c_uint32), ("num_input", C.c_uint32),
                 ("num_output", C.c_uint32), ("num_miss", C.c_uint32), ("num_cache", C.c_uint32),
-                ("overflow", C.c_uint32)]
+                ("overflow", C.c_uint32), ("t_start", C.c_uint64), ("t_sampled", C.c_uint64), ("t_closed", C.c_uint64)]
 
 
 _TORCH_OF = {F32: torch.float32, F64: torch.float64, F16: torch.float16, U8: torch.uint8, I32: torch.int32,

@@ -295,6 +295,12 @@ typedef struct fgnn_batch_meta_s {
   uint32_t num_miss, num_cache;
   uint32_t overflow;                  /* non-zero: the batch is invalid (a capacity was exceeded, or a cross-workgroup
                                          wait inside a single-pass kernel timed out) -- callers must not use it */
+  /* Device time stamps (the GPU's 100 MHz wall clock, 10 ns ticks) taken by the kernels themselves, so that a caller
+   * who wants the reference's per-batch sample / cache-index times (kLogL1SampleTime, kLogL3CacheGetIndexTime) needs
+   * no event records around the calls: first sampler launch of the batch started; cache-index split started
+   * (= sampling done; 0 if fgnn_batch_cache_index was not called); a caller's closing kernel started (written by that
+   * kernel, e.g. the engine's pack kernel; 0 otherwise). */
+  uint64_t t_start, t_sampled, t_closed;
 } fgnn_batch_meta;
 
 fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);

@@ -39,6 +39,11 @@ try:
     dt = time.perf_counter() - t0
     edges = sum(be.sam.get_log_step_value(0, s, be.sam.kLogL1NumSample) for s in range(n))
     print("sampler alone: %d batches in %.4f s = %.1f us per batch, %.3e sampled edges/s" % (n, dt, dt / n * 1e6, edges / dt))
+    sam = be.sam
+    ts = [sam.get_log_step_value(0, s, sam.kLogL1SampleTime) for s in range(n)]
+    ti = [sam.get_log_step_value(0, s, sam.kLogL3CacheGetIndexTime) for s in range(n)]
+    print("per batch, from the kernels' own time stamps: sample %.1f us (median), cache index %.1f us" % (
+        sorted(ts)[n // 2] * 1e6, sorted(ti)[n // 2] * 1e6))
     be.shutdown()
 finally:
     shutil.rmtree(out_dir, ignore_errors=True)
