@@ -571,6 +571,16 @@ def run_single(args):
                                                     steps_per_epoch, next_seq, run_region, mode, leg, metas, cached_ms)
         except Exception as e:  # the headline must not be lost to a problem in a secondary measurement
             extract_leg = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- the epoch WITH training on this one GPU (config 2's shape: one MI355X samples, extracts and trains): the
+    # next batch's sample + extract chain runs on a side stream under the current batch's GraphSAGE step
+    # (examples/models.py, hidden 256, fused Adam), like the reference's arch3 threads
+    train_leg = None
+    if not args.timed_only and not args.no_train_leg and args.sample_type != "random_walk":
+        try:
+            train_leg, next_seq = run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat, label,
+                                                steps_per_epoch, next_seq, mode)
+        except Exception as e:
+            train_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     metas[:] = metas_t
     gather_ms[:] = gather_t
 
@@ -632,9 +642,13 @@ def run_single(args):
                          "sample_plus_extract_cache_0.2_host_misses":
                              steps_per_epoch * extract_leg["ms_per_step"] * 1e-3
                              if extract_leg and "ms_per_step" in extract_leg else None,
-                         "note": f"{steps_per_epoch} steps/epoch x ms_per_step; no training step -- the reference's "
-                                 "Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s); the epoch WITH "
-                                 "training is measured by the N >= 2 runs (trainer processes)"},
+                         "with_training": steps_per_epoch * train_leg["ms_per_step"] * 1e-3
+                             if train_leg and "ms_per_step" in train_leg else None,
+                         "note": f"{steps_per_epoch} steps/epoch x ms_per_step; sample_plus_extract = the reference's "
+                                 "Table 5 'Sample' + 'Extract' columns (0.45 s + 0.35 s on V100s); with_training = the "
+                                 "same batches with a GraphSAGE step each on this GPU (train_leg; the reference: 0.28 s "
+                                 "on 8 V100s, exp/table4); the factored pipeline's epoch is measured by the N >= 2 runs"},
+        "train_leg": train_leg,
         "sample_stage": sample_stage,
         "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps,
         "input_nodes_per_step": rows / args.steps,
@@ -757,6 +771,58 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
 
 # ----------------------------------------------------------------------------------------------------------------------
 # N >= 2: the factored pipeline, one process per GPU
+
+def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat, label, steps_per_epoch, next_seq, mode):
+    """K2 batches: sample + extract (all features in HBM) on a side stream, one batch ahead of a GraphSAGE training step
+    on torch's current stream.  Returns ({ms_per_step, ...}, next sequence number)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from models import MODELS
+    from samgraph.torch.adapter import CooBlock
+    L = len(w["fanout"])
+    model = MODELS["graphsage"](w["feat_dim"], 256, w["num_class"], L, 0.5).to(dev)
+    loss_fcn = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True)
+    model.train()
+    mode[0] = "full"
+    warm, timed = train_region_batches(args.steps, args.train_steps, 1)
+    st = streams[0]
+    bufs = batches[:2]
+
+    def enqueue(i):
+        step, seeds = seeds_of(i)
+        sampler.run_batch(i, seeds, step, bufs[i % 2], table, feat, label, stream=st)
+
+    def region(first, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enqueue(first)
+        for j in range(n):
+            bt = bufs[(first + j) % 2]
+            m = bt.wait()
+            assert not m.overflow
+            blocks = []
+            for l in range(L):
+                row, col, nsrc, ndst = bt.graph(l)
+                blocks.append(CooBlock(row, col, nsrc, ndst))
+            x, y = bt.feat(), bt.label()
+            # the batch's tensors are read by the step below; the next batch goes to the OTHER buffer
+            if j + 1 < n:
+                enqueue(first + j + 1)
+            loss = loss_fcn(model(blocks, x), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.current_stream().synchronize()
+        return time.perf_counter() - t0
+
+    region(next_seq, warm)  # untimed: GEMM kernel selection, optimizer state, lazily loaded code objects
+    next_seq += warm
+    dt = region(next_seq, timed)
+    next_seq += timed
+    return {"ms_per_step": dt / timed * 1e3, "steps": timed,
+            "what": "sample + extract of batch k+1 on a side stream under the GraphSAGE step of batch k (examples/models.py: "
+                    f"{L} SAGEConv layers, hidden 256, fused Adam; aggregation by fgnn_block_aggregate), one GPU"}, next_seq
+
 
 def default_samplers(n_gpus):
     """1S+1T at 2 GPUs, 2S+6T at 8 (exp/table4/run.py:329-330 for GraphSAGE / papers100M); one sampler below 8"""
@@ -1199,7 +1265,7 @@ def parse_args(argv=None):
                     help="N=1: HIP streams each host thread rotates over (batches in flight = threads x this); "
                          "measured on MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
     ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
-    ap.add_argument("--no-train-leg", action="store_true", help="N>=2: skip the region with a training step per batch")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the region with a training step per batch")
     ap.add_argument("--train-steps", type=int, default=40, help="N>=2: batches of the training region (<= --steps)")
     ap.add_argument("--decoupled", action="store_true",
                     help="N>=2 diagnostic (one-GPU development box, where sampler and trainer ranks share the GPU): the "
