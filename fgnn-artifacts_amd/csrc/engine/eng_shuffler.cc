@@ -1,5 +1,7 @@
 #include "eng_shuffler.h"
 
+#include <utility>
+
 namespace sam {
 
 void ShuffleMinstd0(uint32_t *data, size_t n, uint64_t seed) {
@@ -80,11 +82,18 @@ Shuffler::Shuffler(const uint32_t *train_set, size_t num_data, size_t num_epoch,
   dataset_offset_ = p.dataset_offset;
   last_batch_size_ = p.last_batch_size;
   cur_step_ = num_step_;
+  SAM_HIP(hipGetDevice(&device_));
   SAM_HIP(hipMalloc(&d_data_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_next_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
+  SAM_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));  // the helper's own: no null-stream semantics
+  if (num_epoch_ > 0) Prepare(0);  // epoch 0's permutation is ready by the time the first batch is asked for
 }
 
 Shuffler::~Shuffler() {
+  if (prep_.joinable()) prep_.join();
   if (d_data_) (void)hipFree(d_data_);
+  if (d_next_) (void)hipFree(d_next_);
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (d_sanity_bits_) (void)hipFree(d_sanity_bits_);
   if (d_sanity_flags_) (void)hipFree(d_sanity_flags_);
 }
@@ -98,6 +107,18 @@ void Shuffler::EnableSanityCheck(size_t num_node) {
   SAM_HIP(hipMemset(d_sanity_flags_, 0, sizeof(uint32_t)));
 }
 
+void Shuffler::Prepare(uint64_t epoch) {
+  prep_ = std::thread([this, epoch] {
+    next_ = data_;                                           // cumulative: epoch e+1 shuffles epoch e's array
+    ShuffleMinstd0(next_.data(), num_data_, epoch);          // seed = epoch: every sampler gets the same permutation
+    SAM_HIP(hipSetDevice(device_));
+    // d_next_ held the epoch before the current one: its batches were flushed before the current epoch began
+    SAM_HIP(hipMemcpyAsync(d_next_, next_.data() + dataset_offset_, local_size_ * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, copy_stream_));
+    SAM_HIP(hipStreamSynchronize(copy_stream_));
+  });
+}
+
 void Shuffler::ReShuffle() {
   if (!initialized_) {
     cur_epoch_ = 0;
@@ -107,12 +128,15 @@ void Shuffler::ReShuffle() {
   }
   cur_step_ = 0;
   if (cur_epoch_ >= num_epoch_) return;
-  ShuffleMinstd0(data_.data(), num_data_, cur_epoch_);  // seed = epoch: every sampler gets the same permutation
-  SAM_HIP(hipMemcpyAsync(d_data_, data_.data() + dataset_offset_, local_size_ * sizeof(uint32_t),
-                         hipMemcpyHostToDevice, stream_));
-  if (d_sanity_bits_)  // a new epoch may hand every id out again (dist_shuffler.cc:139-144)
+  SAM_CHECK(prep_.joinable());
+  prep_.join();  // normally long done
+  data_.swap(next_);
+  std::swap(d_data_, d_next_);
+  if (d_sanity_bits_) {  // a new epoch may hand every id out again (dist_shuffler.cc:139-144)
     SAM_HIP(hipMemsetAsync(d_sanity_bits_, 0, fgnn_sanity_map_bytes(sanity_num_node_), stream_));
-  SAM_HIP(hipStreamSynchronize(stream_));
+    SAM_HIP(hipStreamSynchronize(stream_));
+  }
+  if (cur_epoch_ + 1 < num_epoch_) Prepare(cur_epoch_ + 1);
 }
 
 bool Shuffler::GetBatch(const uint32_t **d_batch, size_t *size) {
