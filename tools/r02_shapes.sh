@@ -13,6 +13,6 @@ for wl in twitter uk-2006-05; do
   tail -3 gpurun_out/${tag}_timeline_serial_$wl.txt
 done
 for st in khop0 khop1 weighted_khop weighted_khop_hash_dedup; do
-  timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-extract-leg --sample-type $st > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err
+  timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-extract-leg --no-train-leg --sample-type $st > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err
   echo "$st $(python3 tools/show_bench.py gpurun_out/ab_tmp.json | grep -E '\"value\"|\"ms_per_step\"|edges_per_step' | head -3 | tr -d '\n')"
 done | tee gpurun_out/${tag}_sample_types.txt
