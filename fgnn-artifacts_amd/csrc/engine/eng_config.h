@@ -41,13 +41,15 @@ struct RunConfig {
   size_t option_empty_feat = 0;
   size_t mq_budget_bytes = 8ull << 30;  // SAMGRAPH_MQ_BYTES: total size of the shared queue
   // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h).  Unset: 4 where sampler and
-  // extractor share a process (arch2-4, arch6: a plain device pointer), 16 for arch5 (mapped by the trainers with
-  // hipIpc; a trainer that cannot map it makes the whole job fall back to the host ring); 64 x ~46 MB of HBM at
-  // [25,10] x 8000
+  // extractor share a process (arch2-4, arch6: a plain device pointer); for arch5 as many as the host ring has slots
+  // (170 x ~46 MB = 7.8 GB of the 288 at [25,10] x 8000; mapped by the trainers with hipIpc, a trainer that cannot map
+  // it makes the whole job fall back to the host ring): whenever the trainers are the slower side the queue fills up,
+  // and with fewer device slots than queue slots the surplus messages would travel through pinned host memory -- over
+  // the same host link the trainers' miss rows need
   long device_ring_slots = -1;
   size_t DeviceRingSlots() const {
     if (device_ring_slots >= 0) return (size_t)device_ring_slots;
-    return run_arch == kArch5 ? 64 : 4;
+    return run_arch == kArch5 ? 170 : 4;
   }
 
   bool UseGPUCache() const { return cache_percentage > 0 && run_arch != kArch1; }  // run_config.h:84-86
