@@ -41,6 +41,7 @@ bool MemoryQueue::CreateDeviceRing(int ring, uint32_t slots) {
   SAM_CHECK(ring >= 0 && ring < kMaxRings && !owns_ring_[ring]);
   if (slots == 0) return false;
   if (slots > (uint32_t)kMaxRingSlots) slots = kMaxRingSlots;
+  if (slots > meta_->max_size) slots = (uint32_t)meta_->max_size;  // never more messages in flight than queue slots
   RingInfo &r = meta_->rings[ring];
   uint32_t made = 0;
   for (; made < slots; ++made) {
