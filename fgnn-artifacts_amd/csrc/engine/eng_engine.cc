@@ -629,9 +629,8 @@ void Engine::SampleOnceArch5() {
   pub_cv_.notify_all();
   sstat_.enqueue += s.started.Passed();
   ++sstat_.n;
-  // the next call reshuffles the seed array on the device: every batch reading it must be through (the reference
-  // flushes at the same point, dist_loops_arch5.cc:131-137)
-  if (shuffler_->IsLastBatch()) PublishPending();
+  // (the reference drains its pipeline at the end of an epoch because the next call reshuffles the seed array in place,
+  // dist_loops_arch5.cc:131-137; the shuffler here keeps the previous epoch's device array alive instead)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -102,6 +102,9 @@ class Engine {
   uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_step_ + step; }
   Dataset &Data() { return ds_; }
   void ForwardBarrier() { outer_counter_++; }
+  // sample_once only enqueues a batch; its profiler values appear when the publisher thread has published it.  The
+  // profiler getters / reports of the C ABI call this first: everything enqueued so far is published (and logged).
+  void SyncPublished() { if (publish_thread_.joinable()) PublishPending(); }
   // SAMGRAPH_EMPTY_FEAT=k: the feature table holds 2^k rows, node ids are masked before indexing it (the reference's
   // mock extraction, cpu_extraction.cc:47-62)
   uint32_t FeatRowMask() const {

@@ -72,18 +72,32 @@ double samgraph_get_log_init_value(int item) {
 }
 double samgraph_get_log_step_value(uint64_t epoch, uint64_t step, int item) {
   SAM_CHECK_LT(item, kNumLogStepItems);
+  Engine::Get().SyncPublished();
   return Profiler::Get().GetLogStepValue(Engine::Get().BatchKey(epoch, step), item);
 }
 double samgraph_get_log_epoch_value(uint64_t epoch, int item) {
   SAM_CHECK_LT(item, kNumLogEpochItems);
+  Engine::Get().SyncPublished();
   return Profiler::Get().GetLogEpochValue(epoch, item);
 }
 
 void samgraph_report_init(void) { Profiler::Get().ReportInit(); }
-void samgraph_report_step(uint64_t epoch, uint64_t step) { Profiler::Get().ReportStep(epoch, step); }
-void samgraph_report_step_average(uint64_t epoch, uint64_t step) { Profiler::Get().ReportStepAverage(epoch, step); }
-void samgraph_report_epoch(uint64_t epoch) { Profiler::Get().ReportEpoch(epoch); }
-void samgraph_report_epoch_average(uint64_t epoch) { Profiler::Get().ReportEpochAverage(epoch); }
+void samgraph_report_step(uint64_t epoch, uint64_t step) {
+  Engine::Get().SyncPublished();
+  Profiler::Get().ReportStep(epoch, step);
+}
+void samgraph_report_step_average(uint64_t epoch, uint64_t step) {
+  Engine::Get().SyncPublished();
+  Profiler::Get().ReportStepAverage(epoch, step);
+}
+void samgraph_report_epoch(uint64_t epoch) {
+  Engine::Get().SyncPublished();
+  Profiler::Get().ReportEpoch(epoch);
+}
+void samgraph_report_epoch_average(uint64_t epoch) {
+  Engine::Get().SyncPublished();
+  Profiler::Get().ReportEpochAverage(epoch);
+}
 void samgraph_report_node_access(void) {}  // SAMGRAPH_LOG_NODE_ACCESS analysis is an offline study (profiler.cc:568-866)
 
 void samgraph_trace_step_begin(uint64_t key, int item, uint64_t ts) { Profiler::Get().TraceStep(key, item, ts, true); }

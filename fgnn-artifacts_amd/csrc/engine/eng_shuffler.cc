@@ -85,6 +85,7 @@ Shuffler::Shuffler(const uint32_t *train_set, size_t num_data, size_t num_epoch,
   SAM_HIP(hipGetDevice(&device_));
   SAM_HIP(hipMalloc(&d_data_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
   SAM_HIP(hipMalloc(&d_next_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
+  SAM_HIP(hipMalloc(&d_prev_, (local_size_ ? local_size_ : 1) * sizeof(uint32_t)));
   SAM_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));  // the helper's own: no null-stream semantics
   if (num_epoch_ > 0) Prepare(0);  // epoch 0's permutation is ready by the time the first batch is asked for
 }
@@ -93,6 +94,7 @@ Shuffler::~Shuffler() {
   if (prep_.joinable()) prep_.join();
   if (d_data_) (void)hipFree(d_data_);
   if (d_next_) (void)hipFree(d_next_);
+  if (d_prev_) (void)hipFree(d_prev_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (d_sanity_bits_) (void)hipFree(d_sanity_bits_);
   if (d_sanity_flags_) (void)hipFree(d_sanity_flags_);
@@ -112,7 +114,7 @@ void Shuffler::Prepare(uint64_t epoch) {
     next_ = data_;                                           // cumulative: epoch e+1 shuffles epoch e's array
     ShuffleMinstd0(next_.data(), num_data_, epoch);          // seed = epoch: every sampler gets the same permutation
     SAM_HIP(hipSetDevice(device_));
-    // d_next_ held the epoch before the current one: its batches were flushed before the current epoch began
+    // d_next_ held the epoch BEFORE the previous one: a whole epoch has been sampled since its last batch was enqueued
     SAM_HIP(hipMemcpyAsync(d_next_, next_.data() + dataset_offset_, local_size_ * sizeof(uint32_t),
                            hipMemcpyHostToDevice, copy_stream_));
     SAM_HIP(hipStreamSynchronize(copy_stream_));
@@ -131,7 +133,10 @@ void Shuffler::ReShuffle() {
   SAM_CHECK(prep_.joinable());
   prep_.join();  // normally long done
   data_.swap(next_);
-  std::swap(d_data_, d_next_);
+  uint32_t *oldest = d_prev_;
+  d_prev_ = d_data_;  // its last batches may still be in flight
+  d_data_ = d_next_;
+  d_next_ = oldest;
   if (d_sanity_bits_) {  // a new epoch may hand every id out again (dist_shuffler.cc:139-144)
     SAM_HIP(hipMemsetAsync(d_sanity_bits_, 0, fgnn_sanity_map_bytes(sanity_num_node_), stream_));
     SAM_HIP(hipStreamSynchronize(stream_));

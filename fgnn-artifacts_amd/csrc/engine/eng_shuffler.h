@@ -49,10 +49,13 @@ class Shuffler {
   // The reference shuffles on the host at every epoch boundary while the GPU waits (dist_shuffler.cc:98-137): 9 ms for
   // papers100M's 1.2 M train ids -- half of an epoch's sampling time on MI355X.  The permutation of epoch e+1 depends
   // only on epoch e's (in-place, cumulative, seed = epoch), so a helper thread prepares it -- host array and its device
-  // copy, both double-buffered -- while epoch e is being sampled; the boundary then costs a pointer swap.
+  // copy -- while epoch e is being sampled; the boundary then costs a pointer swap.  The host array is double-buffered;
+  // the device copy has THREE buffers, so that the helper for epoch e+2 never writes the buffer the last batches of
+  // epoch e may still be reading when epoch e+1 begins: no flush of the in-flight batches at the epoch boundary either
+  // (the reference drains its pipeline there, dist_loops_arch5.cc:131-137).
   void Prepare(uint64_t epoch);       // starts the helper for `epoch` (from the current host array)
   std::vector<uint32_t> data_, next_;
-  uint32_t *d_data_ = nullptr, *d_next_ = nullptr;
+  uint32_t *d_data_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr;
   std::thread prep_;
   hipStream_t copy_stream_ = nullptr;
   int device_ = 0;
