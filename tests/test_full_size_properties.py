@@ -184,3 +184,106 @@ def test_full_size_neighbourhood_kernels(world):
     # a new batch mark reaches the same level-1 set again and counts it a second time
     lib.neighbourhood_expand(indptr, indices, seeds, stamp, 8, freq, fronts[1], counts[1:2], mark_frontier=True)
     assert int(counts[1].item()) == c1 and int(freq.sum()) == reached + 8000 + c1 and int(freq.max()) == 2
+
+
+def _shape_world(name, with_prefix):
+    sys.path.insert(0, ROOT)
+    import bench
+    from fgnn_hip import lib
+    lib.load()
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS[name]
+    indptr, indices, ne = bench.gen_graph_on_gpu(w["num_node"], w["num_edge"], 42, dev)
+    prefix = bench.gen_prefix_on_gpu(indptr, ne, 11, dev) if with_prefix else None
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    train = torch.randperm(w["num_node"], generator=g, device=dev)[:24000].to(torch.int32)
+    return lib, w, indptr, indices, prefix, train
+
+
+def _edge_in_row(ip, indices, nodes, row, col, samples=300):
+    pick = torch.randint(0, row.numel(), (samples,), device=row.device)
+    s_ids, n_ids = nodes[col[pick]].cpu().numpy(), nodes[row[pick]].cpu().numpy()
+    for s, nb in zip(s_ids, n_ids):
+        a, b = int(ip[s]), int(ip[s + 1])
+        assert (indices[a:b].long() & 0xFFFFFFFF == int(nb)).any()
+
+
+def test_full_size_weighted_gcn_invariants():
+    """BASELINE config 4's sampler side at full size (twitter shape: N=41 652 230, E=1 468 365 182, GCN fanout [5,10,15],
+    weighted_khop_prefix, batch 8000): the properties any run of GPUSampleWeightedKHopPrefix + the dedup satisfies
+    (SURVEY.md 8(c) T3): at most `fanout` edges per seed, output ordered by seed id, no adjacent duplicate pairs, every
+    edge in the CSR row of its seed, layer sizes chained."""
+    lib, w, indptr, indices, prefix, train = _shape_world("twitter", True)
+    sampler = lib.Sampler(indptr, indices, w["fanout"], w["batch_size"], sample_type=lib.WEIGHTED_KHOP_PREFIX, seed=13,
+                          prob_prefix=prefix)
+    ip = indptr.long() & 0xFFFFFFFF
+    for b in range(2):
+        bt = sampler.new_batch()
+        seeds = train[b * 8000:(b + 1) * 8000]
+        sampler.sample(seeds, 40 + b, bt)
+        bt.finish()
+        m = bt.wait()
+        assert m.overflow == 0 and m.num_layers == 3 and m.num_output == 8000
+        nodes = bt.input_nodes().long() & 0xFFFFFFFF
+        assert torch.unique(nodes).numel() == nodes.numel() == int(m.num_input)
+        assert torch.equal(nodes[:8000], seeds.long() & 0xFFFFFFFF)
+        prev_src = None
+        for l in (2, 1, 0):
+            row, col, nsrc, ndst = bt.graph(l)
+            row, col = row.long(), col.long()
+            F = w["fanout"][l]
+            assert nsrc >= ndst and int(row.max()) < nsrc and int(col.max()) < ndst
+            assert ndst == (8000 if l == 2 else prev_src)
+            per_seed = torch.bincount(col, minlength=ndst)
+            deg = ip[nodes[:ndst] + 1] - ip[nodes[:ndst]]
+            assert int(per_seed.max()) <= F and bool((per_seed[deg == 0] == 0).all()) and bool((per_seed[deg > 0] >= 1).all())
+            # ordered by the seed's node id (the reference's stable radix sort by src), draws of a seed together
+            seed_ids = nodes[col]
+            assert bool((seed_ids[1:] >= seed_ids[:-1]).all())
+            # only a draw equal to the seed's NEXT draw is dropped: no adjacent duplicate (seed, neighbour) pairs
+            assert not bool(((col[1:] == col[:-1]) & (row[1:] == row[:-1])).any())
+            _edge_in_row(ip, indices, nodes, row, col)
+            prev_src = nsrc
+        assert prev_src == int(m.num_input)
+    del sampler, prefix, indices
+    torch.cuda.empty_cache()
+
+
+def test_full_size_random_walk_invariants():
+    """BASELINE config 5's sampler side at full size (uk-2006-05 shape: N=77 741 046, E=2 965 197 340, PinSAGE walks
+    25 x 3, restart 0.5, top-5, 3 layers): per seed at most K edges with non-increasing visit counts that sum to at most
+    walks x length, distinct destinations, seeds in input order, layer sizes chained."""
+    lib, w, indptr, indices, _, train = _shape_world("uk-2006-05", False)
+    K, W, Lw = w["fanout"][0], w["num_walks"], w["walk_len"]
+    sampler = lib.Sampler(indptr, indices, w["fanout"], w["batch_size"], sample_type=lib.RANDOM_WALK, seed=13,
+                          walk_len=Lw, num_walks=W, restart_prob=w["restart_prob"])
+    for b in range(2):
+        bt = sampler.new_batch()
+        seeds = train[b * 8000:(b + 1) * 8000]
+        sampler.sample(seeds, 50 + b, bt)
+        bt.finish()
+        m = bt.wait()
+        assert m.overflow == 0 and m.num_layers == 3 and m.num_output == 8000
+        nodes = bt.input_nodes().long() & 0xFFFFFFFF
+        assert torch.unique(nodes).numel() == nodes.numel() == int(m.num_input)
+        prev_src = None
+        for l in (2, 1, 0):
+            row, col, nsrc, ndst = bt.graph(l)
+            cnt = bt.graph_data(l).long()
+            row, col = row.long(), col.long()
+            assert nsrc >= ndst and int(row.max()) < nsrc and int(col.max()) < ndst
+            assert ndst == (8000 if l == 2 else prev_src)
+            assert bool((col[1:] >= col[:-1]).all())                      # seeds in input order
+            per_seed = torch.bincount(col, minlength=ndst)
+            assert int(per_seed.max()) <= K
+            visits = torch.zeros(ndst, dtype=torch.long, device=col.device).index_add_(0, col, cnt)
+            assert int(visits.max()) <= W * Lw and int(cnt.min()) >= 1
+            same = col[1:] == col[:-1]
+            assert bool((cnt[1:][same] <= cnt[:-1][same]).all())            # top-K order: counts non-increasing
+            key = col * (nsrc + 1) + row                                    # destinations of a seed are distinct
+            assert torch.unique(key).numel() == key.numel()
+            prev_src = nsrc
+        assert prev_src == int(m.num_input)
+    del sampler, indices
+    torch.cuda.empty_cache()
