@@ -28,8 +28,34 @@ __device__ __forceinline__ float uniform_float(uint32_t x) {
   return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1], 24 bits, as the oracle
 }
 
-// one lane per (seed, slot).  MODE 0: per-row prefix sums + binary search (weighted_khop_prefix.cu:41-92),
+// the draw of (seed i, slot j).  MODE 0: per-row prefix sums + binary search (weighted_khop_prefix.cu:41-92),
 // 1: uniform with replacement (khop1.cu:42-72), 2: alias method, alias table = node ids (weighted_khop.cu:41-76)
+template <int MODE>
+__device__ __forceinline__ uint32_t weighted_pick(const uint32_t *__restrict__ indices, const float *__restrict__ prefix,
+                                                  const uint32_t *__restrict__ alias, uint32_t off, uint32_t len,
+                                                  uint32_t i, uint32_t j, uint64_t seed, uint64_t batch_key,
+                                                  uint32_t tag) {
+  if (len == 0) return FGNN_EMPTY_KEY;
+  if (MODE == 1) return indices[off + philox_u32(seed, batch_key, tag, i, j) % len];
+  if (MODE == 2) {
+    const u32x4 blk = philox_block(seed, batch_key, tag, i, j >> 1);  // draws 2j, 2j+1 share a block
+    const uint32_t r0 = (j & 1u) ? blk.z : blk.x;
+    const uint32_t r1 = (j & 1u) ? blk.w : blk.y;
+    const uint32_t k = r0 % len;
+    return uniform_float(r1) < prefix[off + k] ? indices[off + k] : alias[off + k];
+  }
+  const float up = prefix[off + len - 1];
+  const float x = uniform_float(philox_u32(seed, batch_key, tag, i, j)) * up;
+  if (x <= prefix[off]) return indices[off];
+  size_t lo = off, hi = (size_t)off + len - 1;
+  while (hi - lo >= 2) {
+    const size_t mid = (lo + hi) >> 1;
+    if (prefix[mid] >= x) hi = mid; else lo = mid;
+  }
+  return indices[hi];
+}
+
+// one lane per (seed, slot)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *__restrict__ indptr,
                                                                const uint32_t *__restrict__ indices,
@@ -48,30 +74,56 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *_
     const uint32_t rid = input[i];
     const uint32_t off = indptr[rid];
     const uint32_t len = indptr[rid + 1] - off;
+    tmp_dst[t] = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag);
+  }
+}
+
+// weighted_draw_kernel + weighted_count_kernel in one launch for fan-outs up to 64: a seed's F draws sit in F consecutive
+// lanes of ONE wavefront (64 / F seeds per wave), so "is this draw equal to the seed's next one" is a lane shuffle and
+// the per-seed count a ballot -- no second pass over the draws.  Also covers the padding up to `cap` like the count
+// kernel (keys / counts / order of unused seed slots).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
+    const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const float *__restrict__ prefix,
+    const uint32_t *__restrict__ alias, const uint32_t *__restrict__ input, size_t n_host, const uint32_t *d_n,
+    size_t cap, uint32_t F, uint32_t *__restrict__ tmp_dst, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+    uint32_t *__restrict__ cnt, uint32_t *bitmap, uint32_t *__restrict__ order, uint64_t seed, uint64_t batch_key,
+    uint32_t tag) {
+  const size_t n = resolve_count(n_host, d_n, cap);
+  const uint32_t G = (uint32_t)kWave / F;               // seeds per wave (F <= 64)
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t g = lane / F, j = lane - g * F;
+  const bool lane_used = g < G;
+  const unsigned long long gmask = lane_used ? (((F == 64u) ? ~0ull : ((1ull << F) - 1ull)) << (g * F)) : 0ull;
+  const size_t waves = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t w = (size_t)blockIdx.x * kWavesPerBlock + wave_id(); w * G < cap; w += waves) {
+    const size_t i = w * G + g;
+    const bool seed_here = lane_used && i < cap;
+    uint32_t rid = FGNN_EMPTY_KEY, off = 0, len = 0;
+    if (seed_here && i < n) {
+      rid = input[i];
+      off = indptr[rid];
+      len = indptr[rid + 1] - off;
+    }
     uint32_t pick = FGNN_EMPTY_KEY;
-    if (len != 0 && MODE == 1) {
-      pick = indices[off + philox_u32(seed, batch_key, tag, (uint32_t)i, j) % len];
-    } else if (len != 0 && MODE == 2) {
-      const u32x4 blk = philox_block(seed, batch_key, tag, (uint32_t)i, j >> 1);  // draws 2j, 2j+1 share a block
-      const uint32_t r0 = (j & 1u) ? blk.z : blk.x;
-      const uint32_t r1 = (j & 1u) ? blk.w : blk.y;
-      const uint32_t k = r0 % len;
-      pick = uniform_float(r1) < prefix[off + k] ? indices[off + k] : alias[off + k];
-    } else if (len != 0) {
-      const float up = prefix[off + len - 1];
-      const float x = uniform_float(philox_u32(seed, batch_key, tag, (uint32_t)i, j)) * up;
-      if (x <= prefix[off]) {
-        pick = indices[off];
-      } else {
-        size_t lo = off, hi = (size_t)off + len - 1;
-        while (hi - lo >= 2) {
-          const size_t mid = (lo + hi) >> 1;
-          if (prefix[mid] >= x) hi = mid; else lo = mid;
-        }
-        pick = indices[hi];
+    if (seed_here && i < n) {
+      pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag);
+      tmp_dst[i * F + j] = pick;
+    }
+    // a draw is dropped when it equals the seed's NEXT draw; the last one is always kept (count_edge, prefix.cu:94-112)
+    const uint32_t nxt = __shfl_down(pick, 1, kWave);
+    const bool keep = seed_here && i < n && len != 0 && (j + 1 == F || pick != nxt);
+    const uint32_t c = (uint32_t)__popcll(__ballot(keep) & gmask);
+    if (seed_here && j == 0) {
+      const uint32_t key = (i < n && len != 0) ? rid : FGNN_EMPTY_KEY;
+      keys[i] = key;
+      vals[i] = (uint32_t)i;
+      cnt[i] = c;
+      if (bitmap) {
+        order[i] = FGNN_EMPTY_KEY;
+        if (key != FGNN_EMPTY_KEY) atomicOr(&bitmap[key >> 5], 1u << (key & 31u));
       }
     }
-    tmp_dst[t] = pick;
   }
 }
 
@@ -415,18 +467,33 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
   void *temp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(sums + nb + 8) + 255) & ~uintptr_t(255));
   size_t temp_bytes = ws_bytes - (static_cast<char *>(temp) - static_cast<char *>(ws));
 
-  size_t blocks = div_up(cap * F, kBlock);
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  uint32_t *bitmap = rank ? rank->bitmap : nullptr;
+  if (F <= (uint32_t)kWave) {
+    // draws + per-seed counts + ranking bits in one launch
+    const size_t seeds_per_wg = (size_t)kWavesPerBlock * ((size_t)kWave / F);
+    size_t blocks = div_up(cap, seeds_per_wg);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+#define FGNN_DRAWC(M)                                                                                            \
+  hipLaunchKernelGGL((weighted_draw_count_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, \
+                     alias, input, num_input, d_num_input, cap, F, tmp_dst, keys, vals, cnt, bitmap, order, seed,    \
+                     batch_key, tag)
+    if (mode == 1) FGNN_DRAWC(1);
+    else if (mode == 2) FGNN_DRAWC(2);
+    else FGNN_DRAWC(0);
+#undef FGNN_DRAWC
+  } else {
+    size_t blocks = div_up(cap * F, kBlock);
+    if (blocks > 256 * 32) blocks = 256 * 32;
 #define FGNN_DRAW(M)                                                                                              \
   hipLaunchKernelGGL((weighted_draw_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, alias, \
                      input, num_input, d_num_input, cap, F, tmp_dst, seed, batch_key, tag)
-  if (mode == 1) FGNN_DRAW(1);
-  else if (mode == 2) FGNN_DRAW(2);
-  else FGNN_DRAW(0);
+    if (mode == 1) FGNN_DRAW(1);
+    else if (mode == 2) FGNN_DRAW(2);
+    else FGNN_DRAW(0);
 #undef FGNN_DRAW
-  uint32_t *bitmap = rank ? rank->bitmap : nullptr;
-  hipLaunchKernelGGL(weighted_count_kernel, dim3(nb), dim3(kBlock), 0, st, indptr, input, num_input, d_num_input, cap, F,
-                     tmp_dst, keys, vals, cnt, bitmap, order);
+    hipLaunchKernelGGL(weighted_count_kernel, dim3(nb), dim3(kBlock), 0, st, indptr, input, num_input, d_num_input, cap,
+                       F, tmp_dst, keys, vals, cnt, bitmap, order);
+  }
   if (rank) {
     // order by counting bits below each seed id (see the file header): 5 launches per layer in all
     const size_t words = rank_words(num_node);
