@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 SEED = 0x5A4D47
 NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, 2000
-BATCH, NUM_EPOCH = 256, 2
+BATCH, NUM_EPOCH = 256, int(os.environ.get("FGNN_TEST_NUM_EPOCH", "2"))
 # FGNN_TEST_CACHE_POLICY=static: the kCacheByPreSampleStatic policy (whole neighbourhoods instead of sampled ones)
 STATIC_PRESAMPLE = os.environ.get("FGNN_TEST_CACHE_POLICY", "") == "static"
 # where the arch5 workers run: both on cuda:0 by default; FGNN_TEST_TRAINER_DEVICE=cuda:1 puts the trainers on a second

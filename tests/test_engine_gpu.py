@@ -25,6 +25,14 @@ def test_arch1_single_gpu(tmp_path, sample_type):
 
 
 @pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch5", ["khop2", 2, 1, 0.25, "pipeline"])])
+def test_five_epochs(tmp_path, mode, args):
+    """Every epoch's permutation (and its device copy) is prepared by a helper thread during the epoch before, out of three
+    rotating device arrays, with no flush at the epoch boundary (eng_shuffler.h): five epochs cycle every buffer, and
+    each batch is still the one the reference's shuffle (dist_shuffler.cc:98-137) and the oracle produce."""
+    assert "ok" in _run(tmp_path, mode, *args, env={"FGNN_TEST_NUM_EPOCH": "5"})
+
+
+@pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch5", ["khop2", 2, 1, 0.25, "pipeline"])])
 def test_sanity_check_passes_on_a_clean_train_set(tmp_path, mode, args):
     """SAMGRAPH_SANITY_CHECK=1 (run_config.cc:91, dist_shuffler.cc:169-176): every batch is checked on the GPU for
     invalid ids and for ids already handed out in the epoch; a clean train set runs through, results unchanged."""
