@@ -52,3 +52,16 @@ print("accepted", rc["_arch"], rc["_sample_type"], rc["num_epoch"])
 ''' % (os.path.join(root, "fgnn-artifacts_amd"), mode, argv)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert p.returncode == 0 and "accepted" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_hardware_queue_default_is_set_before_the_first_hip_call():
+    """An arch5 rank drives five HIP streams; the runtime's default of 4 hardware queues makes two batch streams take
+    turns.  Importing the package sets GPU_MAX_HW_QUEUES=8 unless the user has set it."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); "
+            "import samgraph.common; print(os.environ['GPU_MAX_HW_QUEUES'])" % os.path.join(ROOT, "fgnn-artifacts_amd"))
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip() == "8"
+    code = code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '5'")
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip() == "5"
