@@ -268,6 +268,7 @@ void Engine::InitInProcess() {
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
+    shuffler_->TrackStream(s.st);
   }
   if (RC().UseGPUCache()) {
     Timer tp;
@@ -424,6 +425,7 @@ void Engine::SampleInit(int worker_id, Context ctx) {
     SAM_HIP(hipEventCreate(&s.e0));
     SAM_HIP(hipEventCreate(&s.e1));
     SAM_HIP(hipEventCreate(&s.e2));
+    if (s.owns_st) shuffler_->TrackStream(s.st);  // batches in flight read the epoch's seed array
   }
   if (RC().UseGPUCache()) {
     Timer tp;
@@ -700,16 +702,17 @@ void Engine::BuildTrainerCache() {
 void Engine::TrainerOnce() {
   SAM_HIP(hipSetDevice(tdevice_));
   while (pool_->Full()) std::this_thread::sleep_for(std::chrono::microseconds(1));
-  TrainerIssue(xctx_[0]);
+  TrainerIssue(xctx_[0], nullptr, 0);
   TrainerComplete(xctx_[0]);
 }
 
-void Engine::TrainerIssue(ExtractCtx &x) {
+// `msg` null: block for the next message (the caller holds no queue slot); else the message TryRecv handed out
+void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
   hipStream_t tstream_ = x.st;  // everything of this batch goes to the context's stream
   hipEvent_t *te_ = x.ev;
   Timer t_recv;
-  size_t mq_key = 0;
-  const char *msg = static_cast<const char *>(mq_->Recv(&mq_key));
+  size_t mq_key = taken_key;
+  const char *msg = static_cast<const char *>(taken ? taken : mq_->Recv(&mq_key));
   const double recv_time = t_recv.Passed();
   Timer t_copy;
   TransData hdr;
@@ -928,19 +931,25 @@ void Engine::StartExtract(int count) {
   if (extract_thread_.joinable()) extract_thread_.join();
   extract_thread_ = std::thread([this, count]() {
     SAM_HIP(hipSetDevice(tdevice_));
-    // up to kExtractDepth batches in flight; a batch is completed as soon as no further message is waiting, so a
-    // received batch is never held back behind a blocking receive
+    // Up to kExtractDepth batches in flight.  A further message is taken only when one is PUBLISHED (TryRecv never
+    // waits): a trainer that blocked for a message while holding unreleased queue slots could wait for a sampler that
+    // is itself waiting for one of those slots (few slots: large fan-outs under SAMGRAPH_MQ_BYTES, many trainers).
+    // With nothing in flight the thread holds no slot and may block like the reference's loop does.
     int issued = 0, head = 0, inflight = 0;
     while ((issued < count || inflight) && !shutdown_) {
-      if (inflight && (issued >= count || inflight == kExtractDepth || mq_->Pending() == 0)) {
-        TrainerComplete(xctx_[head]);
-        head = (head + 1) % kExtractDepth;
-        --inflight;
-        continue;
+      if (issued < count && inflight < kExtractDepth) {
+        const void *msg = nullptr;
+        size_t key = 0;
+        if (inflight == 0 || mq_->TryRecv(&msg, &key)) {
+          TrainerIssue(xctx_[(head + inflight) % kExtractDepth], msg, key);
+          ++inflight;
+          ++issued;
+          continue;
+        }
       }
-      TrainerIssue(xctx_[(head + inflight) % kExtractDepth]);
-      ++inflight;
-      ++issued;
+      TrainerComplete(xctx_[head]);
+      head = (head + 1) % kExtractDepth;
+      --inflight;
     }
   });
 }

@@ -139,7 +139,7 @@ class Engine {
   // arch5 trainer
   void TrainerOnce();
   struct ExtractCtx;
-  void TrainerIssue(ExtractCtx &x);
+  void TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key);
   void TrainerComplete(ExtractCtx &x);
   void BuildTrainerCache();
 

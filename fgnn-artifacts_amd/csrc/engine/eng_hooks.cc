@@ -96,6 +96,78 @@ extern "C" int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t 
   return bad;
 }
 
+// The extraction thread's discipline (Engine::StartExtract): up to `depth` received messages are held UNRELEASED; a
+// further one is taken only through TryRecv (published or nothing), with nothing held the consumer may block.  Must
+// terminate for any slot count >= 2 -- a consumer that blocked for a claimed-but-unpublished message while holding
+// slots would wait for a producer that waits for exactly those slots.
+extern "C" int fgnn_host_queue_selftest_deep(size_t slots, size_t slot_bytes, size_t messages, int producers,
+                                             int consumers, int depth) {
+  if (producers < 1 || consumers < 1 || slot_bytes < 64 || depth < 1) return 2;
+  MemoryQueue mq(slot_bytes, slots);
+  auto *seen = static_cast<uint32_t *>(mmap(nullptr, (messages + 1) * sizeof(uint32_t), PROT_READ | PROT_WRITE,
+                                            MAP_SHARED | MAP_ANONYMOUS, -1, 0));
+  if (seen == MAP_FAILED) return 2;
+  std::vector<pid_t> kids;
+  for (int p = 0; p < producers; ++p) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      alarm(60);  // a dead-locked ring ends the child instead of hanging the caller
+      for (size_t m = (size_t)p; m < messages; m += (size_t)producers) {
+        size_t key;
+        auto *w = static_cast<uint64_t *>(mq.GetPtr(&key));
+        if (Mix(m) % 7 == 0) usleep(200);  // a slot claimed long before it is published
+        w[0] = m;
+        w[1] = Mix(m);
+        mq.SimpleSend(key);
+      }
+      _exit(0);
+    }
+    kids.push_back(pid);
+  }
+  for (int c = 0; c < consumers; ++c) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      alarm(60);
+      const size_t mine = messages / (size_t)consumers + ((size_t)c < messages % (size_t)consumers ? 1 : 0);
+      std::vector<size_t> held;  // keys, oldest first
+      size_t taken = 0;
+      while (taken < mine || !held.empty()) {
+        if (taken < mine && (int)held.size() < depth) {
+          const void *msg = nullptr;
+          size_t key = 0;
+          bool got = true;
+          if (held.empty()) msg = mq.Recv(&key);
+          else got = mq.TryRecv(&msg, &key);
+          if (got) {
+            auto *w = static_cast<const uint64_t *>(msg);
+            if (w[0] < messages && w[1] == Mix(w[0])) __sync_fetch_and_add(&seen[w[0]], 1u);
+            else __sync_fetch_and_add(&seen[messages], 1u);
+            held.push_back(key);
+            ++taken;
+            continue;
+          }
+        }
+        if (Mix(taken) % 5 == 0) usleep(100);  // "waiting for the GPU"
+        mq.Release(held.front());
+        held.erase(held.begin());
+      }
+      _exit(0);
+    }
+    kids.push_back(pid);
+  }
+  int bad = 0;
+  for (pid_t pid : kids) {
+    int st = 0;
+    waitpid(pid, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  if (seen[messages] != 0) bad = 1;
+  for (size_t m = 0; m < messages; ++m)
+    if (seen[m] != 1) bad = 1;
+  munmap(seen, (messages + 1) * sizeof(uint32_t));
+  return bad;
+}
+
 extern "C" int fgnn_host_queue_named_role(size_t slots, size_t slot_bytes, size_t messages, int role, int index,
                                           int peers) {
   if (peers < 1 || index < 0 || index >= peers || slot_bytes < 64) return 2;

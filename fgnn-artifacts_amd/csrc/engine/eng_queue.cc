@@ -31,6 +31,7 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
     sem_init(meta_->sem_list + i, 1, 0);
     sem_init(meta_->release_list + i, 1, 1);
     meta_->payload_loc[i] = 0;
+    meta_->pub_seq[i] = 0;
   }
   memset(meta_->rings, 0, sizeof(meta_->rings));
   meta_->ipc_broken = 0;
@@ -204,7 +205,10 @@ void *MemoryQueue::GetPtr(size_t *key) {
   return meta_->data + (k % meta_->max_size) * meta_->mq_nbytes;
 }
 
-void MemoryQueue::SimpleSend(size_t key) { SAM_CHECK(sem_post(meta_->sem_list + (key % meta_->max_size)) == 0); }
+void MemoryQueue::SimpleSend(size_t key) {
+  __atomic_store_n(&meta_->pub_seq[key % meta_->max_size], key + 1, __ATOMIC_RELEASE);
+  SAM_CHECK(sem_post(meta_->sem_list + (key % meta_->max_size)) == 0);
+}
 
 const void *MemoryQueue::Recv(size_t *key) {
   while (*(volatile size_t *)&meta_->recv_cnt == *(volatile size_t *)&meta_->send_cnt)
@@ -216,9 +220,23 @@ const void *MemoryQueue::Recv(size_t *key) {
 }
 
 bool MemoryQueue::TryRecv(const void **data, size_t *key) {
-  if (*(volatile size_t *)&meta_->recv_cnt == *(volatile size_t *)&meta_->send_cnt) return false;
-  *data = Recv(key);
-  return true;
+  // Claims the oldest message only if it has been PUBLISHED.  send_cnt counts claimed slots (GetPtr), not published
+  // ones, so "recv_cnt < send_cnt" alone would send the caller into a blocking wait for a message whose sender may
+  // itself be waiting for a slot the caller still holds.  pub_seq[k % N] == k + 1 says that exactly message k sits
+  // published in its slot (a semaphore value could still be the unconsumed post of message k - N); the CAS makes this
+  // caller its one receiver, so the sem_wait below takes k's own post and never blocks.
+  for (;;) {
+    const size_t k = __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE);
+    if (k >= __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE)) return false;
+    if (__atomic_load_n(&meta_->pub_seq[k % meta_->max_size], __ATOMIC_ACQUIRE) != k + 1) return false;
+    size_t expect = k;
+    if (!__atomic_compare_exchange_n(&meta_->recv_cnt, &expect, k + 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+      continue;  // another receiver took k: look at the next one
+    SAM_CHECK(sem_wait(meta_->sem_list + (k % meta_->max_size)) == 0);
+    *key = k;
+    *data = meta_->data + (k % meta_->max_size) * meta_->mq_nbytes;
+    return true;
+  }
 }
 
 void MemoryQueue::Release(size_t key) {

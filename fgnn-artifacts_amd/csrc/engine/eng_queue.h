@@ -66,6 +66,7 @@ struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   size_t send_cnt, recv_cnt, max_size, mq_nbytes;
   sem_t sem_list[kMaxSlots];
   sem_t release_list[kMaxSlots];
+  size_t pub_seq[kMaxSlots];        // key + 1 of the message last PUBLISHED in the slot (TryRecv), 0: none yet
   uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
   int ipc_broken;                   // set by the first receiver that could not map a ring: samplers stop using theirs
   RingInfo rings[kMaxRings];
@@ -79,10 +80,12 @@ class MemoryQueue {
   void *GetPtr(size_t *key);                         // claim a slot for writing (blocks while the ring is full)
   void SimpleSend(size_t key);                       // publish
   const void *Recv(size_t *key);                     // blocks until a message is available
-  bool TryRecv(const void **data, size_t *key);      // non-blocking: false if nothing has been claimed for sending
+  bool TryRecv(const void **data, size_t *key);      // never blocks: takes the oldest message only if it is PUBLISHED
   void Release(size_t key);                          // SharedData::~SharedData
   size_t SlotBytes() const { return meta_->mq_nbytes; }
   size_t NumSlots() const { return meta_->max_size; }
+  // slots claimed for sending and not yet claimed by a receiver -- NOT the number of receivable messages (a claimed
+  // slot may still be waiting for its payload): use TryRecv to ask for a message without blocking
   size_t Pending() const { return *(volatile size_t *)&meta_->send_cnt - *(volatile size_t *)&meta_->recv_cnt; }
   // device-visible address of a pointer into the (pinned) queue region, for kernels that read a host slot in place
   const void *DeviceVisiblePtr(const void *host_ptr) const {

@@ -114,7 +114,13 @@ void Shuffler::Prepare(uint64_t epoch) {
     next_ = data_;                                           // cumulative: epoch e+1 shuffles epoch e's array
     ShuffleMinstd0(next_.data(), num_data_, epoch);          // seed = epoch: every sampler gets the same permutation
     SAM_HIP(hipSetDevice(device_));
-    // d_next_ held the epoch BEFORE the previous one: a whole epoch has been sampled since its last batch was enqueued
+    // d_next_ held epoch - 3's slice (fresh memory for the first three epochs).  Its batches were all enqueued before
+    // epoch - 2 began, so everything that can still read it is already on the readers' streams: wait for that, here on
+    // the helper thread.  (Usually a no-op: a whole epoch has been sampled since.)
+    if (epoch >= 3) {
+      SAM_HIP(hipStreamSynchronize(stream_));
+      for (hipStream_t st : readers_) SAM_HIP(hipStreamSynchronize(st));
+    }
     SAM_HIP(hipMemcpyAsync(d_next_, next_.data() + dataset_offset_, local_size_ * sizeof(uint32_t),
                            hipMemcpyHostToDevice, copy_stream_));
     SAM_HIP(hipStreamSynchronize(copy_stream_));

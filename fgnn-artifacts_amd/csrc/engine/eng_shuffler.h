@@ -43,6 +43,13 @@ class Shuffler {
   // SAMGRAPH_SANITY_CHECK (dist_shuffler.cc:139-144,169-176): every batch handed out is checked on the GPU for invalid
   // ids and for ids already handed out in this epoch; a violation is fatal like the reference's device assert
   void EnableSanityCheck(size_t num_node);
+  // A stream on which the caller enqueues work that reads the batches handed out (the engine's batch streams).  The
+  // helper that prepares epoch e+1 recycles the device array of epoch e-2; before it overwrites that array it waits
+  // for everything enqueued on the tracked streams (and on the constructor's stream).  With long epochs those batches
+  // finished long ago and the wait returns at once; with a handful of steps per epoch and several batches in flight
+  // (tiny train sets, many samplers) batches of epoch e-2 may still be QUEUED when epoch e begins -- without the wait
+  // they would read epoch e+1's seeds.  Call before the first GetBatch.
+  void TrackStream(hipStream_t st) { readers_.push_back(st); }
 
  private:
   void ReShuffle();
@@ -52,12 +59,14 @@ class Shuffler {
   // copy -- while epoch e is being sampled; the boundary then costs a pointer swap.  The host array is double-buffered;
   // the device copy has THREE buffers, so that the helper for epoch e+2 never writes the buffer the last batches of
   // epoch e may still be reading when epoch e+1 begins: no flush of the in-flight batches at the epoch boundary either
-  // (the reference drains its pipeline there, dist_loops_arch5.cc:131-137).
+  // (the reference drains its pipeline there, dist_loops_arch5.cc:131-137); the helper itself waits for the readers of
+  // the array it recycles (TrackStream), off the sampling thread.
   void Prepare(uint64_t epoch);       // starts the helper for `epoch` (from the current host array)
   std::vector<uint32_t> data_, next_;
   uint32_t *d_data_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr;
   std::thread prep_;
   hipStream_t copy_stream_ = nullptr;
+  std::vector<hipStream_t> readers_;  // see TrackStream
   int device_ = 0;
   size_t num_data_, num_epoch_, batch_size_;
   size_t num_step_, epoch_step_, last_batch_size_, dataset_offset_, local_size_, step_offset_;

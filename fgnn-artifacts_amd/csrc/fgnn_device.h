@@ -555,6 +555,8 @@ struct ScanWsHost {
   // the section of the diagnostic phase log
   // use_ticket: the kernel draws its tiles with scan_take_tile (hash_dedup_kernel); otherwise tile = blockIdx.x and
   // waiters help (scan_prefix_help)
+  // A ticketed launch that the runtime refused never drew its tickets: the caller hands them back (unnext_tickets).
+  void unnext_tickets(size_t grid) { ws.ticket_base -= (uint32_t)grid; }
   ScanWs next(uint32_t kind, size_t grid, bool use_ticket = false) {
     if (ws.gen >= 0x3FFFFFFEu) {
       // generations are about to repeat (once per 2^30 launches): descriptors stamped during the previous cycle
@@ -566,13 +568,14 @@ struct ScanWsHost {
     }
     ws.gen += 1u;
     ScanWs v = ws;
-    // FGNN_SCAN_TICKETS=1: tickets in every single-pass kernel (the A/B of profiles/r02_ticket_ab.txt)
-    static const bool all_tickets = [] { const char *e = getenv("FGNN_SCAN_TICKETS"); return e && atoi(e) != 0; }();
+    // (the A/B switch that put tickets into EVERY single-pass kernel, profiles/r02_ticket_ab.txt, is gone: kernels that
+    // take tile = blockIdx.x never draw from the counter, so advancing the base for them left base and counter out of
+    // step for the next ticketed launch on the slot)
     // FGNN_SCAN_HELP_AFTER=<polls>: 0 makes every wait that is not satisfied at once take the helping path (tests)
     static const int help_after = [] { const char *e = getenv("FGNN_SCAN_HELP_AFTER"); return e ? atoi(e) : -1; }();
     if (help_after >= 0) v.help_after = (uint32_t)help_after;
     v.helps = scan_help_counter();
-    if (use_ticket || all_tickets) ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
+    if (use_ticket) ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
     else v.ticket = nullptr;
     if (uint32_t *sink = scan_error_sink()) v.error = sink;
     unsigned long long *log = phase_log_base();

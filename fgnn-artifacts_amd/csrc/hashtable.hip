@@ -254,7 +254,15 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = bk[u] != kNoBucket ? ht_value(t, t.table[bk[u]]) : FGNN_EMPTY_KEY;
+        for (int u = 0; u < 4; ++u) {
+          // a helper (own == false) reads buckets another workgroup may be rewriting right now (pend|i -> local id):
+          // agent-scope atomic accesses on both sides make that a defined race whose either outcome is handled (see
+          // the release / acquire note below), instead of plain loads the compiler may hoist or an XCD's L2 may serve
+          // stale in the wrong direction
+          if (bk[u] == kNoBucket) v[u] = FGNN_EMPTY_KEY;
+          else if (own) v[u] = ht_value(t, t.table[bk[u]]);
+          else v[u] = ht_value(t, __hip_atomic_load(&t.table[bk[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -308,7 +316,9 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
       if (local < max_items) {
         // low half of the bucket = value.  final_fill: nothing looks these keys up again before the table is reset
         // (last layer of a batch; the fix-up below takes a duplicate's id from its owner's remap entry instead)
-        if (!final_fill) reinterpret_cast<uint32_t *>(&t.table[pos[i]])[0] = t.gen_base | local;
+        if (!final_fill)
+          __hip_atomic_store(reinterpret_cast<uint32_t *>(&t.table[pos[i]]), t.gen_base | local, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
         n2o[local] = items[i];
       }
       if (mapped) mapped[i] = local < max_items ? local : FGNN_EMPTY_KEY;

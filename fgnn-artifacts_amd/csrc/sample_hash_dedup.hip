@@ -138,6 +138,13 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
                      d_num_out, MODE, sums)
   if (mode == 0) {
     FGNN_HD(0);
+    if (scan_host && scan.ticket && scan.desc == scan_host->ws.desc) {
+      // a launch the runtime refused drew no tickets: hand them back, or the slot's next ticketed launch would compute
+      // its tiles against a base the device counter never reached
+      const int rc = launch_status(__func__);
+      if (rc != FGNN_OK) scan_host->unnext_tickets(nb);
+      return rc;
+    }
   } else {
     FGNN_HD(1);
     if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(kBlock) void rank_scatter_kernel(const uint32_t *__
   const uint32_t key = keys[i];
   if (key == FGNN_EMPTY_KEY) return;
   const uint32_t w = key >> 5, b = key & 31u;
-  order[pre[w] + (uint32_t)__popc(bitmap[w] & ((1u << b) - 1u))] = (uint32_t)i;
+  // a rank beyond the seed count means the bitmap held bits that are not this call's (a failed earlier call on the
+  // slot): never write outside order[]
+  const size_t r = (size_t)pre[w] + (uint32_t)__popc(bitmap[w] & ((1u << b) - 1u));
+  if (r < cap) order[r] = (uint32_t)i;
 }
 
 // pre[w] = set bits before word w in ONE launch: a workgroup popcounts its kWordsPerBlock words, publishes the sum and
@@ -505,7 +508,10 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
     } else {  // graphs beyond ~200 M nodes: per-workgroup sums -> scan -> prefixes
       uint32_t *sums2 = pre + words;
       hipLaunchKernelGGL((rank_popcount_kernel<0>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
-      if (launch_scan_block_sums(sums2, nb2, nullptr, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;
+      if (launch_scan_block_sums(sums2, nb2, nullptr, nullptr, nullptr, nullptr, st) != FGNN_OK) {
+        (void)hipMemsetAsync(bitmap, 0, words * sizeof(uint32_t), st);  // the contract: all zero between calls
+        return FGNN_EHIP;
+      }
       hipLaunchKernelGGL((rank_popcount_kernel<1>), dim3(nb2), dim3(kBlock), 0, st, bitmap, words, sums2, pre);
     }
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap, pre, order);
@@ -519,7 +525,10 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
       else if (ipt == 4) FGNN_EMIT(4);
       else FGNN_EMIT(16);
 #undef FGNN_EMIT
-      return launch_status(__func__);
+      const int rc = launch_status(__func__);
+      // the emit kernel is what clears the bits it consumed: if a launch of this call was refused, wipe them here
+      if (rc != FGNN_OK) (void)hipMemsetAsync(bitmap, 0, words * sizeof(uint32_t), st);
+      return rc;
     }
     hipLaunchKernelGGL(rank_clear_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap);
   } else {

@@ -33,6 +33,13 @@ void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_la
  * intact.  Returns 0 on success. */
 int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t messages, int producers, int consumers);
 
+/* The same, with consumers that behave like the engine's extraction thread (eng_engine.cc: StartExtract): each holds up
+ * to `depth` received messages unreleased and takes a further one only when it is already published (TryRecv); with
+ * nothing held it blocks.  Must terminate for any slots >= 2 (a ring of 2-3 slots is what large fan-outs leave under
+ * SAMGRAPH_MQ_BYTES).  Returns 0 on success. */
+int fgnn_host_queue_selftest_deep(size_t slots, size_t slot_bytes, size_t messages, int producers, int consumers,
+                                  int depth);
+
 /* The same ring between processes that were NOT forked from a common parent (one process per GPU started by torchrun):
  * with SAMGRAPH_SHM_PREFIX set, every process calling this attaches to the same named ring (eng_dataset.cc:
  * SharedCreate).  role 0 = producer `index` of `peers` (sends its share of `messages`), role 1 = consumer `index` of

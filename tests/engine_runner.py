@@ -19,10 +19,15 @@ sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 SEED = 0x5A4D47
-NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, 2000
+NUM_NODE, NUM_EDGE, DIM, NUM_CLASS, NUM_TRAIN = 20000, 300000, 16, 47, int(os.environ.get("FGNN_TEST_NUM_TRAIN", "2000"))
 BATCH, NUM_EPOCH = 256, int(os.environ.get("FGNN_TEST_NUM_EPOCH", "2"))
-# FGNN_TEST_CACHE_POLICY=static: the kCacheByPreSampleStatic policy (whole neighbourhoods instead of sampled ones)
-STATIC_PRESAMPLE = os.environ.get("FGNN_TEST_CACHE_POLICY", "") == "static"
+# FGNN_TEST_CACHE_POLICY=static: the kCacheByPreSampleStatic policy (whole neighbourhoods instead of sampled ones);
+# degree | random | heuristic | degree_hop | fake_optimal: the file-backed rankings (engine.cc:216-256), the file written
+# by tools/dataset/fgnn_dataset before the engine starts
+CACHE_POLICY = os.environ.get("FGNN_TEST_CACHE_POLICY", "")
+STATIC_PRESAMPLE = CACHE_POLICY == "static"
+FILE_POLICY = CACHE_POLICY if CACHE_POLICY in ("degree", "random", "heuristic", "degree_hop", "fake_optimal") else None
+DATASET_TOOL = os.path.join(ROOT, "tools", "dataset", "fgnn_dataset")
 # where the arch5 workers run: both on cuda:0 by default; FGNN_TEST_TRAINER_DEVICE=cuda:1 puts the trainers on a second
 # GPU (the hand-off then crosses xGMI: the sampler's HBM ring is mapped by hipIpcOpenMemHandle and read peer to peer)
 SAMPLER_DEV = os.environ.get("FGNN_TEST_SAMPLER_DEVICE", "cuda:0")
@@ -38,12 +43,21 @@ def dataset(workdir, sample_type):
         t = np.fromfile(os.path.join(d, "train_set.bin"), dtype=np.uint32)
         t[-1] = t[0]
         t.tofile(os.path.join(d, "train_set.bin"))
+    if FILE_POLICY:
+        import subprocess
+        if not os.path.exists(DATASET_TOOL) or os.path.getmtime(DATASET_TOOL) < os.path.getmtime(DATASET_TOOL + ".cc"):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-o", DATASET_TOOL, DATASET_TOOL + ".cc"], check=True)
+        extra = ["5", "3", "16"] if FILE_POLICY == "fake_optimal" else []  # the runner's fanout, 16 train nodes at a time
+        subprocess.run([DATASET_TOOL, "cache-by-" + FILE_POLICY.replace("_", "-"), d] + extra, check=True,
+                       stdout=subprocess.DEVNULL)
     return d
 
 
 def base_config(path, arch, sample_type):
     import samgraph.common as sc
     policy = sc.kCacheByPreSampleStatic if STATIC_PRESAMPLE else sc.kCacheByPreSample
+    if FILE_POLICY:
+        policy = sc.cache_policies[FILE_POLICY]
     cfg = dict(dataset_path=path, _arch=arch, _sample_type=sc.sample_types[sample_type], batch_size=BATCH,
                num_epoch=NUM_EPOCH, _cache_policy=policy, cache_percentage=0.0, max_sampling_jobs=10,
                max_copying_jobs=2, omp_thread_num=8, seed=SEED, presample_epoch=1, barriered_epoch=0)
@@ -95,7 +109,11 @@ class OracleReplay:
             self.part = oracle.dist_shuffler_partition(NUM_TRAIN, BATCH, worker, num_sampler)
             self.num_step = self.plain_step
         self.rank = None
-        if presample and worker == 0:
+        if presample and FILE_POLICY:
+            # the ranking the engine must have loaded (engine.cc:216-256): the file, as the tool wrote it
+            self.rank = np.fromfile(os.path.join(path, "cache_by_%s.bin" % FILE_POLICY), dtype=np.uint32)
+            assert sorted(self.rank.tolist()) == list(range(NUM_NODE))
+        elif presample and worker == 0:
             self._presample()
 
     def _sample(self, seeds, key):
@@ -249,7 +267,8 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
     sam.shutdown()
     print("%s %s cache %.2f %s%s ok: %d batches, %d miss rows" % (arch, sample_type, cache_pct,
                                                                 "threads" if threaded else "inline",
-                                                                " static-presample" if STATIC_PRESAMPLE else "", n,
+                                                                " static-presample" if STATIC_PRESAMPLE else
+                                                                " policy-%s" % FILE_POLICY if FILE_POLICY else "", n,
                                                                 miss_total))
 
 
@@ -340,7 +359,7 @@ def _sampler_proc(worker, num_sampler, barrier, err):
         os._exit(1)
 
 
-def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample, pipeline, barrier, err):
+def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample, pipeline, barrier, err, cache_pct=0.0):
     try:
         faulthandler.dump_traceback_later(400, exit=True)  # a stuck child shows where it is stuck
         import samgraph.torch as sam
@@ -359,19 +378,30 @@ def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample
         mine = total // num_trainer + (1 if worker < total % num_trainer else 0)
         if pipeline:
             sam.extract_start(mine)
-        seen = 0
+        seen = miss_total = 0
         for _ in range(mine):
             if not pipeline:
                 sam.sample_once()
             key = sam.get_next_batch()
             seeds, task, rep = expected.pop(key)
             check_batch(sam, key, seeds, task, rep, "arch5 key %d" % key)
+            if presample:
+                # which rows were misses is the ranking made observable (kLogL1MissBytes, dist_loops.cc:830-835): the
+                # sampler split the batch against table[rank[i]] = i, i < num_cached (dist_engine.cc:193-229) and this
+                # trainer fetched exactly the rows outside the first num_cached entries from host memory
+                cached = np.zeros(NUM_NODE, dtype=bool)
+                cached[rank[:int(NUM_NODE * cache_pct)]] = True
+                misses = int((~cached[task["input_nodes"]]).sum())
+                epoch, step = key // rep.plain_step, key % rep.plain_step
+                got = sam.get_log_step_value(epoch, step, sam.kLogL1MissBytes)
+                assert got == misses * DIM * 4, (key, got, misses)
+                miss_total += misses
             seen += 1
         if num_trainer == 1:
             assert not expected
         sam.shutdown()
-        print("trainer %d checked %d batches (presample rank head %s)" % (worker, seen,
-                                                                        None if rank is None else rank[:4]))
+        print("trainer %d checked %d batches, %d miss rows (rank head %s)" % (worker, seen, miss_total,
+                                                                              None if rank is None else rank[:4]))
     except BaseException:
         traceback.print_exc()
         err.value = 1
@@ -390,14 +420,16 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     err = ctx.Value("i", 0)
     procs = [ctx.Process(target=_sampler_proc, args=(w, num_sampler, barrier, err)) for w in range(num_sampler)]
     procs += [ctx.Process(target=_trainer_proc,
-                          args=(w, num_trainer, num_sampler, path, sample_type, cache_pct > 0, pipeline, barrier, err))
+                          args=(w, num_trainer, num_sampler, path, sample_type, cache_pct > 0, pipeline, barrier, err,
+                                cache_pct))
               for w in range(num_trainer)]
     for p in procs:
         p.start()
     bad = _join_all(procs, ["sampler"] * num_sampler + ["trainer"] * num_trainer)
     if bad or err.value:
         sys.exit(1)
-    print("arch5 %s %dS+%dT cache %.2f ok" % (sample_type, num_sampler, num_trainer, cache_pct))
+    print("arch5 %s %dS+%dT cache %.2f%s ok" % (sample_type, num_sampler, num_trainer, cache_pct,
+                                                " policy-%s" % FILE_POLICY if FILE_POLICY else ""))
 
 
 class _FileBarrier:
@@ -437,7 +469,7 @@ def run_arch5_named_role(sample_type, workdir, role, idx, num_sampler, num_train
     if role == "s":
         _sampler_proc(idx, num_sampler, barrier, _Err())
     else:
-        _trainer_proc(idx, num_trainer, num_sampler, path, sample_type, cache_pct > 0, True, barrier, _Err())
+        _trainer_proc(idx, num_trainer, num_sampler, path, sample_type, cache_pct > 0, True, barrier, _Err(), cache_pct)
     print("arch5-named %s%d ok" % (role, idx))
 
 

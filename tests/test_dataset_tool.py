@@ -95,6 +95,58 @@ def test_heuristic_degree_hop_rankings_and_64bit_copies(tool, tmp_path):
         np.testing.assert_array_equal(np.fromfile(os.path.join(d, name + "64.bin"), dtype=np.uint64), a32)
 
 
+def test_fake_optimal_ranking(tool, tmp_path):
+    """cache_by_fake_optimal.cc:66-185 restated with Python floats (IEEE doubles, same multiplication order): expected
+    number of one-node batches whose 2-hop [25,10]-style sample touches a node; ranking = descending (value, id)."""
+    from fgnn_hip import synth
+    num_node = 1500
+    d = synth.write_dataset(str(tmp_path), "g", num_node, 30000, 4, 5, 120, 20, 20, seed=4)
+    indptr = np.fromfile(os.path.join(d, "indptr.bin"), dtype=np.uint32).astype(np.int64)
+    indices = np.fromfile(os.path.join(d, "indices.bin"), dtype=np.uint32)
+    train = np.fromfile(os.path.join(d, "train_set.bin"), dtype=np.uint32)
+
+    def expectation(f0, f1, batch):
+        exp = [0.0] * num_node
+        for b0 in range(0, len(train), batch):
+            mine = [int(t) for t in train[b0:b0 + batch]]
+            m1, m2, order = {}, {}, list(mine)
+            for t in mine:
+                row = indices[indptr[t]:indptr[t + 1]]
+                miss = max(0.0, 1 - f1 / len(row)) if len(row) else 0.0
+                for v in row:
+                    v = int(v)
+                    m1[v] = m1.get(v, 1.0) * miss
+                    if v not in order:
+                        order.append(v)
+            for t in mine:
+                m1[t] = 0.0
+            for h in list(order):
+                row = indices[indptr[h]:indptr[h + 1]]
+                if not len(row):
+                    continue
+                path_miss = 1 - (1 - m1.get(h, 1.0)) * min(1.0, f0 / len(row))
+                for w in row:
+                    w = int(w)
+                    m2[w] = m2.get(w, 1.0) * path_miss
+                    if w not in order:
+                        order.append(w)
+            for t in mine:
+                m2[t] = 0.0
+            for c in order:
+                a, b = m1.get(c, 1.0), m2.get(c, 1.0)
+                if not (a == 1 and b == 1):
+                    exp[c] += 1 - a * b
+        return np.array(exp)
+
+    for args, (f0, f1, batch) in (((), (25, 10, 1)), ((3, 2, 7), (3, 2, 7))):
+        _run(tool, "cache-by-fake-optimal", d, *args)
+        got = np.fromfile(os.path.join(d, "cache_by_fake_optimal.bin"), dtype=np.uint32)
+        exp = expectation(f0, f1, batch)
+        want = np.lexsort((-np.arange(num_node), -exp)).astype(np.uint32)
+        np.testing.assert_array_equal(got, want)
+        assert exp[got[0]] >= 1.0 and sorted(got.tolist()) == list(range(num_node))
+
+
 def test_cache_by_random_matches_standard_library_golden(tool, tmp_path, golden_dir):
     d = tmp_path / "g"
     d.mkdir()

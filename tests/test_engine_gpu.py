@@ -32,6 +32,16 @@ def test_five_epochs(tmp_path, mode, args):
     assert "ok" in _run(tmp_path, mode, *args, env={"FGNN_TEST_NUM_EPOCH": "5"})
 
 
+@pytest.mark.parametrize("mode,args", [("arch5", ["khop2", 1, 1, 0.25, "pipeline"]), ("arch5", ["khop0", 2, 1, 0.0, "pipeline"]),
+                                       ("arch3", ["khop2", 0.25, "threads"])])
+def test_many_epochs_shorter_than_the_pipeline(tmp_path, mode, args):
+    """A train set of two batches per epoch (one per sampler with two samplers) over 12 epochs: the sampler runs up to
+    six batches = several EPOCHS ahead of the GPU, so the helper that prepares epoch e+1's device seed array must wait
+    for the readers of the array it recycles (epoch e-2's, eng_shuffler.h: TrackStream) -- the reference drains its
+    pipeline at every epoch boundary instead (dist_loops_arch5.cc:131-137).  Every batch still equals the oracle's."""
+    assert "ok" in _run(tmp_path, mode, *args, env={"FGNN_TEST_NUM_EPOCH": "12", "FGNN_TEST_NUM_TRAIN": "500"})
+
+
 @pytest.mark.parametrize("mode,args", [("arch1", ["khop2"]), ("arch5", ["khop2", 2, 1, 0.25, "pipeline"])])
 def test_sanity_check_passes_on_a_clean_train_set(tmp_path, mode, args):
     """SAMGRAPH_SANITY_CHECK=1 (run_config.cc:91, dist_shuffler.cc:169-176): every batch is checked on the GPU for
@@ -78,6 +88,20 @@ def test_static_presample_policy(tmp_path, arch, sample_type, cache, mode):
     assert "static-presample ok" in out
 
 
+@pytest.mark.parametrize("policy", ["degree", "random", "heuristic", "degree_hop", "fake_optimal"])
+@pytest.mark.parametrize("mode,args", [("arch3", ["khop2", 0.25, "inline"]), ("arch5", ["khop2", 2, 1, 0.2, "pipeline"])])
+def test_file_backed_cache_policies(tmp_path, policy, mode, args):
+    """The rankings the engine loads from cache_by_<policy>.bin (engine.cc:216-256; consumed by the cache managers,
+    dist_cache_manager_host.cc:60-119, dist_engine.cc:193-229), the file written by tools/dataset/fgnn_dataset: every
+    batch bit-exact, and every batch's miss volume equals the rows outside the first cache_percentage * N entries of
+    that file -- in the single-process engine and across sampler / trainer processes."""
+    out = _run(tmp_path, mode, *args, env={"FGNN_TEST_CACHE_POLICY": policy})
+    assert "policy-%s ok" % policy in out
+    import re
+    miss = [int(m) for m in re.findall(r"(\d+) miss rows", out)]
+    assert miss and sum(miss) > 0  # a quarter of the nodes cached: some rows do come from host memory
+
+
 @pytest.mark.parametrize("sample_type,mode", [("khop0", "inline"), ("khop1", "threads"), ("weighted_khop", "inline")])
 def test_arch4_dynamic_cache(tmp_path, sample_type, mode):
     """the arch4 dynamic-cache prototype (DoGPUSampleDyCache + DoDynamicCacheFeatureCopy): blocks, the prefetch node
@@ -106,6 +130,15 @@ def test_arch5_multi_process(tmp_path, sample_type, ns, nt, cache, mode):
     """FGNN: sampler processes -> shared pinned queue -> trainer processes, all on cuda:0
     (dist_loops_arch5.cc; the reference's --single-gpu topology, common_config.py:186-191)."""
     assert "ok" in _run(tmp_path, "arch5", sample_type, ns, nt, cache, mode)
+
+
+@pytest.mark.parametrize("mq_bytes,ns,nt", [(300000, 1, 1), (420000, 1, 2), (300000, 2, 1)])
+def test_arch5_pipelined_trainer_on_a_tiny_queue(tmp_path, mq_bytes, ns, nt):
+    """SAMGRAPH_MQ_BYTES that leaves the shared ring 2-3 slots (what GCN-sized fan-outs leave under the default budget
+    with many trainers): the extraction thread keeps up to 4 batches in flight and must never block for a message
+    while it holds the slots its sampler needs (eng_engine.cc: StartExtract, MemoryQueue::TryRecv)."""
+    out = _run(tmp_path, "arch5", "khop2", ns, nt, 0.25, "pipeline", env={"SAMGRAPH_MQ_BYTES": str(mq_bytes)})
+    assert "ok" in out
 
 
 def _two_gpu_env():

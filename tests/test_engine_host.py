@@ -139,6 +139,18 @@ def test_queue_multiprocess(eng, producers, consumers, slots):
     assert rc == 0
 
 
+@pytest.mark.parametrize("producers,consumers,slots,depth", [(1, 1, 2, 4), (1, 2, 3, 4), (2, 3, 4, 4), (2, 2, 170, 4),
+                                                             (1, 3, 2, 2)])
+def test_queue_deep_receivers_never_deadlock(eng, producers, consumers, slots, depth):
+    """The extraction thread keeps up to 4 batches in flight (unreleased queue slots).  A slot counts as "sent" from the
+    moment it is claimed, so asking `send_cnt - recv_cnt` whether a message waits would block a receiver on a message
+    whose sender waits for one of the receiver's own slots (2 slots, 1 trainer: certain).  TryRecv answers only for
+    PUBLISHED messages; every message still arrives exactly once."""
+    rc = eng.fgnn_host_queue_selftest_deep(C.c_size_t(slots), C.c_size_t(4096), C.c_size_t(600), producers, consumers,
+                                           depth)
+    assert rc == 0
+
+
 _NAMED_ROLE = r"""
 import ctypes as C, sys
 eng = C.CDLL(sys.argv[1])

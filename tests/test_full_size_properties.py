@@ -287,3 +287,71 @@ def test_full_size_random_walk_invariants():
         assert prev_src == int(m.num_input)
     del sampler, indices
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fanout", [[10, 5], [25, 10]])
+def test_products_shape_bit_exact_and_invariants(oracle, fanout):
+    """BASELINE configs 1 and 2 at full size on the GPU box (products shape: N=2 449 029, E~123.7 M, D=100, C=47,
+    batch 8000; fanout [10,5] = config 1's sampling work, [25,10] = config 2; datagen/products.py:92-98): this graph is
+    small enough to bring to the host, so on top of the size-independent invariants the whole batch -- blocks, unique
+    list, cache split, D=100 feature rows (25 sixteen-byte chunks: the gather's odd-width path), labels and khop2's
+    mutated CSR -- is compared BIT-EXACTLY with the oracle's restatement of DoGPUSample (cuda_loops.cc:50-267) over
+    three consecutive batches (the CSR mutation carries)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from fgnn_hip import lib
+    lib.load()
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS["products"]
+    N, D, B = w["num_node"], w["feat_dim"], w["batch_size"]
+    assert (N, D, w["num_class"], w["num_train"]) == (2449029, 100, 47, 196615)
+    indptr, indices, ne = bench.gen_graph_on_gpu(N, w["num_edge"], 42, dev)
+    feat = bench.gen_features_on_gpu(N, D, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    label = torch.randint(0, w["num_class"], (N,), generator=g, device=dev, dtype=torch.int64)
+    train = torch.randperm(N, generator=g, device=dev)[:w["num_train"]].to(torch.int32)
+    rank = torch.randperm(N, generator=g, device=dev).to(torch.int32)
+    table = lib.cache_table_build(rank, N // 5, N)
+    h_indptr = indptr.cpu().numpy().view(np.uint32)
+    h_indices = indices.cpu().numpy().view(np.uint32).copy()
+    h_feat, h_label = feat.cpu().numpy(), label.cpu().numpy()
+    h_table = table.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(h_table, oracle.cache_table_build(rank.cpu().numpy().view(np.uint32), N // 5, N))
+    d_indices = indices.clone()
+    sampler = lib.Sampler(indptr, d_indices, fanout, B, sample_type=lib.KHOP2, seed=0x5A4D47)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, 0x5A4D47)
+    oht = oracle.HashTable(N, oracle.predict_num_nodes(B, fanout))
+    ip = indptr.long() & 0xFFFFFFFF
+    # the last batch of an epoch is short (196 615 = 24 * 8000 + 4615): take it as one of the three
+    spans = [(0, B), (B, 2 * B), (24 * B, w["num_train"])]
+    for b, (lo, hi) in enumerate(spans):
+        seeds = train[lo:hi]
+        bt = sampler.new_batch(D, lib.F32, lib.I64)
+        sampler.run_batch(b, seeds, 7 + b, bt, table, feat, label)
+        m = bt.wait()
+        assert m.overflow == 0 and m.num_output == hi - lo
+        h_seeds = seeds.cpu().numpy().view(np.uint32)
+        want = oracle.do_sample(h_indptr, h_indices, h_seeds, fanout, oracle.KHOP2, rng, 7 + b, oht)
+        nodes = bt.input_nodes().cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        prev_src = None
+        for l in (1, 0):
+            row, col, nsrc, ndst = bt.graph(l)
+            gr = want["graphs"][l]
+            assert (nsrc, ndst, int(m.num_edge[l])) == (gr["num_src"], gr["num_dst"], gr["num_edge"])
+            np.testing.assert_array_equal(row.cpu().numpy().view(np.uint32), gr["row"])
+            np.testing.assert_array_equal(col.cpu().numpy().view(np.uint32), gr["col"])
+            # invariants that hold for any run of the reference (SURVEY 8(c) T3)
+            assert ndst == (hi - lo if l == 1 else prev_src)
+            dn = torch.from_numpy(nodes[:ndst].astype(np.int64)).to(dev)
+            assert torch.equal(torch.bincount(col.long(), minlength=ndst), torch.clamp(ip[dn + 1] - ip[dn], max=fanout[l]))
+            prev_src = nsrc
+        o_split = oracle.get_miss_cache_index(h_table, nodes)
+        assert int(m.num_miss) + int(m.num_cache) == len(nodes)
+        for got, wv in zip(bt.cache_index_arrays(), o_split):
+            np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), wv)
+        assert bt.feat().cpu().numpy().tobytes() == oracle.extract(h_feat, nodes).tobytes()
+        np.testing.assert_array_equal(bt.label().cpu().numpy(), h_label[h_seeds])
+    np.testing.assert_array_equal(d_indices.cpu().numpy().view(np.uint32), h_indices)  # khop2's swaps, all three batches
+    assert (h_indices != indices.cpu().numpy().view(np.uint32)).any()

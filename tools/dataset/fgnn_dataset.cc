@@ -5,6 +5,7 @@
 //   fgnn_dataset cache-by-random   <dir>                 -> cache_by_random.bin
 //   fgnn_dataset cache-by-heuristic <dir>                -> cache_by_heuristic.bin (train set, its neighbours, rest by degree)
 //   fgnn_dataset cache-by-degree-hop <dir>               -> cache_by_degree_hop.bin (degree inside the 2-hop reach first)
+//   fgnn_dataset cache-by-fake-optimal <dir> [f0 f1 [batch]] -> cache_by_fake_optimal.bin (expected 2-hop touch count)
 //   fgnn_dataset 32to64            <dir>                 -> indptr64.bin, indices64.bin, {train,test,valid}_set64.bin
 //   fgnn_dataset prob-prefix-table <dir> [policy]        -> prob_prefix_table.bin (f32[E], per-row inclusive sums)
 //   fgnn_dataset alias-table       <dir> [policy]        -> prob_table.bin (f32[E]) + alias_table.bin (u32[E], node ids)
@@ -12,7 +13,7 @@
 //   fgnn_dataset check             <dir>                 -> validates meta.txt against the CSR files
 //
 // What each file must contain follows the reference's generators (utility/data-process/toolkit/cache/
-// cache_by_degree.cc:29-62, cache_by_random.cc:29-50, cache_by_heuristic.cc:29-101, cache_by_degree_hop.cc:30-165,
+// cache_by_degree.cc:29-62, cache_by_random.cc:29-50, cache_by_heuristic.cc:29-101, cache_by_degree_hop.cc:30-165, cache_by_fake_optimal.cc:66-185,
 // generator/32to64.cc:33-82, weight/create_prob_prefix_table.cc:87-136,
 // weight/create_alias_table.cc:95-190, generator/coo_to_dataset.cc:128-222, property/csr_checker.cc); the weight
 // policies are kSrcSuffix (default), kInverseSrcDegreeRand, kDefault and kInverseBothDegreeRand -- the last two draw
@@ -195,6 +196,64 @@ int CacheByDegreeHop(const Dataset &d) {
   return 0;
 }
 
+// cache_by_fake_optimal.cc:66-164: expected number of batches (of `batch` train nodes; the reference uses 1) whose
+// 2-hop sample touches a node, under fanout {f0, f1} = {25, 10} (layer 1 draws f1 of a train node's row, layer 0 draws
+// f0 of every row reached): per batch, miss1[v] = prod over train nodes t listing v of max(0, 1 - f1/deg(t)), then
+// miss2[w] = prod over touched h listing w of 1 - (1 - miss1[h]) * min(1, f0/deg(h)); train nodes of the batch are
+// certain hits in both tables; expectation += 1 - miss1 * miss2.  Ranking = descending (expectation, id).  Products are
+// taken in the reference's order (train index, then row position; touched nodes grouped by id % 1 thread = insertion
+// order) so the doubles agree bit for bit with a one-thread run of the reference.
+int CacheByFakeOptimal(const Dataset &d, double f0, double f1, size_t batch) {
+  const std::vector<uint32_t> train = TrainSet(d);
+  const size_t n = d.num_node;
+  std::vector<double> expect(n, 0.0), miss1(n, 1.0), miss2(n, 1.0);
+  std::vector<uint8_t> seen(n, 0);
+  std::vector<uint32_t> touched;
+  auto touch = [&](uint32_t v) {
+    if (!seen[v]) {
+      seen[v] = 1;
+      touched.push_back(v);
+    }
+  };
+  if (batch == 0) batch = 1;
+  for (size_t b0 = 0; b0 < train.size(); b0 += batch) {
+    const size_t b1 = std::min(b0 + batch, train.size());
+    touched.clear();
+    for (size_t i = b0; i < b1; ++i) touch(train[i]);
+    for (size_t i = b0; i < b1; ++i) {
+      const uint32_t t = train[i];
+      const uint32_t deg = d.indptr[t + 1] - d.indptr[t];
+      const double miss = std::max(0.0, 1 - f1 / static_cast<double>(deg));
+      for (uint32_t e = d.indptr[t]; e < d.indptr[t + 1]; ++e) {
+        miss1[d.indices[e]] *= miss;
+        touch(d.indices[e]);
+      }
+    }
+    for (size_t i = b0; i < b1; ++i) miss1[train[i]] = 0.0;
+    const size_t hop1 = touched.size();  // train nodes + first hop; the loop below appends the second hop
+    for (size_t j = 0; j < hop1; ++j) {
+      const uint32_t h = touched[j];
+      const uint32_t deg = d.indptr[h + 1] - d.indptr[h];
+      const double path_miss = 1 - (1 - miss1[h]) * std::min(1.0, f0 / static_cast<double>(deg));
+      for (uint32_t e = d.indptr[h]; e < d.indptr[h + 1]; ++e) {
+        miss2[d.indices[e]] *= path_miss;
+        touch(d.indices[e]);
+      }
+    }
+    for (size_t i = b0; i < b1; ++i) miss2[train[i]] = 0.0;
+    for (uint32_t c : touched) {
+      if (!(miss1[c] == 1 && miss2[c] == 1)) expect[c] += 1 - miss1[c] * miss2[c];
+      miss1[c] = miss2[c] = 1.0;
+      seen[c] = 0;
+    }
+  }
+  std::vector<uint32_t> rank(n);
+  for (size_t i = 0; i < n; ++i) rank[i] = (uint32_t)i;
+  std::sort(rank.begin(), rank.end(), [&](uint32_t a, uint32_t b) { return expect[a] != expect[b] ? expect[a] > expect[b] : a > b; });
+  WriteFile(d.dir + "cache_by_fake_optimal.bin", rank);
+  return 0;
+}
+
 // generator/32to64.cc:33-82: 64-bit copies of the topology and node sets for the loaders of the DGL / PyG baselines
 int To64(const Dataset &d) {
   auto widen = [&](const std::vector<uint32_t> &v, const std::string &name) {
@@ -366,7 +425,7 @@ int Check(const Dataset &d) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  if (argc < 3) Die("usage: fgnn_dataset <cache-by-degree|cache-by-random|cache-by-heuristic|cache-by-degree-hop|32to64|prob-prefix-table|alias-table|coo-to-dataset|check> <dir> [arg]");
+  if (argc < 3) Die("usage: fgnn_dataset <cache-by-degree|cache-by-random|cache-by-heuristic|cache-by-degree-hop|cache-by-fake-optimal|32to64|prob-prefix-table|alias-table|coo-to-dataset|check> <dir> [arg]");
   const std::string cmd = argv[1];
   if (cmd == "coo-to-dataset") {
     if (argc < 4) Die("coo-to-dataset needs <dir> <coo.bin>");
@@ -377,6 +436,8 @@ int main(int argc, char **argv) {
   if (cmd == "cache-by-random") return CacheByRandom(d);
   if (cmd == "cache-by-heuristic") return CacheByHeuristic(d);
   if (cmd == "cache-by-degree-hop") return CacheByDegreeHop(d);
+  if (cmd == "cache-by-fake-optimal")
+    return CacheByFakeOptimal(d, argc > 4 ? atof(argv[3]) : 25, argc > 4 ? atof(argv[4]) : 10, argc > 5 ? (size_t)atoll(argv[5]) : 1);
   if (cmd == "32to64") return To64(d);
   if (cmd == "prob-prefix-table") return ProbPrefixTable(d, ParsePolicy(argc > 3 ? argv[3] : nullptr));
   if (cmd == "alias-table") return AliasTable(d, ParsePolicy(argc > 3 ? argv[3] : nullptr));
