@@ -31,6 +31,10 @@ struct fgnn_sampler {
     uint32_t *tmp_dst = nullptr;          // [max_edge_cap] sampled neighbours (global ids)
     void *ws = nullptr;                   // kernel scratch
     hipEvent_t done = nullptr, csr = nullptr;
+    // FGNN_CHAIN_PRIORITY (see fgnn_sampler_sample_ordered): the sampling stage of the slot's batches runs on this
+    // high-priority stream, the caller's stream keeps the cache split and the bandwidth-bound gather
+    hipStream_t chain_st = nullptr;
+    hipEvent_t entered = nullptr;
     bool was_used = false;
     fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
     uint32_t *rank_bitmap = nullptr;      // with-replacement samplers: seed ranking bitmap over the node ids (all zero
@@ -47,6 +51,10 @@ struct fgnn_sampler {
   uint64_t csr_passed = 0;                // calls [0, csr_passed) have enqueued their last sampler kernel
   bool done_flag[kSlots] = {false, false, false, false};
   bool csr_flag[kSlots] = {false, false, false, false};
+  // switches, read from the environment at create time (see env_int)
+  int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
+  int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
+  int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
 };
 
 struct fgnn_batch {
@@ -79,6 +87,18 @@ namespace {
 // marks the batch so that the host does not take the truncated tensor for the whole one (fgnn_hip.h, `overflow`)
 __global__ void batch_rows_overflow_kernel(fgnn_batch_meta *m, uint32_t cap) {
   if (m->num_input > cap) m->overflow = 1u;
+}
+
+// FGNN_CHAIN_PRIORITY=1: a batch's sampling stage (samplers, dedup, remap -- everything up to the table's generation
+// bump) is enqueued on a high-priority stream of its sampler slot; the caller's stream, which then carries only the
+// cache split and the feature gather, waits for the slot's `done` event.  The latency-bound kernels of khop2's
+// cross-batch order chain are then dispatched ahead of the bandwidth-bound gathers of the other batches in flight
+// whenever wave slots free up.  0 (default): everything on the caller's stream.
+// (switches of this file are read when a sampler is created, not cached per process: an A/B tool can create one
+// sampler per setting over the same graph, tools/ab_variants.py)
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
 }
 
 size_t dtype_size(int dtype) {
@@ -129,6 +149,9 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
+  s->opt_chain_priority = env_int("FGNN_CHAIN_PRIORITY", 0);
+  s->opt_split_l0 = env_int("FGNN_KHOP_SPLIT_L0", -1);
+  s->opt_unordered = env_int("FGNN_KHOP2_UNORDERED", 0);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -158,8 +181,13 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     bool ok = sl.ht != nullptr;
     ok = ok && hipMalloc(&sl.tmp_dst, s->max_edge_cap * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
-    for (hipEvent_t *e : {&sl.done, &sl.csr})
+    for (hipEvent_t *e : {&sl.done, &sl.csr, &sl.entered})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (s->opt_chain_priority != 0) {
+      int lo = 0, hi = 0;  // numerically lower = higher priority
+      ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+      ok = ok && hipStreamCreateWithPriority(&sl.chain_st, hipStreamNonBlocking, hi) == hipSuccess;
+    }
     ok = ok && sl.scan_sample.create(s->max_nodes / 64 + 2) == FGNN_OK;
     if (cfg->num_node && (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX || cfg->sample_type == FGNN_KHOP1 ||
                           cfg->sample_type == FGNN_WEIGHTED_KHOP)) {
@@ -183,8 +211,9 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
     if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
     if (sl.rank_bitmap) (void)hipFree(sl.rank_bitmap);
     if (sl.ws) (void)hipFree(sl.ws);
-    for (hipEvent_t e : {sl.done, sl.csr})
+    for (hipEvent_t e : {sl.done, sl.csr, sl.entered})
       if (e) (void)hipEventDestroy(e);
+    if (sl.chain_st) (void)hipStreamDestroy(sl.chain_st);
   }
   delete s;
 }
@@ -276,6 +305,7 @@ struct SeqGuard {
   fgnn_sampler *s;
   uint64_t seq;
   hipStream_t st;
+  hipStream_t caller_st;
   bool csr_marked = false;
   bool finished = false;  // the success path has reset the slot's table and recorded its events itself
   // An early error return leaves the slot's table with this batch's pending buckets and notes: the slot's next batch
@@ -285,6 +315,7 @@ struct SeqGuard {
     (void)fgnn::hashtable_next_generation(sl.ht, st, false);
     if (s->cfg.sample_type == FGNN_KHOP2 && !csr_marked) (void)hipEventRecord(sl.csr, st);
     (void)hipEventRecord(sl.done, st);
+    if (st != caller_st) (void)hipStreamWaitEvent(caller_st, sl.done, 0);
     sl.was_used = true;
   }
   void mark_csr() {
@@ -317,10 +348,15 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
                                            uint64_t batch_key, fgnn_batch *out, void *stream) {
   if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
     return FGNN_EINVAL;
-  auto st = static_cast<hipStream_t>(stream);
+  const hipStream_t caller_st = static_cast<hipStream_t>(stream);
+  hipStream_t st = caller_st;
+  if (hipStream_t c = s->slot[seq % kSlots].chain_st) {
+    st = c;
+    stream = c;
+  }
   const size_t L = s->cfg.num_layers;
   // FGNN_KHOP2_UNORDERED=1 (profiling only; results then depend on the overlap): drop khop2's batch-order chain
-  static const bool unordered = [] { const char *e = getenv("FGNN_KHOP2_UNORDERED"); return e && atoi(e) != 0; }();
+  const bool unordered = s->opt_unordered != 0;
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
   const bool ordered = mutates && !unordered;
   // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one (FGNN_KHOP_SPLIT_L0=0: fused).
@@ -329,7 +365,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   // half of it is the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's
   // sampling starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more
   // launch and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt)
-  static const int split_env = [] { const char *e = getenv("FGNN_KHOP_SPLIT_L0"); return e ? atoi(e) : -1; }();
+  const int split_env = s->opt_split_l0;
   {
     // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
     std::unique_lock<std::mutex> lk(s->mu);
@@ -337,9 +373,13 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return seq < s->returned + kSlots; })) return FGNN_EINVAL;
     if (seq < s->returned) return FGNN_EINVAL;
   }
-  SeqGuard guard{s, seq, st};
+  SeqGuard guard{s, seq, st, caller_st};
   fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+  if (st != caller_st) {  // whatever the caller enqueued before this call (the seeds, the batch buffer's last use)
+    FGNN_HIP_CHECK(hipEventRecord(sl.entered, caller_st));
+    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.entered, 0));
+  }
   fgnn_hashtable *ht = sl.ht;
   uint32_t *tmp_dst = sl.tmp_dst;
   void *ws = sl.ws;
@@ -422,6 +462,14 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
       FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
       guard.mark_csr();
+      if (st != caller_st && s->opt_chain_priority == 2) {
+        // mode 2: only the order chain itself ran at high priority; the last layer's insert and dedup, which nothing
+        // of the next batch waits for, go back to the caller's stream
+        FGNN_HIP_CHECK(hipStreamWaitEvent(caller_st, sl.csr, 0));
+        st = caller_st;
+        stream = caller_st;
+        guard.st = caller_st;
+      }
     }
     const bool inserted = (s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0) && !split;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
@@ -441,6 +489,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   rc = fgnn::hashtable_next_generation(ht, stream, false);
   if (rc != FGNN_OK) return rc;
   FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
+  if (st != caller_st) FGNN_HIP_CHECK(hipStreamWaitEvent(caller_st, sl.done, 0));
   sl.was_used = true;
   guard.finished = true;
   return launch_status(__func__);

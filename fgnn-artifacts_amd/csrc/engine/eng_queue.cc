@@ -28,10 +28,9 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
   meta_->max_size = num_slots;
   meta_->mq_nbytes = slot_bytes;
   for (size_t i = 0; i < num_slots; ++i) {
-    sem_init(meta_->sem_list + i, 1, 0);
-    sem_init(meta_->release_list + i, 1, 1);
-    meta_->payload_loc[i] = 0;
     meta_->pub_seq[i] = 0;
+    meta_->rel_seq[i] = 0;
+    meta_->payload_loc[i] = 0;
   }
   memset(meta_->rings, 0, sizeof(meta_->rings));
   meta_->ipc_broken = 0;
@@ -196,35 +195,51 @@ void MemoryQueue::PinMemory() {
   dev_base_ = static_cast<const char *>(d);
 }
 
+// Hand-shakes by per-slot SEQUENCE numbers, not by the reference's per-slot semaphore pairs (memory_queue.cc:104-138):
+// a semaphore cannot tell message k from message k + N of the same slot.  With more blocked receivers (or more
+// in-flight slots per receiver, StartExtract keeps four) than slots, the sender of k + N can take the release post
+// meant for the sender of k, and the receiver of k + N the data post meant for the receiver of k.  pub_seq[slot] ==
+// k + 1 <=> message k is published in the slot; rel_seq[slot] == g <=> generations < g of the slot are released, i.e.
+// message k may be written when rel_seq == k / N.  Waiters spin briefly, then sleep in short steps (the reference's
+// own wait loops poll at 1 us).
+namespace {
+template <typename Pred>
+void WaitFor(Pred ready) {
+  for (int i = 0; i < 4000; ++i) {
+    if (ready()) return;
+    __builtin_ia32_pause();
+  }
+  while (!ready()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+}
+}  // namespace
+
 void *MemoryQueue::GetPtr(size_t *key) {
-  const size_t k = __sync_fetch_and_add(&meta_->send_cnt, 1);
-  while (k >= *(volatile size_t *)&meta_->recv_cnt + meta_->max_size)
-    std::this_thread::sleep_for(std::chrono::microseconds(1));
-  SAM_CHECK(sem_wait(meta_->release_list + (k % meta_->max_size)) == 0);
+  const size_t k = __atomic_fetch_add(&meta_->send_cnt, 1, __ATOMIC_ACQ_REL);
+  const size_t slot = k % meta_->max_size, gen = k / meta_->max_size;
+  WaitFor([&] { return __atomic_load_n(&meta_->rel_seq[slot], __ATOMIC_ACQUIRE) == gen; });
   *key = k;
-  return meta_->data + (k % meta_->max_size) * meta_->mq_nbytes;
+  return meta_->data + slot * meta_->mq_nbytes;
 }
 
 void MemoryQueue::SimpleSend(size_t key) {
   __atomic_store_n(&meta_->pub_seq[key % meta_->max_size], key + 1, __ATOMIC_RELEASE);
-  SAM_CHECK(sem_post(meta_->sem_list + (key % meta_->max_size)) == 0);
 }
 
 const void *MemoryQueue::Recv(size_t *key) {
-  while (*(volatile size_t *)&meta_->recv_cnt == *(volatile size_t *)&meta_->send_cnt)
-    std::this_thread::sleep_for(std::chrono::microseconds(1));
-  const size_t k = __sync_fetch_and_add(&meta_->recv_cnt, 1);
-  SAM_CHECK(sem_wait(meta_->sem_list + (k % meta_->max_size)) == 0);
+  WaitFor([&] {
+    return __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE) != __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE);
+  });
+  const size_t k = __atomic_fetch_add(&meta_->recv_cnt, 1, __ATOMIC_ACQ_REL);
+  const size_t slot = k % meta_->max_size;
+  WaitFor([&] { return __atomic_load_n(&meta_->pub_seq[slot], __ATOMIC_ACQUIRE) == k + 1; });
   *key = k;
-  return meta_->data + (k % meta_->max_size) * meta_->mq_nbytes;
+  return meta_->data + slot * meta_->mq_nbytes;
 }
 
 bool MemoryQueue::TryRecv(const void **data, size_t *key) {
   // Claims the oldest message only if it has been PUBLISHED.  send_cnt counts claimed slots (GetPtr), not published
-  // ones, so "recv_cnt < send_cnt" alone would send the caller into a blocking wait for a message whose sender may
-  // itself be waiting for a slot the caller still holds.  pub_seq[k % N] == k + 1 says that exactly message k sits
-  // published in its slot (a semaphore value could still be the unconsumed post of message k - N); the CAS makes this
-  // caller its one receiver, so the sem_wait below takes k's own post and never blocks.
+  // ones, so "recv_cnt < send_cnt" alone would send the caller into a wait for a message whose sender may itself be
+  // waiting for a slot the caller still holds.
   for (;;) {
     const size_t k = __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE);
     if (k >= __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE)) return false;
@@ -232,7 +247,6 @@ bool MemoryQueue::TryRecv(const void **data, size_t *key) {
     size_t expect = k;
     if (!__atomic_compare_exchange_n(&meta_->recv_cnt, &expect, k + 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
       continue;  // another receiver took k: look at the next one
-    SAM_CHECK(sem_wait(meta_->sem_list + (k % meta_->max_size)) == 0);
     *key = k;
     *data = meta_->data + (k % meta_->max_size) * meta_->mq_nbytes;
     return true;
@@ -247,7 +261,7 @@ void MemoryQueue::Release(size_t key) {
     __atomic_store_n(&r.busy[loc & 0xffu], 0u, __ATOMIC_RELEASE);
     loc = 0;
   }
-  SAM_CHECK(sem_post(meta_->release_list + (key % meta_->max_size)) == 0);
+  __atomic_store_n(&meta_->rel_seq[key % meta_->max_size], key / meta_->max_size + 1, __ATOMIC_RELEASE);
 }
 
 size_t MaxMessageBytes(size_t batch_size, const size_t *fanout, size_t num_layers, bool have_data) {

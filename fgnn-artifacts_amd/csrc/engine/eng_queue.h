@@ -1,14 +1,13 @@
 // eng_queue.h -- sampler -> trainer hand-off: a lock-free MPMC ring of fixed-size slots in a
 // MAP_SHARED|MAP_ANONYMOUS host mapping, hipHostRegister'ed by every child after fork, with the
-// reference's counters + process-shared semaphores (memory_queue.h:46-115, memory_queue.cc:33-138)
+// reference's send / receive counters (memory_queue.h:46-115, memory_queue.cc:33-138; per-slot sequence numbers where
+// the reference has semaphore pairs, see eng_queue.cc)
 // and the reference's wire format (task_queue.cc:68-88: TransData 40 B header, GraphData 24 B).
 //
 // MI355X change: the sampler does not issue one D2H copy per tensor with sizes known on the host
 // (task_queue.cc:154-227); ONE kernel (pack.hip) reads the sizes on the device and writes the whole
 // serialized message into the mapped slot, so the sampler never waits for a size.
 #pragma once
-#include <semaphore.h>
-
 #include <atomic>
 #include <thread>
 
@@ -64,9 +63,8 @@ struct RingInfo {
 
 struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   size_t send_cnt, recv_cnt, max_size, mq_nbytes;
-  sem_t sem_list[kMaxSlots];
-  sem_t release_list[kMaxSlots];
-  size_t pub_seq[kMaxSlots];        // key + 1 of the message last PUBLISHED in the slot (TryRecv), 0: none yet
+  size_t pub_seq[kMaxSlots];        // key + 1 of the message last PUBLISHED in the slot, 0: none yet
+  size_t rel_seq[kMaxSlots];        // generations of the slot released so far: message k may be written at k / N
   uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
   int ipc_broken;                   // set by the first receiver that could not map a ring: samplers stop using theirs
   RingInfo rings[kMaxRings];
