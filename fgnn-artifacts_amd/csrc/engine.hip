@@ -55,6 +55,10 @@ struct fgnn_sampler {
   int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
+  // khop2's batch order handed over on the device (fgnn_device.h, ChainSync) instead of an event between the batches'
+  // streams: kChainWords zeroed words, null when the sampler orders its batches with events (FGNN_CHAIN_FLAGS=0, other
+  // sample types, or a last layer too large for arrival counting)
+  uint32_t *d_chain = nullptr;
 };
 
 struct fgnn_batch {
@@ -175,6 +179,14 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
+  if (cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered && env_int("FGNN_CHAIN_FLAGS", 1) != 0 &&
+      s->in_cap[0] <= 131072) {  // <= 2048 workgroups arrive per launch (sample_khop.hip picks 64 seeds per workgroup)
+    if (hipMalloc(&s->d_chain, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(s->d_chain, 0, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess) {
+      fgnn_sampler_destroy(s);
+      return fail(FGNN_EHIP);
+    }
+  }
   for (auto &sl : s->slot) {
     int err = FGNN_OK;
     sl.ht = fgnn_hashtable_create_ex(s->max_nodes, s->max_edge_cap, &err);  // fills are at most a layer's edges
@@ -215,6 +227,7 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
       if (e) (void)hipEventDestroy(e);
     if (sl.chain_st) (void)hipStreamDestroy(sl.chain_st);
   }
+  if (s->d_chain) (void)hipFree(s->d_chain);
   delete s;
 }
 
@@ -307,16 +320,26 @@ struct SeqGuard {
   hipStream_t st;
   hipStream_t caller_st;
   bool csr_marked = false;
+  bool chain_published = false;  // device hand-off: this batch's turn has been (or will be, by an enqueued launch) passed on
   bool finished = false;  // the success path has reset the slot's table and recorded its events itself
   // An early error return leaves the slot's table with this batch's pending buckets and notes: the slot's next batch
   // must not dedup against them, and must still find the slot's events recorded.
   void abandon() {
     fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
     (void)fgnn::hashtable_next_generation(sl.ht, st, false);
+    pass_chain();
     if (s->cfg.sample_type == FGNN_KHOP2 && !csr_marked) (void)hipEventRecord(sl.csr, st);
     (void)hipEventRecord(sl.done, st);
     if (st != caller_st) (void)hipStreamWaitEvent(caller_st, sl.done, 0);
     sl.was_used = true;
+  }
+  // device hand-off: a batch that launches no publishing sampler kernel (no seeds, an error on the way) still waits
+  // for its predecessor and publishes its own number, or every later batch would time out
+  void pass_chain() {
+    if (!s->d_chain || chain_published) return;
+    chain_published = true;
+    const fgnn::ChainSync c{s->d_chain, nullptr, (uint32_t)seq, (uint32_t)seq + 1u, seq > 0 ? 1u : 0u, 1u};
+    (void)fgnn::launch_chain_pass(c, st);
   }
   void mark_csr() {
     if (csr_marked) return;
@@ -393,7 +416,8 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       std::unique_lock<std::mutex> lk(s->mu);
       if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
     }
-    FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
+    // (the wait above keeps the ENQUEUE order, which the device hand-off's forward progress rests on as well)
+    if (!s->d_chain) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
   int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
@@ -444,23 +468,28 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
       const bool first = start_in_sampler && l == (long)L - 1;
+      // device hand-off of khop2's batch order: the batch's first sampler launch waits for batch seq - 1, its last
+      // one publishes seq + 1
+      fgnn::ChainSync chain{ordered ? s->d_chain : nullptr, &out->d_meta->overflow, (uint32_t)seq, (uint32_t)seq + 1u,
+                            (l == (long)L - 1 && seq > 0) ? 1u : 0u, l == 0 ? 1u : 0u};
       // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
       // (not when this launch also inserts the seeds: their local ids would replace pending edges without a note)
       split = ordered && l == 0 && !first && split_env != 0;
       if (split)
         rc = fgnn::sample_khop_plain(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
                                      out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
-                                     stream, &sl.scan_sample);
+                                     stream, &sl.scan_sample, &chain);
       else {
       resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
       rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
                              tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
-                             &sl.scan_sample, first ? &start : nullptr, resolved);
+                             &sl.scan_sample, first ? &start : nullptr, resolved, &chain);
       }
     }
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
-      FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+      if (s->d_chain && ordered) guard.chain_published = true;  // by the launch just enqueued
+      if (!s->d_chain || s->opt_chain_priority == 2) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
       guard.mark_csr();
       if (st != caller_st && s->opt_chain_priority == 2) {
         // mode 2: only the order chain itself ran at high priority; the last layer's insert and dedup, which nothing
@@ -483,7 +512,10 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     d_cur_n = fgnn_hashtable_d_num_items(ht);
     cur_n_host = 0;
   }
-  if (mutates && num_seeds == 0) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+  if (mutates && num_seeds == 0) {
+    if (ordered) guard.pass_chain();
+    FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+  }
   // wipe the table for the slot's next batch (Reset, cuda_hashtable.cu:714-723), then mark the slot reusable
   // Reset (cuda_hashtable.cu:714-723) for the slot's next batch: a generation bump, no memory traffic
   rc = fgnn::hashtable_next_generation(ht, stream, false);

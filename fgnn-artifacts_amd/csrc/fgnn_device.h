@@ -584,6 +584,57 @@ struct ScanWsHost {
   }
 };
 
+// ---- khop2's cross-batch order chain, handed over on the DEVICE -------------------------------------------------
+// khop2 rewrites CSR rows in place (cuda_sampling_khop2.cu:74-83), so the sampler kernels of consecutive batches must
+// run in batch order however the batches overlap on their streams.  Ordering them with an event between two streams
+// costs 20-40 us per batch on this runtime (profiles/r03_ab1_priority_unordered.txt: sampler-side stage 0.094 ms per
+// batch ordered, 0.067 with the order dropped), more than the chain's own kernels.  Instead the LAST sampler launch of
+// batch b publishes b + 1 in a device word once all its workgroups have written their rows back, and the FIRST sampler
+// launch of batch b + 1 -- enqueued with no stream dependency on batch b -- polls that word right before its first
+// read of the CSR.  Forward progress: the host enqueues the waiting launch only after the publishing launch (and hence
+// everything the publisher depends on); hardware queues are in order, so no launch the publisher needs can sit behind
+// a waiter; waiters hold a few hundred wave slots at most.  A waiter that outlasts kChainTimeoutTicks marks the batch
+// invalid (`error`) and goes on -- it never hangs.
+constexpr int kChainGroups = 32;
+constexpr size_t kChainWords = 2 + kChainGroups;                  // flag | top | per-group arrival counters
+constexpr unsigned long long kChainTimeoutTicks = 300000000ull;   // 3 s of the 100 MHz wall clock
+struct ChainSync {
+  uint32_t *words;     // null: no hand-off (khop0, stateless entry points, event-ordered samplers)
+  uint32_t *error;     // batch summary's overflow word
+  uint32_t wait_for;   // do_wait: proceed once the published count has reached this (batches are numbered from 0)
+  uint32_t publish;    // do_publish: the count to publish when the whole grid is done (wait_for + 1)
+  uint32_t do_wait, do_publish;
+};
+
+__device__ __forceinline__ void chain_wait(const ChainSync &c) {  // one lane per workgroup, a barrier behind it
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(&c.words[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int32_t)(v - c.wait_for) >= 0) return;
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > kChainTimeoutTicks) {
+      if (c.error) atomicOr(c.error, 1u);
+      return;
+    }
+  }
+}
+
+// called by one lane of every workgroup that had a tile (tile <= last_tile), after a release fence by all its lanes
+// and a barrier.  Two levels of counters: a single word would take (grid x ~30 ns) of same-address atomics.
+__device__ __forceinline__ void chain_arrive(const ChainSync &c, uint32_t tile, uint32_t last_tile) {
+  const uint32_t g = tile % kChainGroups;
+  const uint32_t group_size = (last_tile - g) / kChainGroups + 1;  // tiles t <= last_tile with t % groups == g (g <= last_tile)
+  const uint32_t ngroups = last_tile + 1 < (uint32_t)kChainGroups ? last_tile + 1 : (uint32_t)kChainGroups;
+  uint32_t *sub = c.words + 2 + g;
+  if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 != group_size) return;
+  __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next publishing launch
+  if (__hip_atomic_fetch_add(&c.words[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 != ngroups) return;
+  __hip_atomic_store(&c.words[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&c.words[0], c.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a batch without a sampler launch (no seeds, or given up on an error) still takes its turn: wait, then publish
+int launch_chain_pass(const ChainSync &c, hipStream_t stream);  // sample_khop.hip
+
 struct ScanWsHost;
 // where the dedup's last pass leaves the sizes of the layer it just closed (all device pointers, nullable)
 struct LayerSummary {
@@ -666,11 +717,11 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
                       void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr,
-                      bool resolve = false);
+                      bool resolve = false, const ChainSync *chain = nullptr);
 int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                      void *stream, ScanWsHost *scan);
+                      void *stream, ScanWsHost *scan, const ChainSync *chain = nullptr);
 // resolve: the fill is the batch's last (hashtable_fill_duplicates_ex(..., final_fill, resolved = true) must follow):
 // ws[e] receives the insert's OUTCOME (ht_insert_resolve) instead of the bucket.  Needs ht->disp.
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
                                                         uint32_t tag, FuseArgs fuse, uint32_t ablate, ScanWs scan,
-                                                        size_t *d_num_out) {
+                                                        size_t *d_num_out, ChainSync chain) {
   constexpr int NW = T / kWave;
   static_assert(T >= S && T % kWave == 0, "threads per workgroup");
   extern __shared__ uint32_t dyn[];
@@ -279,7 +279,11 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
       if (klen > kHugeRow) reservoir(row, klen, (uint32_t)tid, T);  // workgroup-uniform
     }
   }
+  // khop2's batch order, handed over on the device (fgnn_device.h, ChainSync): everything above reads immutable
+  // inputs only; the rows themselves are first read below
+  if (KHOP2 && chain.words && chain.do_wait && tid == 0) chain_wait(chain);
   __syncthreads();
+  if (KHOP2 && chain.words && chain.do_wait) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   phase_mark(scan, tile, 1);
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
@@ -375,6 +379,16 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
   }
   phase_mark(scan, tile, 4);
+  if (KHOP2 && chain.words && chain.do_publish) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this lane's row stores are visible device-wide ...
+    __syncthreads();                                    // ... for every lane of the workgroup
+    if (tid == 0) chain_arrive(chain, tile, last_tile);
+  }
+}
+
+__global__ void chain_pass_kernel(ChainSync chain) {
+  if (chain.do_wait) chain_wait(chain);
+  if (chain.do_publish) __hip_atomic_store(&chain.words[0], chain.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool KHOP2>
@@ -382,12 +396,14 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
                 size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr,
-                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr, bool resolve = false) {
+                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr, bool resolve = false,
+                const ChainSync *chain_in = nullptr) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
+  const ChainSync chain = chain_in ? *chain_in : ChainSync{nullptr, nullptr, 0, 0, 0, 0};
   if (cap == 0) {
     if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), stream));
-    return FGNN_OK;
+    return chain.words ? launch_chain_pass(chain, stream) : FGNN_OK;  // no launch: the batch still takes its turn
   }
   if (cap > 0xffffffffull) return FGNN_EINVAL;
   const uint32_t F = (uint32_t)fanout;
@@ -450,7 +466,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     }                                                                                                          \
     hipLaunchKernelGGL((khop_sample_kernel<SS, 256, KHOP2, FM>), dim3(nb), dim3(256), lds, stream, indptr, indices, \
                        input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag, fuse, ablate, scan, d_num_out);                                         \
+                       batch_key, tag, fuse, ablate, scan, d_num_out, chain);                                  \
   } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \
@@ -471,16 +487,23 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
 
 }  // namespace
 
+int launch_chain_pass(const ChainSync &c, hipStream_t stream) {
+  if (!c.words) return FGNN_OK;
+  hipLaunchKernelGGL(chain_pass_kernel, dim3(1), dim3(1), 0, stream, c);
+  return launch_status(__func__);
+}
+
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start, bool resolve) {
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start, bool resolve,
+                      const ChainSync *chain) {
   if (!ht) return FGNN_EINVAL;
   if (start && (d_num_input || !start->n2o)) return FGNN_EINVAL;  // the first launch takes the seeds with a host count
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
-                                   resolve)
+                                   resolve, chain)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                     d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
                                     resolve);
@@ -491,10 +514,11 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
 int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                      void *stream, ScanWsHost *scan) {
+                      void *stream, ScanWsHost *scan, const ChainSync *chain) {
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan)
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan,
+                                   nullptr, false, chain)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                     d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan);
 }
