@@ -577,6 +577,13 @@ void Engine::PublishSlot(int slot) {
   P.LogEpochAdd(key, kLogEpochSampleGetCacheMissIndexTime, ms_index * 1e-3);
   P.LogEpochAdd(key, kLogEpochSampleSendTime, ms_send * 1e-3);
   P.LogEpochAdd(key, kLogEpochSampleTotalTime, total);
+  if (s.started_us) {  // the engine's own events of the Chrome trace (profiler.h:142-165): sample = enqueue .. published
+    const uint64_t now = Timer::NowMicro();
+    P.TraceStep(key, kL1Event_Sample, s.started_us, true);
+    P.TraceStep(key, kL1Event_Sample, now, false);
+    P.TraceStep(key, kL2Event_Sample_Core, s.started_us, true);
+    P.TraceStep(key, kL2Event_Sample_Core, s.started_us + (uint64_t)(ms_sample * 1e3), false);
+  }
   sstat_.pub_rest += t_pub.Passed();
 }
 
@@ -596,6 +603,7 @@ void Engine::SampleOnceArch5() {
   }
   sstat_.slot_wait += t_wait.Passed();
   s.started = Timer();
+  s.started_us = RC().option_dump_trace ? Timer::NowMicro() : 0;
   s.key = key;
   SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, s.st));
   const bool use_cache = RC().UseGPUCache();
@@ -710,6 +718,7 @@ void Engine::TrainerOnce() {
 void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
   hipStream_t tstream_ = x.st;  // everything of this batch goes to the context's stream
   hipEvent_t *te_ = x.ev;
+  const uint64_t recv_us = RC().option_dump_trace ? Timer::NowMicro() : 0;
   Timer t_recv;
   size_t mq_key = taken_key;
   const char *msg = static_cast<const char *>(taken ? taken : mq_->Recv(&mq_key));
@@ -863,6 +872,7 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
   xstat_.issue += t_copy.Passed();
   ++xstat_.n;
   x.recv_time = recv_time;
+  x.recv_us = recv_us;
   x.t_copy = t_copy;
   x.timed_gathers = timed_gathers;
   x.miss_rows = miss_rows;
@@ -909,6 +919,14 @@ void Engine::TrainerComplete(ExtractCtx &x) {
   P.LogEpochAdd(b->key, kLogEpochCopyTime, recv_time + copy_time);
   P.LogEpochAdd(b->key, kLogEpochFeatureBytes, (double)hdr.input_size * row_bytes);
   P.LogEpochAdd(b->key, kLogEpochMissBytes, (double)miss_rows * row_bytes);
+  if (x.recv_us) {  // copy = message received .. batch handed to the graph pool
+    const uint64_t now = Timer::NowMicro();
+    P.TraceStep(b->key, kL1Event_Copy, x.recv_us, true);
+    P.TraceStep(b->key, kL1Event_Copy, now, false);
+    P.TraceStep(b->key, RC().UseGPUCache() ? kL2Event_Copy_CacheCopy : kL2Event_Copy_Extract,
+                x.recv_us + (uint64_t)(recv_time * 1e6), true);
+    P.TraceStep(b->key, RC().UseGPUCache() ? kL2Event_Copy_CacheCopy : kL2Event_Copy_Extract, now, false);
+  }
 }
 
 void Engine::StartExtract(int count) {

@@ -159,6 +159,7 @@ class Engine {
     std::shared_ptr<GraphBatch> b;
     size_t mq_key = 0, miss_rows = 0, graph_bytes = 0, input_size = 0, output_size = 0;
     double recv_time = 0;
+    uint64_t recv_us = 0;     // SAMGRAPH_DUMP_TRACE: wall clock when the receive began
     Timer t_copy;
     bool timed_gathers = false;
   };
@@ -198,6 +199,7 @@ class Engine {
     size_t mq_key = 0;
     uint64_t key = 0;
     Timer started;
+    uint64_t started_us = 0;  // SAMGRAPH_DUMP_TRACE: wall clock of the sample_once call
   };
   std::vector<Slot> slots_;
   size_t next_slot_ = 0;

@@ -2,6 +2,7 @@
 // tables [item][epoch*num_step+step]; the getters and item numbering are part of the Python contract.
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 namespace sam {
@@ -26,6 +27,13 @@ enum {
 enum {
   kLogEpochSampleTime = 0, kLogEpochSampleGetCacheMissIndexTime = 1, kLogEpochSampleSendTime = 2,
   kLogEpochSampleTotalTime = 3, kLogEpochCopyTime = 4, kLogEpochFeatureBytes = 8, kLogEpochMissBytes = 9,
+};
+
+enum {  // trace items (profiler.h:142-165)
+  kL0Event_Train_Step = 0, kL1Event_Sample = 1, kL2Event_Sample_Shuffle = 2, kL2Event_Sample_Core = 3,
+  kL2Event_Sample_IdRemap = 4, kL1Event_Copy = 5, kL2Event_Copy_Id = 6, kL2Event_Copy_Graph = 7,
+  kL2Event_Copy_Extract = 8, kL2Event_Copy_FeatCopy = 9, kL2Event_Copy_CacheCopy = 10, kL1Event_Convert = 17,
+  kL1Event_Train = 18,
 };
 
 class Profiler {
@@ -55,6 +63,7 @@ class Profiler {
   std::vector<double> epoch_[kNumLogEpochItems];
   struct Trace { uint64_t key; int item; uint64_t begin, end; };
   std::vector<Trace> traces_;
+  mutable std::mutex trace_mu_;  // the engine's threads and the script log events concurrently
 };
 
 }  // namespace sam

@@ -204,3 +204,68 @@ def test_queue_named_regions_between_unrelated_processes(hooks, producers, consu
             if f.startswith(prefix):
                 os.unlink(os.path.join("/dev/shm", f))
     assert not [f for f in os.listdir("/dev/shm") if f.startswith(prefix)]
+
+
+_PROFILER_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+from fgnn_hip import synth
+import samgraph.torch as sam  # imports torch + the engine library; no GPU call below
+wd = sys.argv[2]
+d = synth.write_dataset(wd, "g", 2000, 20000, 4, 5, 300, 20, 20, seed=3)
+sam.config(dict(dataset_path=d, _arch=sam.kArch5, _sample_type=sam.kKHop2, batch_size=100, num_epoch=2,
+                _cache_policy=sam.kCacheByPreSample, cache_percentage=0.1, max_sampling_jobs=1, max_copying_jobs=1,
+                omp_thread_num=1, num_sample_worker=1, num_train_worker=1, num_fanout=2, fanout=[5, 3]))
+sam.data_init()                       # arch5: dataset + shared queue, no GPU touched
+assert sam.steps_per_epoch() == 3 and sam.num_epoch() == 2
+for step in range(3):
+    sam.log_step(1, step, sam.kLogL1SampleTime, 0.5 + step)
+    sam.log_step(1, step, sam.kLogL1FeatureBytes, 3 * 1024 * 1024)
+    sam.log_step(1, step, sam.kLogL2CacheCopyTime, 0.25)
+    sam.log_step(1, step, sam.kLogL3CacheCombineMissTime, 0.125)
+    sam.log_epoch_add(1, sam.kLogEpochSampleTime, 0.5 + step)
+assert sam.get_log_step_value(1, 2, sam.kLogL1SampleTime) == 2.5
+assert sam.get_log_epoch_value(1, sam.kLogEpochSampleTime) == 4.5
+sam.report_init()
+sam.report_step(1, 2)
+sam.report_step_average(1, 2)
+sam.report_epoch(1)
+sam.report_epoch_average(1)
+key = 1 * 3 + 2
+sam.trace_step_begin(key, sam.kL1Event_Train, 1000)
+sam.trace_step_end(key, sam.kL1Event_Train, 1500)
+sam.trace_step_begin(key, sam.kL3Event_Copy_CacheCopy_CombineMiss, 1100)
+sam.trace_step_end(key, sam.kL3Event_Copy_CacheCopy_CombineMiss, 1200)
+sam.trace_step_begin_now(key, sam.kL0Event_Train_Step)
+sam.trace_step_end_now(key, sam.kL0Event_Train_Step)
+sam.trace_step_begin(key + 1, sam.kL1Event_Copy, 2000)   # never ended: skipped with a warning
+sam.dump_trace()
+sys.stdout.flush()
+"""
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_profiler_reports_and_trace_dump(tmp_path, level):
+    """samgraph_report_* gated by SAMGRAPH_PROFILE_LEVEL with the reference's item names (profiler.cc:371-557), and
+    samgraph_dump_trace writing the Chrome trace JSON of profiler.cc:286-364 (B/E pairs named <item>-<key>) -- to the
+    file SAMGRAPH_DUMP_TRACE names.  Runs through samgraph.torch with arch5's data_init only: no GPU needed."""
+    import json
+    trace = tmp_path / "trace.json"
+    env = dict(os.environ, SAMGRAPH_PROFILE_LEVEL=str(level), SAMGRAPH_DUMP_TRACE=str(trace))
+    p = subprocess.run([sys.executable, "-c", _PROFILER_SCRIPT, os.path.join(ROOT, "fgnn-artifacts_amd"), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    out = p.stdout
+    assert "[Step(profile) Profiler Level 1 E1 S2]" in out and "SampleTime 2.5000" in out
+    assert "FeatureBytes 3.00 MB" in out
+    assert "[Step(average) Profiler Level 1 E1 S2]" in out
+    assert "[Init Profiler Level 1]" in out and "[Epoch(profile) E1]" in out and "SampleTime 4.5000" in out
+    assert ("Profiler Level 2 E1 S2]" in out) == (level >= 2) and ("CacheCopyTime 0.2500" in out) == (level >= 2)
+    assert ("CacheCombineMissTime 0.1250" in out) == (level >= 3)
+    ev = json.loads(trace.read_text())
+    names = [(e["name"], e["ph"], e["tid"]) for e in ev]
+    assert ("kL1Event_Train-5", "B", 3) in names and ("kL1Event_Train-5", "E", 3) in names
+    assert ("kL3Event_Copy_CacheCopy_CombineMiss-5", "B", 2) in names and ("kL0Event_Train_Step-5", "E", 0) in names
+    assert not [n for n in names if n[0].startswith("kL1Event_Copy-")] and "without end" in p.stderr
+    t = {(e["name"], e["ph"]): e["ts"] for e in ev}
+    assert t[("kL1Event_Train-5", "B")] == 1000 and t[("kL1Event_Train-5", "E")] == 1500
