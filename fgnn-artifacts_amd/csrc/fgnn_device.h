@@ -606,10 +606,16 @@ struct ChainSync {
   uint32_t do_wait, do_publish;
 };
 
+// Cache discipline (measured: with agent-scope acquire / release FENCES -- an L2 invalidate per poll, an L2 write-back
+// per arriving wave -- the step went 0.119 -> 0.198 ms, profiles/r03_ab2_chain_flags_v1_fenced.txt): no fence at agent
+// scope anywhere.  The publishing launch writes its rows with agent-scope atomic stores (write-through: complete =
+// visible device-wide), waits for their completion (workgroup-scope release = s_waitcnt) and only then arrives; the
+// waiting launch polls with relaxed loads and reads the rows with agent-scope atomic loads, which no stale cache line
+// can serve.  Every access of the hand-off is an atomic at agent scope; the counters order them.
 __device__ __forceinline__ void chain_wait(const ChainSync &c) {  // one lane per workgroup, a barrier behind it
   const unsigned long long t0 = wall_clock64();
   for (;;) {
-    const uint32_t v = __hip_atomic_load(&c.words[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t v = __hip_atomic_load(&c.words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int32_t)(v - c.wait_for) >= 0) return;
     __builtin_amdgcn_s_sleep(32);
     if (wall_clock64() - t0 > kChainTimeoutTicks) {
@@ -619,18 +625,19 @@ __device__ __forceinline__ void chain_wait(const ChainSync &c) {  // one lane pe
   }
 }
 
-// called by one lane of every workgroup that had a tile (tile <= last_tile), after a release fence by all its lanes
-// and a barrier.  Two levels of counters: a single word would take (grid x ~30 ns) of same-address atomics.
+// called by one lane of every workgroup that had a tile (tile <= last_tile), once the row stores of all its lanes have
+// completed (workgroup-scope release + barrier).  Two levels of counters: a single word would take (grid x ~30 ns) of
+// same-address atomics.
 __device__ __forceinline__ void chain_arrive(const ChainSync &c, uint32_t tile, uint32_t last_tile) {
   const uint32_t g = tile % kChainGroups;
   const uint32_t group_size = (last_tile - g) / kChainGroups + 1;  // tiles t <= last_tile with t % groups == g (g <= last_tile)
   const uint32_t ngroups = last_tile + 1 < (uint32_t)kChainGroups ? last_tile + 1 : (uint32_t)kChainGroups;
   uint32_t *sub = c.words + 2 + g;
-  if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 != group_size) return;
+  if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != group_size) return;
   __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next publishing launch
-  if (__hip_atomic_fetch_add(&c.words[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 != ngroups) return;
+  if (__hip_atomic_fetch_add(&c.words[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != ngroups) return;
   __hip_atomic_store(&c.words[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&c.words[0], c.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&c.words[0], c.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // a batch without a sampler launch (no seeds, or given up on an error) still takes its turn: wait, then publish
 int launch_chain_pass(const ChainSync &c, hipStream_t stream);  // sample_khop.hip
