@@ -665,6 +665,15 @@ def run_single(args):
                      "serial": serial, "torch_copy_GBps": copy_gbs,
                      "torch_copy_GBps_spread": {"min": min(copies), "max": max(copies), "samples": copies}},
         "roofline_extract": extract_leg,
+        # the N >= 2 lines measure the factored pipeline with the features in HOST memory behind a cache_ratio cache; the
+        # same work on ONE GPU (this process samples AND does the cached extraction with host misses) is the N = 1 point
+        # of that curve -- `value` above is config 2's shape (features HBM-resident) and is not comparable with N >= 2
+        "pipeline_n1_point": ({"value": (edges / args.steps) / (extract_leg["ms_per_step"] * 1e-3), "unit": "edges/s",
+                               "ms_per_step": extract_leg["ms_per_step"],
+                               "what": "sample + dedup + remap + cache split + cached extraction (hits from the HBM cache, "
+                                       "misses over the host link) on one GPU: the like-for-like N = 1 point of the "
+                                       "--gpus N >= 2 pipeline lines"}
+                              if extract_leg and "ms_per_step" in extract_leg else None),
         "epoch_time_s": {"sample_plus_extract": steps_per_epoch * (elapsed / args.steps),
                          "sample_plus_extract_cache_0.2_host_misses":
                              steps_per_epoch * extract_leg["ms_per_step"] * 1e-3
@@ -951,6 +960,9 @@ class EngineBackend:
                 "graph_bytes": tot(sam.kLogL1GraphBytes), "ms_miss": tot(sam.kLogL3CacheCombineMissTime) * 1e3,
                 "ms_cache": tot(sam.kLogL3CacheCombineCacheTime) * 1e3}
 
+    def queue_stats(self, rings):
+        return [self.sam.ext_queue_stats(r) for r in range(rings)]
+
     def shutdown(self):
         self.sam.shutdown()
 
@@ -1003,6 +1015,9 @@ class RehearsalBackend:
     def trainer_stats(self, keys):
         assert all(self.got[e * self.steps_per_epoch + s] == self.edges_of(e * self.steps_per_epoch + s) for e, s in keys)
         return {"rows": float(len(keys)), "miss_rows": 0.0, "graph_bytes": 0.0, "ms_miss": 0.0, "ms_cache": 0.0}
+
+    def queue_stats(self, rings):
+        return [None] * rings
 
     def shutdown(self):
         self.eng.fgnn_host_queue_close(self.q)
@@ -1061,6 +1076,11 @@ def run_pipeline_rank(args, rank, world):
         min_local = steps_per_epoch // S
         per_sampler = max(sum(split_count(n, S, 0) for n in (W, K, K2W, K2)), 1)
         num_epoch = (per_sampler + min_local - 1) // min_local + 1
+        # hand-off self-check in the untimed warm-up region: every sampler checksums its first W // S messages, the
+        # trainer that receives one recomputes the sum through the address it reads the payload from (the sampler's
+        # HBM slot mapped over xGMI, or the pinned host slot) and the job dies on a mismatch (eng_engine.cc)
+        check_n = W // S
+        os.environ["SAMGRAPH_HANDOFF_CHECK"] = str(check_n)
         be = (RehearsalBackend if args.rehearse else EngineBackend)(args, w, job, S, T, is_sampler, idx, dev_id, num_epoch)
         dist.barrier()  # every process has attached to every shared region
         if is_sampler:
@@ -1158,10 +1178,26 @@ def run_pipeline_rank(args, rank, world):
             [stats["edges"], stats["rows"], stats["miss_rows"], stats["graph_bytes"], stats["ms_miss"],
              stats["ms_cache"], n_batches if is_sampler else 0, n_batches if not is_sampler else 0],
             dist.ReduceOp.SUM)
+        dist.barrier()  # every trainer has verified what it was going to verify
+        rings = be.queue_stats(S) if rank == 0 else None  # shared counters: any process of the job can read them
         be.shutdown()
         dist.barrier()
         if rank == 0:
             assert int(nb_s) == K and int(nb_t) == K, (nb_s, nb_t, K)
+            live = [r for r in rings if r]
+            handoff = {"rings": rings, "check_messages_per_sampler": check_n,
+                       "verified": sum(r["verified"] for r in live), "check_failed": sum(r["check_failed"] for r in live),
+                       "sent_device": sum(r["sent_device"] for r in live), "sent_host": sum(r["sent_host"] for r in live),
+                       "spilled": sum(r["spilled"] for r in live),
+                       "transport": ("none (rehearsal)" if not live else
+                                     "sampler HBM ring, peer-read by the trainers" if all(
+                                         r["sent_host"] == 0 and r["spilled"] == 0 and r["sent_device"] > 0 for r in live)
+                                     else "pinned host ring" if all(r["sent_device"] == 0 for r in live)
+                                     else "MIXED: part of the messages fell back to the pinned host ring"),
+                       "note": "per sampler ring: slots, messages by payload location, copies back on request, and the "
+                               "warm-up messages the receiving trainers verified end to end (a mismatch aborts the job)"}
+            if live and handoff["check_failed"]:
+                sys.exit("bench.py: hand-off check failed: %s" % handoff)
             row_b = w["feat_dim"] * 4
             hit_rows = rows - miss_rows
             handoff_bytes = graph_bytes + 8 * rows + 4 * bs * K  # COO arrays + (miss|cache) index pairs + output ids
@@ -1195,7 +1231,11 @@ def run_pipeline_rank(args, rank, world):
                     "sampler_busy_s": s_busy, "trainer_busy_s": t_busy,
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
-                    "handoff_peak_GBps": XGMI_LINK_GBS,
+                    "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff,
+                    "n1_point_of_this_curve": "N = 1 runs config 2's shape (features HBM-resident, no hand-off); the "
+                                              "like-for-like N = 1 point of THIS pipeline (host-memory features behind a "
+                                              f"{args.cache_ratio} cache, one GPU doing both halves) is the N = 1 line's "
+                                              "`pipeline_n1_point.value` (= edges_per_step / roofline_extract.ms_per_step)",
                     "miss": {"bound": "host link", "bytes_per_step": miss_rows * row_b / K,
                              "achieved": miss_rows * row_b / t_max / 1e9 / T, "peak": HOST_LINK_GBS,
                              "unit": "GB/s per trainer GPU", "frac": miss_rows * row_b / t_max / 1e9 / T / HOST_LINK_GBS,

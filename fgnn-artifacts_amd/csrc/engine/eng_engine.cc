@@ -389,6 +389,8 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   SAM_CHECK(ctx.IsGPU()) << "sampler context must be cuda:N (no CPU sampling path in this build)";
   Timer t;
   dist_type_ = DistType::Sample;
+  worker_id_ = worker_id;
+  if (const char *e = getenv("SAMGRAPH_HANDOFF_CHECK")) handoff_check_left_ = (size_t)strtoull(e, nullptr, 10);
   const bool arch6 = RC().run_arch == kArch6;
   if (arch6) CreateQueue();  // joins this worker's sampler half and extractor half only
   UploadTopology(ctx.device_id);
@@ -628,7 +630,22 @@ void Engine::SampleOnceArch5() {
   a.payload = mq_->ClaimDeviceSlot(ring_id_, s.mq_key);  // null: no device ring, or none of its slots is free
   a.slot_bytes = mq_->SlotBytes();
   a.h_meta = reinterpret_cast<uint32_t *>(fgnn_batch_host_meta(s.fb));
+  const bool check = handoff_check_left_ > 0;
+  if (check) {
+    --handoff_check_left_;
+    if (!s.d_msg_words) SAM_HIP(hipMalloc(&s.d_msg_words, sizeof(uint32_t)));
+    a.msg_words = s.d_msg_words;
+  }
+  mq_->MarkChecked(s.mq_key, worker_id_, check);
   SAM_FGNN(LaunchPack(a, s.st));
+  if (check) {  // checksum of the packed words, appended behind them in the slot the payload went to
+    uint32_t *where = static_cast<uint32_t *>(a.payload ? a.payload : a.slot);
+    SAM_FGNN(LaunchMessageChecksum(where, s.d_msg_words, 0, 0, nullptr, s.st));
+    // SAMGRAPH_HANDOFF_CHECK_SELFTEST=corrupt: one payload word is overwritten AFTER the checksum was taken, as a
+    // broken mapping would deliver it -- the receivers must refuse the message (tests prove the check can fail)
+    static const bool corrupt = [] { const char *e = getenv("SAMGRAPH_HANDOFF_CHECK_SELFTEST"); return e && !strcmp(e, "corrupt"); }();
+    if (corrupt) SAM_HIP(hipMemsetAsync(where + sizeof(TransData) / 4 + 1, 0x5a, 4, s.st));
+  }
   SAM_FGNN(fgnn_batch_meta_copied(s.fb));  // by the pack kernel
   SAM_FGNN(fgnn_batch_finish(s.fb, s.st));
   {  // hand the batch to the publisher thread: it waits for the GPU work and publishes in this order
@@ -821,6 +838,16 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     graph_bytes += v.num_edge * (hdr.have_data ? 12 : 8);
   }
   SAM_CHECK_LE((size_t)((const char *)p - msg), mq_->SlotBytes());
+  x.checking = mq_->IsChecked(mq_key);
+  if (x.checking) {
+    // the sender's checksum, recomputed through the very address the arrays are read from (the sampler's HBM slot
+    // mapped over xGMI, or the pinned host slot): a mapping that reads garbage must not pass as a slow but valid run
+    if (!x.d_check) SAM_HIP(hipMalloc(&x.d_check, sizeof(uint32_t)));
+    SAM_HIP(hipMemsetAsync(x.d_check, 0, sizeof(uint32_t), tstream_));
+    const char *base = payload_on_device ? payload : static_cast<const char *>(mq_->DeviceVisiblePtr(msg));
+    SAM_FGNN(LaunchMessageChecksum(reinterpret_cast<uint32_t *>(const_cast<char *>(base)), nullptr,
+                                   (size_t)((const char *)p - msg) / sizeof(uint32_t), 1, x.d_check, tstream_));
+  }
   SAM_FGNN(LaunchUnpack(ua, tstream_));
 
   // features (DoCacheFeatureCopy / DoSwitchCacheFeatureCopy / DoCPUFeatureExtract+DoFeatureCopy)
@@ -897,6 +924,15 @@ void Engine::TrainerComplete(ExtractCtx &x) {
   Timer t_sync;
   SAM_HIP(hipStreamSynchronize(tstream_));
   xstat_.sync += t_sync.Passed();
+  if (x.checking) {
+    uint32_t bad = 0;
+    SAM_HIP(hipMemcpy(&bad, x.d_check, sizeof(bad), hipMemcpyDeviceToHost));
+    mq_->CountCheck(mq_key, bad == 0);
+    SAM_CHECK(bad == 0) << "hand-off check: message " << mq_key << " (batch key " << b->key
+                        << ") does not verify on the receiving GPU -- the payload read through the "
+                        << "mapped slot differs from what the sampler packed";
+    x.checking = false;
+  }
   mq_->Release(mq_key);
   pool_->Submit(b);
 
@@ -1063,6 +1099,7 @@ void Engine::Shutdown() {
     for (auto &e : x.ev)
       if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (x.st) { (void)hipStreamDestroy(x.st); x.st = nullptr; }
+    if (x.d_check) { (void)hipFree(x.d_check); x.d_check = nullptr; }
     x.b.reset();
   }
   if (mq_ && ring_id_ >= 0) {
@@ -1087,6 +1124,7 @@ void Engine::Shutdown() {
     if (s.e1) (void)hipEventDestroy(s.e1);
     if (s.e2) (void)hipEventDestroy(s.e2);
     if (s.st && s.owns_st) (void)hipStreamDestroy(s.st);
+    if (s.d_msg_words) (void)hipFree(s.d_msg_words);
   }
   slots_.clear();
   if (sampler_) {

@@ -102,6 +102,7 @@ class Engine {
   uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_step_ + step; }
   Dataset &Data() { return ds_; }
   void ForwardBarrier() { outer_counter_++; }
+  bool QueueStats(int ring, uint64_t out[6]) const { return mq_ && mq_->RingStats(ring, out); }
   // sample_once only enqueues a batch; its profiler values appear when the publisher thread has published it.  The
   // profiler getters / reports of the C ABI call this first: everything enqueued so far is published (and logged).
   void SyncPublished() { if (publish_thread_.joinable()) PublishPending(); }
@@ -162,6 +163,8 @@ class Engine {
     uint64_t recv_us = 0;     // SAMGRAPH_DUMP_TRACE: wall clock when the receive began
     Timer t_copy;
     bool timed_gathers = false;
+    uint32_t *d_check = nullptr;  // SAMGRAPH_HANDOFF_CHECK: result word of the verification kernel
+    bool checking = false;
   };
   ExtractCtx xctx_[kExtractDepth];
   // where the extraction thread's time goes (reported at shutdown, log level info)
@@ -200,6 +203,7 @@ class Engine {
     uint64_t key = 0;
     Timer started;
     uint64_t started_us = 0;  // SAMGRAPH_DUMP_TRACE: wall clock of the sample_once call
+    uint32_t *d_msg_words = nullptr;  // SAMGRAPH_HANDOFF_CHECK: message length left by the pack kernel
   };
   std::vector<Slot> slots_;
   size_t next_slot_ = 0;
@@ -220,6 +224,10 @@ class Engine {
   std::thread extract_thread_, sample_thread_;
   std::atomic<bool> shutdown_{false};
   std::atomic<size_t> outer_counter_{0};
+  // SAMGRAPH_HANDOFF_CHECK=n: this sampler appends a checksum to its first n messages; a receiver verifies every
+  // message that carries one through the address it reads the payload from, and aborts on a mismatch
+  size_t handoff_check_left_ = 0;
+  int worker_id_ = 0;
 };
 
 // presample.hip

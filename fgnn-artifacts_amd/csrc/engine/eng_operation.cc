@@ -6,6 +6,7 @@
 
 #include "eng_engine.h"
 #include "samgraph.h"
+#include "samgraph_ext.h"
 
 using namespace sam;
 
@@ -111,6 +112,12 @@ void samgraph_trace_step_end_now(uint64_t key, int item) {
 void samgraph_dump_trace(void) { Profiler::Get().DumpTrace(); }
 
 void samgraph_forward_barrier(void) { Engine::Get().ForwardBarrier(); }
+
+// include/samgraph_ext.h
+int samgraph_ext_queue_stats(int ring, uint64_t out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  return Engine::Get().QueueStats(ring, out) ? 0 : -1;
+}
 
 void samgraph_data_init(void) {
   SAM_CHECK(RC().is_configured);

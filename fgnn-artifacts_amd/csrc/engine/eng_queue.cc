@@ -31,7 +31,11 @@ MemoryQueue::MemoryQueue(size_t slot_bytes, size_t num_slots) {
     meta_->pub_seq[i] = 0;
     meta_->rel_seq[i] = 0;
     meta_->payload_loc[i] = 0;
+    meta_->checked[i] = 0;
+    meta_->sender[i] = 0;
   }
+  memset(meta_->check_verified, 0, sizeof(meta_->check_verified));
+  memset(meta_->check_failed, 0, sizeof(meta_->check_failed));
   memset(meta_->rings, 0, sizeof(meta_->rings));
   meta_->ipc_broken = 0;
   SharedPublish(meta_);
@@ -186,6 +190,18 @@ void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {
     local_slot_[ring][i] = nullptr;
   }
   owns_ring_[ring] = false;
+}
+
+bool MemoryQueue::RingStats(int ring, uint64_t out[6]) const {
+  if (ring < 0 || ring >= kMaxRings) return false;
+  const RingInfo &r = meta_->rings[ring];
+  out[0] = r.ready ? r.slots : 0;
+  out[1] = r.sent_device;
+  out[2] = r.sent_host;
+  out[3] = r.spilled;
+  out[4] = meta_->check_verified[ring];
+  out[5] = meta_->check_failed[ring];
+  return true;
 }
 
 void MemoryQueue::PinMemory() {

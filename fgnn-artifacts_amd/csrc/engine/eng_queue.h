@@ -67,6 +67,11 @@ struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   size_t rel_seq[kMaxSlots];        // generations of the slot released so far: message k may be written at k / N
   uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
   int ipc_broken;                   // set by the first receiver that could not map a ring: samplers stop using theirs
+  // SAMGRAPH_HANDOFF_CHECK: a message whose sender appended a checksum of its words behind it (pack.hip); the receiver
+  // recomputes it THROUGH THE ADDRESS IT READS THE PAYLOAD FROM (mapped HBM slot, host slot) before it uses the batch
+  uint32_t checked[kMaxSlots];      // 1: the message in the slot carries the trailer; + which sampler sent it
+  uint32_t sender[kMaxSlots];
+  size_t check_verified[kMaxRings], check_failed[kMaxRings];  // per sending sampler, counted by the receivers
   RingInfo rings[kMaxRings];
   alignas(256) char data[0];
 };
@@ -80,6 +85,18 @@ class MemoryQueue {
   const void *Recv(size_t *key);                     // blocks until a message is available
   bool TryRecv(const void **data, size_t *key);      // never blocks: takes the oldest message only if it is PUBLISHED
   void Release(size_t key);                          // SharedData::~SharedData
+  // hand-off check bookkeeping (see QueueMeta)
+  void MarkChecked(size_t key, int sender, bool on) {
+    meta_->checked[key % meta_->max_size] = on ? 1u : 0u;
+    meta_->sender[key % meta_->max_size] = (uint32_t)sender;
+  }
+  bool IsChecked(size_t key) const { return meta_->checked[key % meta_->max_size] != 0; }
+  void CountCheck(size_t key, bool ok) {
+    const uint32_t sdr = meta_->sender[key % meta_->max_size] % kMaxRings;
+    __atomic_fetch_add(ok ? &meta_->check_verified[sdr] : &meta_->check_failed[sdr], 1, __ATOMIC_RELAXED);
+  }
+  // out[6] as samgraph_ext_queue_stats (include/samgraph_ext.h); false: no such ring
+  bool RingStats(int ring, uint64_t out[6]) const;
   size_t SlotBytes() const { return meta_->mq_nbytes; }
   size_t NumSlots() const { return meta_->max_size; }
   // slots claimed for sending and not yet claimed by a receiver -- NOT the number of receivable messages (a claimed
@@ -130,6 +147,7 @@ struct PackArgs {
   void *payload;         // device-ring slot for the arrays (same layout and offsets as the host slot), or null
   size_t slot_bytes;
   uint32_t *h_meta;      // pinned copy of the batch summary the pack kernel fills on the way (fgnn_batch_host_meta), or null
+  uint32_t *msg_words;   // device word that receives the message length in 4-byte words (0: did not fit), or null
 };
 // enqueues the serialisation of one batch into `slot` (device-visible host memory)
 int LaunchPack(const PackArgs &a, hipStream_t stream);
@@ -143,5 +161,12 @@ struct UnpackArgs {
   struct { uint32_t *dst; const uint32_t *src; size_t words; } seg[kMaxSegments];
 };
 int LaunchUnpack(const UnpackArgs &a, hipStream_t stream);
+
+// SAMGRAPH_HANDOFF_CHECK.  Sender (verify == 0): position-weighted 64-bit sum of the message's words -> the two words
+// behind the message (`msg` = where the payload was packed; length from *d_words, written by the pack kernel).
+// Receiver (verify != 0): the same sum over `words` words read through `msg`, compared with the trailer; *d_result |= 1
+// on a mismatch.
+int LaunchMessageChecksum(uint32_t *msg, const uint32_t *d_words, size_t words, int verify, uint32_t *d_result,
+                          hipStream_t stream);
 
 }  // namespace sam

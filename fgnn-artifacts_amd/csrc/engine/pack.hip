@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kPackBlock) void pack_kernel(PackArgs a) {
       }
     }
     hn = n;
+    if (a.msg_words) *a.msg_words = fits ? (uint32_t)(p - base) : 0u;  // SAMGRAPH_HANDOFF_CHECK: the checksum kernel's length
   }
   __syncthreads();
   // ... and the summary goes to the host from here (every other kernel that writes it is earlier in the stream; the
@@ -159,7 +160,38 @@ __global__ __launch_bounds__(kPackBlock) void unpack_kernel(UnpackArgs a) {
   copy_flat(tab);
 }
 
+// one workgroup: sum of word[i] * (2 i + 1) mod 2^64 -- a dropped, repeated, shifted or swapped word changes it
+constexpr int kSumBlock = 1024;
+__global__ __launch_bounds__(kSumBlock) void message_checksum_kernel(uint32_t *msg, const uint32_t *d_words,
+                                                                     size_t words_host, int verify, uint32_t *d_result) {
+  __shared__ unsigned long long part[kSumBlock / 64];
+  const size_t words = d_words ? *d_words : words_host;
+  unsigned long long s = 0;
+  for (size_t i = threadIdx.x; i < words; i += kSumBlock) s += (unsigned long long)msg[i] * (2ull * i + 1ull);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kSumBlock / 64; ++w) t += part[w];
+    if (!verify) {
+      if (words) {
+        msg[words] = (uint32_t)t;
+        msg[words + 1] = (uint32_t)(t >> 32);
+      }
+    } else if (words == 0 || msg[words] != (uint32_t)t || msg[words + 1] != (uint32_t)(t >> 32)) {
+      atomicOr(d_result, 1u);
+    }
+  }
+}
+
 }  // namespace
+
+int LaunchMessageChecksum(uint32_t *msg, const uint32_t *d_words, size_t words, int verify, uint32_t *d_result,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(message_checksum_kernel, dim3(1), dim3(kSumBlock), 0, stream, msg, d_words, words, verify, d_result);
+  return hipGetLastError() == hipSuccess ? FGNN_OK : FGNN_EHIP;
+}
 
 int LaunchUnpack(const UnpackArgs &a, hipStream_t stream) {
   size_t words = 0;

@@ -144,6 +144,12 @@ _SIGNATURES = {
 }
 
 
+# entry points the reference does not have (include/samgraph_ext.h); nothing reference-shaped depends on them
+_EXT_SIGNATURES = {
+    'samgraph_ext_queue_stats': (_int, (_int, ctypes.POINTER(_u64))),
+}
+
+
 class SamGraphBasics(object):
     """Same method surface as the reference class (common/__init__.py:268-500)."""
 
@@ -154,6 +160,10 @@ class SamGraphBasics(object):
                               "(the engine has no Python or CPU fallback)")
         self.C_LIB_CTYPES = ctypes.CDLL(full_path, mode=ctypes.RTLD_GLOBAL)
         for name, (res, argt) in _SIGNATURES.items():
+            fn = getattr(self.C_LIB_CTYPES, name)
+            fn.restype = res
+            fn.argtypes = argt
+        for name, (res, argt) in _EXT_SIGNATURES.items():
             fn = getattr(self.C_LIB_CTYPES, name)
             fn.restype = res
             fn.argtypes = argt
@@ -169,6 +179,14 @@ class SamGraphBasics(object):
                 for v in run_config.values()]
         n = len(keys)
         return self.C_LIB_CTYPES.samgraph_config((_cstr * n)(*keys), (_cstr * n)(*vals), n)
+
+    def ext_queue_stats(self, ring):
+        """hand-off statistics of sampler `ring` (include/samgraph_ext.h), or None without a queue / ring"""
+        out = (_u64 * 6)()
+        if self.C_LIB_CTYPES.samgraph_ext_queue_stats(ring, out) != 0:
+            return None
+        return dict(zip(("ring_slots", "sent_device", "sent_host", "spilled", "verified", "check_failed"),
+                        (int(x) for x in out)))
 
     def sample_init(self, worker_id, ctx):
         return self.C_LIB_CTYPES.samgraph_sample_init(worker_id, str.encode(ctx))

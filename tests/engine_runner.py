@@ -426,6 +426,9 @@ def run_arch5(sample_type, workdir, num_sampler, num_trainer, cache_pct, pipelin
     for p in procs:
         p.start()
     bad = _join_all(procs, ["sampler"] * num_sampler + ["trainer"] * num_trainer)
+    # hand-off statistics (include/samgraph_ext.h): the counters live in the shared queue region this parent created
+    for w in range(num_sampler):
+        print("ring %d stats %s" % (w, sam.ext_queue_stats(w)))
     if bad or err.value:
         sys.exit(1)
     print("arch5 %s %dS+%dT cache %.2f%s ok" % (sample_type, num_sampler, num_trainer, cache_pct,

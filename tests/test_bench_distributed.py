@@ -43,7 +43,7 @@ def _run(cmd, env=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gpus,samplers", [(2, 0), (4, 2), (3, 0)])
+@pytest.mark.parametrize("gpus,samplers", [(2, 0), (4, 2), (3, 0), (8, 0)])
 def test_plain_launch_spawns_ranks(gpus, samplers):
     """`python bench.py --gpus N` (how the driver ran it in round 1): bench.py starts the N rank processes itself"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -52,13 +52,14 @@ def test_plain_launch_spawns_ranks(gpus, samplers):
     if samplers:
         cmd += ["--samplers", str(samplers)]
     out = _run(cmd, env)
-    S = samplers or 1
+    S = samplers or max(1, gpus // 4)  # bench.default_samplers: 2S+6T at 8 GPUs (exp/table4/run.py:329-330)
     assert out["n_gpus"] == gpus and out["steps"] == 20 and out["warmup"] == 5
     assert out["pipeline"]["samplers"] == S and out["pipeline"]["trainers"] == gpus - S
     assert out["config"]["parallelism"].startswith("%dS+%dT" % (S, gpus - S))
     assert round(out["edges_per_step"] * 20) == _expected_edges(gpus, S, 5, 20)
     assert out["input_nodes_per_step"] == 1.0  # every one of the 20 batches reached exactly one trainer
     assert out["scaling"] == "strong" and out["ms_per_step"] > 0
+    assert out["pipeline"]["handoff"]["transport"] == "none (rehearsal)" and len(out["pipeline"]["handoff"]["rings"]) == S
     assert not [f for f in set(os.listdir("/dev/shm")) - before if f.startswith("fgnn_bench_")]  # rank 0 cleaned up
 
 

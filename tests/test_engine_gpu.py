@@ -141,6 +141,38 @@ def test_arch5_pipelined_trainer_on_a_tiny_queue(tmp_path, mq_bytes, ns, nt):
     assert "ok" in out
 
 
+@pytest.mark.parametrize("slots", [None, 0])
+def test_handoff_check_verifies_and_counts(tmp_path, slots):
+    """SAMGRAPH_HANDOFF_CHECK=n: every sampler appends a checksum to its first n messages, the receiving trainer
+    recomputes it through the address it reads the payload from (the sampler's HBM ring slot mapped with
+    hipIpcOpenMemHandle, or the pinned host slot with SAMGRAPH_DEVICE_RING_SLOTS=0) before it uses the batch;
+    samgraph_ext_queue_stats reports per ring what went where and how many messages verified."""
+    import ast
+    import re
+    env = {"SAMGRAPH_HANDOFF_CHECK": "5"}
+    if slots is not None:
+        env["SAMGRAPH_DEVICE_RING_SLOTS"] = str(slots)
+    out = _run(tmp_path, "arch5", "khop2", 2, 2, 0.25, "pipeline", env=env)
+    assert "ok" in out
+    stats = [ast.literal_eval(m) for m in re.findall(r"ring \d+ stats (\{.*\})", out)]
+    assert len(stats) == 2
+    for st in stats:
+        assert st["verified"] == 5 and st["check_failed"] == 0 and st["spilled"] == 0
+        assert st["sent_device"] + st["sent_host"] == 8  # 2 epochs x 4 local steps
+        assert (st["ring_slots"] == 0 and st["sent_device"] == 0) if slots == 0 else st["sent_device"] > 0
+
+
+def test_handoff_check_refuses_a_corrupted_payload(tmp_path):
+    """the same with one payload word overwritten after the checksum was taken: the receiving trainer aborts
+    (non-zero exit of the job), it does not train on the batch"""
+    p = subprocess.run([sys.executable, RUNNER, "arch5", "khop2", str(tmp_path), "1", "1", "0.25", "pipeline"],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SAMGRAPH_HANDOFF_CHECK="3", SAMGRAPH_HANDOFF_CHECK_SELFTEST="corrupt"))
+    assert p.returncode != 0
+    assert "hand-off check: message" in p.stderr and "does not verify" in p.stderr, p.stderr[-3000:]
+    assert "'check_failed': 1" in p.stdout or "'check_failed': 1" in p.stderr, p.stdout[-2000:]
+
+
 def _two_gpu_env():
     import torch
     if torch.cuda.device_count() < 2:  # counting devices does not initialise the GPU in this process
@@ -215,6 +247,27 @@ def test_bench_pipeline_two_processes(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["pipeline"]["samplers"] == 1
     assert out["value"] > 0 and out["edges_per_step"] > 1000 and 0 < out["pipeline"]["hit_rate"] <= 1
     assert out["epoch_time_s"]["with_training"] > 0
+
+
+def test_bench_pipeline_two_samplers_three_trainers(tmp_path):
+    """the shape default_samplers(8) picks -- several samplers feeding several trainers -- as far as one GPU box allows
+    (at most 6 processes may use its GPU: 2S+3T ranks plus this test process): the real launcher, engine, device rings
+    and gradient all-reduce between the trainers; the line carries the per-ring hand-off counters and the verified
+    warm-up messages of the hand-off self-check."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--samplers", "2", "--workload",
+                        "small", "--steps", "15", "--warmup", "6", "--train-steps", "6", "--empty-feat-bits", "16"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 5 and out["pipeline"]["samplers"] == 2 and out["pipeline"]["trainers"] == 3
+    h = out["pipeline"]["handoff"]
+    assert len(h["rings"]) == 2 and h["check_failed"] == 0 and h["check_messages_per_sampler"] == 3
+    assert h["verified"] == 6 and h["sent_device"] > 0 and h["spilled"] == 0
+    assert h["transport"].startswith("sampler HBM ring")
+    assert out["value"] > 0 and out["epoch_time_s"]["with_training"] > 0
 
 
 @pytest.mark.parametrize("arch,sample_type,workers,cache,mode", [
