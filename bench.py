@@ -709,6 +709,94 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
+# ---- NUMA placement of host tables the GPU reads over the host link ---------------------------------------------------
+def gpu_numa_node(dev_id):
+    """NUMA node the GPU's PCIe root hangs off (sysfs), or None"""
+    try:
+        p = torch.cuda.get_device_properties(dev_id)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            n = int(f.read().strip())
+        return n if n >= 0 else None
+    except Exception:
+        return None
+
+
+def numa_nodes_with_memory():
+    try:
+        txt = open("/sys/devices/system/node/has_memory").read().strip()
+        out = []
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+        return out
+    except Exception:
+        return []
+
+
+def pages_by_numa_node(addr, nbytes, samples=1024):
+    """{node: pages} over `samples` evenly spaced pages of [addr, addr + nbytes) (move_pages in query mode)"""
+    import ctypes as C
+    try:
+        numa = C.CDLL("libnuma.so.1")
+        n = max(1, min(samples, nbytes // 4096))
+        base = addr & ~4095
+        pages = (C.c_void_p * n)(*[base + (i * (nbytes // n) & ~4095) for i in range(n)])
+        status = (C.c_int * n)()
+        numa.numa_move_pages.argtypes = [C.c_int, C.c_ulong, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.c_int]
+        if numa.numa_move_pages(0, n, pages, None, status, 0) != 0:
+            return None
+        hist = {}
+        for v in status:
+            hist[int(v)] = hist.get(int(v), 0) + 1
+        return {str(k): v for k, v in sorted(hist.items())}
+    except Exception:
+        return None
+
+
+class HostTable:
+    """A pinned, GPU-readable host array placed on a chosen NUMA node: numa_alloc_onnode + first touch + hipHostRegister.
+    torch's pin_memory (hipHostMalloc) leaves the placement to the runtime; on a two-socket host a table on the far
+    socket costs the GPU's row reads the inter-socket hop (BENCH_r02: 35.9 GB/s on one box, 49-55 on others)."""
+
+    def __init__(self, rows, dim, node):
+        import ctypes as C
+        self.C, self.nbytes, self.node = C, rows * dim * 4, node
+        self.numa = C.CDLL("libnuma.so.1")
+        self.numa.numa_alloc_onnode.restype = C.c_void_p
+        self.numa.numa_alloc_onnode.argtypes = [C.c_size_t, C.c_int]
+        self.numa.numa_free.argtypes = [C.c_void_p, C.c_size_t]
+        self.ptr = self.numa.numa_alloc_onnode(self.nbytes, node)
+        if not self.ptr:
+            raise MemoryError("numa_alloc_onnode(%d bytes, node %d)" % (self.nbytes, node))
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=np.float32).reshape(rows, dim)
+        self.array[:] = 0  # first touch under the node binding
+        self.hip = C.CDLL("libamdhip64.so")
+        self.registered = False
+        rc = self.hip.hipHostRegister(C.c_void_p(self.ptr), C.c_size_t(self.nbytes), C.c_uint(3))  # portable | mapped
+        if rc != 0:
+            self.free()
+            raise RuntimeError("hipHostRegister failed with %d" % rc)
+        self.registered = True
+        d = C.c_void_p()
+        rc = self.hip.hipHostGetDevicePointer(C.byref(d), C.c_void_p(self.ptr), C.c_uint(0))
+        if rc != 0 or not d.value:
+            self.free()
+            raise RuntimeError("hipHostGetDevicePointer failed with %d" % rc)
+        self.device_ptr = d.value
+        self.tensor = torch.from_numpy(self.array)
+
+    def free(self):
+        if self.registered:
+            self.hip.hipHostUnregister(self.C.c_void_p(self.ptr))
+            self.registered = False
+        if self.ptr:
+            self.tensor = self.array = None
+            self.numa.numa_free(self.C.c_void_p(self.ptr), self.nbytes)
+            self.ptr = None
+
+
 def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label, steps_per_epoch, next_seq, run_region,
                     mode, leg, metas, cached_ms):
     bs = w["batch_size"]
@@ -735,20 +823,39 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     # 57 GB table is not needed to exercise random host-DRAM row reads; 2^24 rows x 512 B = 8.6 GB is far beyond any cache
     bits = min(args.empty_feat_bits, int(np.floor(np.log2(num_node))))
     mask = (1 << bits) - 1
-    host_feat = torch.empty((1 << bits, dim), dtype=torch.float32).pin_memory()
+    # on the GPU's NUMA node when the host has several (--host-feat-numa auto): one consumer, so next to it
+    gnode, nodes = gpu_numa_node(dev.index or 0), numa_nodes_with_memory()
+    want = args.host_feat_numa
+    table_obj, placement = None, "torch pin_memory (hipHostMalloc; placement left to the runtime)"
+    node = gnode if want in ("auto", "gpu") else int(want[5:]) if want.startswith("node:") else None
+    if node is not None and len(nodes) > 1 and node in nodes:
+        try:
+            table_obj = HostTable(1 << bits, dim, node)
+            host_feat = table_obj.tensor
+            placement = "numa_alloc_onnode(node %d) + first touch + hipHostRegister" % node
+        except Exception as e:
+            placement += "; node-local allocation failed: %s" % e
+            table_obj = None
+    if table_obj is None:
+        host_feat = torch.empty((1 << bits, dim), dtype=torch.float32).pin_memory()
     host_feat.copy_(feat[:1 << bits])
+    numa_info = {"gpu_node": gnode, "nodes_with_memory": nodes, "host_feat_placement": placement,
+                 "host_feat_pages_by_node": pages_by_numa_node(host_feat.data_ptr(), host_feat.numel() * 4),
+                 "policy_requested": want}
     # the cache holds the rows the trainer would read for the cached nodes: feat[rank[i] & mask]
     cache_rows = torch.empty((n_cached, dim), dtype=torch.float32, device=dev)
     lib.gather_rows(cache_rows, feat, src_index=rank[:n_cached], src_row_mask=mask)
     for b in batches:
         lib.load().fgnn_batch_set_feat_row_mask(b.h, mask)
-    leg.update(table=ptable, cache_rows=cache_rows, host_feat=host_feat)
+    # what the kernels get: the device-visible address of the table (== the host address for hipHostMalloc memory)
+    leg.update(table=ptable, cache_rows=cache_rows,
+               host_feat=lib.DevicePointer(table_obj.device_ptr, host_feat) if table_obj else host_feat)
     torch.cuda.synchronize()
     mode[0] = "cached"
     # correctness of the leg, once: every row of one batch equals feat[input_nodes & mask]
     step0 = 3
-    sampler.run_batch_cached(next_seq, train[step0 * bs:(step0 + 1) * bs], step0, bt, ptable, cache_rows, host_feat,
-                             label, stream=streams[0])
+    sampler.run_batch_cached(next_seq, train[step0 * bs:(step0 + 1) * bs], step0, bt, ptable, cache_rows,
+                             leg["host_feat"], label, stream=streams[0])
     next_seq += 1
     m = bt.wait()
     torch.cuda.synchronize()
@@ -796,12 +903,16 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
                    "note": "CombineCacheData launch: hit rows x (read + write + 2 index words) / its HIP-event time"},
         "presample_s": t_presample, "init_s": time.time() - t_init - dt,
         "checked": "one batch compared row by row with the direct gather",
+        "numa": numa_info,
     }
     for b in batches:
         lib.load().fgnn_batch_set_feat_row_mask(b.h, 0xFFFFFFFF)
     mode[0] = "full"
     leg.clear()
     del host_feat, cache_rows, ptable, freq, rank
+    if table_obj is not None:
+        torch.cuda.synchronize()
+        table_obj.free()
     return res, next_seq
 
 
@@ -1323,6 +1434,9 @@ def parse_args(argv=None):
     ap.add_argument("--cache-ratio", type=float, default=0.2)
     ap.add_argument("--empty-feat-bits", type=int, default=24,
                     help="host feature table of 2^k rows, node ids masked (SAMGRAPH_EMPTY_FEAT)")
+    ap.add_argument("--host-feat-numa", default="auto",
+                    help="N=1 extract leg: where the host feature table lives: auto / gpu = the GPU's NUMA node, node:<n>, "
+                         "runtime = torch pin_memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extract-leg", action="store_true", help="N=1: skip the cache-0.2 / host-miss extract leg")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")

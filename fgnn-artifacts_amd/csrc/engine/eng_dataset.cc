@@ -3,8 +3,10 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
+#include <cctype>
 #include <cerrno>
 #include <cstring>
 #include <fstream>
@@ -129,11 +131,63 @@ HostArray MapFile(const std::string &path, size_t expect_bytes, bool required) {
   return a;
 }
 
+// ---- NUMA placement of the host feature table ------------------------------------------------------------------------
+// Every trainer GPU of the job pulls its miss rows out of this ONE table (36-55 GB/s of random 512-byte reads per
+// trainer): first-touched by whoever reads the file it would sit on that process's socket, all trainers would
+// load one socket's memory controllers and the GPUs of the other socket would cross the socket link for every row.
+// SAMGRAPH_HOST_FEAT_NUMA: interleave (default when more than one node has memory: pages round-robin over the nodes),
+// node:<n> (bind to one node -- a single-trainer job next to its GPU), local (leave it to first touch).
+static std::vector<int> NodesWithMemory() {
+  std::vector<int> nodes;
+  std::ifstream f("/sys/devices/system/node/has_memory");
+  std::string s;
+  if (!(f >> s)) return nodes;
+  size_t i = 0;
+  while (i < s.size()) {  // "0-1,4"
+    const int a = atoi(s.c_str() + i);
+    int b = a;
+    while (i < s.size() && isdigit((unsigned char)s[i])) ++i;
+    if (i < s.size() && s[i] == '-') {
+      b = atoi(s.c_str() + ++i);
+      while (i < s.size() && isdigit((unsigned char)s[i])) ++i;
+    }
+    for (int n = a; n <= b && n < 1024; ++n) nodes.push_back(n);
+    if (i < s.size() && s[i] == ',') ++i;
+  }
+  return nodes;
+}
+
+std::string PlaceHostTable(void *ptr, size_t bytes, const char *what) {
+  const char *e = getenv("SAMGRAPH_HOST_FEAT_NUMA");
+  const std::string want = e && *e ? e : "interleave";
+  const std::vector<int> nodes = NodesWithMemory();
+  if (want == "local" || nodes.size() < 2 || bytes == 0) return "first touch (" + std::to_string(nodes.size()) + " node(s))";
+  unsigned long mask[16] = {0};
+  int mode = 3;  // MPOL_INTERLEAVE
+  std::string desc = "interleaved over " + std::to_string(nodes.size()) + " nodes";
+  if (want.compare(0, 5, "node:") == 0) {
+    const int n = atoi(want.c_str() + 5);
+    mask[(n % 1024) / 64] |= 1ul << (n % 64);
+    mode = 2;  // MPOL_BIND
+    desc = "bound to node " + std::to_string(n);
+  } else {
+    for (int n : nodes) mask[n / 64] |= 1ul << (n % 64);
+  }
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr) & ~uintptr_t(4095);
+  const size_t len = (reinterpret_cast<uintptr_t>(ptr) + bytes - a + 4095) & ~size_t(4095);
+  if (syscall(SYS_mbind, a, len, mode, mask, 1024ul + 1, 0u) != 0) {
+    SAM_LOG(kWarning) << what << ": mbind refused (" << strerror(errno) << "); pages go where they are first touched";
+    return std::string("first touch (mbind: ") + strerror(errno) + ")";
+  }
+  SAM_LOG(kInfo) << what << ": " << desc;
+  return desc;
+}
+
 // Reads a whole file into MAP_SHARED|MAP_ANONYMOUS memory: unlike a file-backed mapping it can be
 // hipHostRegister'ed (the trainers' gather kernels read miss rows straight from it) and it is shared by
 // the forked children without copies.  The reference locks its file mappings in RAM as well
 // (MAP_LOCKED, common.cc:98).
-static HostArray ReadFileShared(const std::string &path, size_t expect_bytes) {
+static HostArray ReadFileShared(const std::string &path, size_t expect_bytes, bool place = false) {
   HostArray a;
   int fd = open(path.c_str(), O_RDONLY);
   if (fd < 0) return a;
@@ -145,6 +199,7 @@ static HostArray ReadFileShared(const std::string &path, size_t expect_bytes) {
   a.bytes = expect_bytes;
   a.from_file = true;
   if (reg.creator) {
+    if (place) (void)PlaceHostTable(a.ptr, expect_bytes, "host feature table");  // before the first touch below
     size_t done = 0;
     while (done < expect_bytes) {
       ssize_t r = pread(fd, static_cast<char *>(a.ptr) + done, expect_bytes - done, (off_t)done);
@@ -186,10 +241,17 @@ void Dataset::Load(const RunConfig &rc) {
 
   // features: file, or an uninitialised buffer (engine.cc:138-155); SAMGRAPH_EMPTY_FEAT=k => 2^k rows
   feat_rows = rc.option_empty_feat ? (1ull << rc.option_empty_feat) : num_node;
-  if (!rc.option_empty_feat) feat = ReadFileShared(dir + "feat.bin", num_node * feat_dim * 4);
+  if (!rc.option_empty_feat) feat = ReadFileShared(dir + "feat.bin", num_node * feat_dim * 4, true);
   if (!feat.ptr) {
     feat.bytes = feat_rows * feat_dim * 4;
-    feat.ptr = SharedAnonymous(feat.bytes);
+    SharedRegion reg = SharedCreate(feat.bytes);
+    feat.ptr = reg.ptr;
+    if (reg.creator) {
+      // (the policy belongs to the shared object: whoever faults a page in later -- hipHostRegister pins them all in
+      // every trainer -- gets it placed accordingly)
+      (void)PlaceHostTable(feat.ptr, feat.bytes, "host feature table");
+      SharedPublish(feat.ptr);
+    }
   }
   label = ReadFileShared(dir + "label.bin", num_node * 8);
   if (!label.ptr) {

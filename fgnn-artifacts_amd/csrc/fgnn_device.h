@@ -606,12 +606,12 @@ struct ChainSync {
   uint32_t do_wait, do_publish;
 };
 
-// Cache discipline (measured: with agent-scope acquire / release FENCES -- an L2 invalidate per poll, an L2 write-back
-// per arriving wave -- the step went 0.119 -> 0.198 ms, profiles/r03_ab2_chain_flags_v1_fenced.txt): no fence at agent
-// scope anywhere.  The publishing launch writes its rows with agent-scope atomic stores (write-through: complete =
-// visible device-wide), waits for their completion (workgroup-scope release = s_waitcnt) and only then arrives; the
-// waiting launch polls with relaxed loads and reads the rows with agent-scope atomic loads, which no stale cache line
-// can serve.  Every access of the hand-off is an atomic at agent scope; the counters order them.
+// Cache discipline: the rows are ordinary memory in the per-XCD L2s, so the hand-off needs one L2 write-back per
+// publishing workgroup (after every wave's stores have reached the L2: s_waitcnt vmcnt(0) + barrier, then ONE lane's
+// agent-scope release fence) and one invalidate per waiting wave AFTER the wait (polls are relaxed loads).  A first
+// version that polled with acquire loads (an invalidate per poll) and fenced in every lane (four write-backs per
+// workgroup, 5 500 per launch) was correct but took the step from 0.119 to 0.198 ms
+// (profiles/r03_ab2_chain_flags_v1_fenced.txt).
 __device__ __forceinline__ void chain_wait(const ChainSync &c) {  // one lane per workgroup, a barrier behind it
   const unsigned long long t0 = wall_clock64();
   for (;;) {

@@ -281,11 +281,12 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
   }
   // khop2's batch order, handed over on the device (fgnn_device.h, ChainSync): everything above reads immutable
   // inputs only; the rows themselves are first read below
-  const bool chain_reads = KHOP2 && chain.words && chain.do_wait;    // rows read with agent-scope atomic loads
-  const bool chain_writes = KHOP2 && chain.words && chain.do_publish;  // rows written with agent-scope atomic stores
-  if (chain_reads && tid == 0) chain_wait(chain);
+  const bool chain_reads = KHOP2 && chain.words && chain.do_wait;
+  const bool chain_writes = KHOP2 && chain.words && chain.do_publish;
+  if (chain_reads && tid == 0) chain_wait(chain);  // relaxed polls: no cache maintenance while waiting
   __syncthreads();
-  if (chain_reads) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // nothing below moves above the wait
+  // ONE acquire per wave once the wait is over: rows cached before the predecessor's write-back are dropped
+  if (chain_reads) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   phase_mark(scan, tile, 1);
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
@@ -332,14 +333,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         const uint32_t pos = bigv[u] ? sh_o[slot[u]] : j;
         srcv[u] = src_mode == FGNN_SRC_LOCAL ? (uint32_t)(first + k) : sh_rid[k];
         if (!(ablate & 8u)) {
-          if (chain_reads) {
-            v[u] = __hip_atomic_load(&indices[koff + pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bigv[u])
-              wv[u] = __hip_atomic_load(&indices[koff + sh_w[slot[u]]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            v[u] = indices[koff + pos];
-            if (KHOP2 && bigv[u]) wv[u] = indices[koff + sh_w[slot[u]]];
-          }
+          v[u] = indices[koff + pos];
+          if (KHOP2 && bigv[u]) wv[u] = indices[koff + sh_w[slot[u]]];
         }
       }
     }
@@ -380,23 +375,20 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         const uint32_t j = p - sh_lo[kk];
         const uint32_t koff = sh_off[kk];
         const uint32_t sl = j * S + kk;
+        indices[koff + klen - 1 - j] = sh_o[sl];  // the emitted value moves to the consumed tail slot
         const uint32_t sj = sh_s[sl];
-        if (chain_writes) {
-          __hip_atomic_store(&indices[koff + klen - 1 - j], sh_o[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (sj & kWriteBack)
-            __hip_atomic_store(&indices[koff + (sj & ~kWriteBack)], sh_w[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          indices[koff + klen - 1 - j] = sh_o[sl];  // the emitted value moves to the consumed tail slot
-          if (sj & kWriteBack) indices[koff + (sj & ~kWriteBack)] = sh_w[sl];
-        }
+        if (sj & kWriteBack) indices[koff + (sj & ~kWriteBack)] = sh_w[sl];
       }
     }
   }
   phase_mark(scan, tile, 4);
   if (chain_writes) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this lane's write-through row stores have completed ...
-    __syncthreads();                                        // ... and so have those of every lane of the workgroup
-    if (tid == 0) chain_arrive(chain, tile, last_tile);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores have reached the L2 of its XCD ...
+    __syncthreads();                     // ... and so have those of every wave of the workgroup (one CU, one L2)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // ONE write-back of that L2 per workgroup, then arrive
+      chain_arrive(chain, tile, last_tile);
+    }
   }
 }
 

@@ -76,6 +76,19 @@ def _check(code, what):
         raise FgnnError(f"{what} failed with code {code} {detail}")
 
 
+class DevicePointer:
+    """a raw device-visible address standing in for a tensor argument (registered host memory whose device address is
+    not its host address); `keep` holds whatever owns the memory"""
+
+    def __init__(self, address, keep=None):
+        self.address, self.keep = int(address), keep
+
+    def data_ptr(self):
+        return self.address
+
+    is_cuda = True
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr() if t is not None else 0)
 
