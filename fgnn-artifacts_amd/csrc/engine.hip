@@ -55,10 +55,16 @@ struct fgnn_sampler {
   int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
-  // khop2's batch order handed over on the device (fgnn_device.h, ChainSync) instead of an event between the batches'
-  // streams: kChainWords zeroed words, null when the sampler orders its batches with events (FGNN_CHAIN_FLAGS=0, other
-  // sample types, or a last layer too large for arrival counting)
+  int opt_seeds_ready = 0;      // FGNN_CHAIN_SEEDS_READY: with a chain stream, do not order it behind the caller's stream
+                                // (the caller guarantees seeds and batch buffer are ready when it calls)
+  // FGNN_CHAIN_FLAGS=1 (off by default: measured slower than events, profiles/r03_ab3_chain_flags_v3.txt): khop2's
+  // batch order handed over on the device (fgnn_device.h, ChainSync) instead of an event between the batches' streams;
+  // kChainWords zeroed words, null otherwise
   uint32_t *d_chain = nullptr;
+  // FGNN_CHAIN_PRIORITY=3: ONE stream carries the order chain (every sampler launch up to the last layer's, and the
+  // dedup between them) of ALL batches -- stream order instead of an event between consecutive batches; the rest of a
+  // batch runs on the caller's stream behind the slot's `csr` event
+  hipStream_t chain_all = nullptr;
 };
 
 struct fgnn_batch {
@@ -156,6 +162,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   s->opt_chain_priority = env_int("FGNN_CHAIN_PRIORITY", 0);
   s->opt_split_l0 = env_int("FGNN_KHOP_SPLIT_L0", -1);
   s->opt_unordered = env_int("FGNN_KHOP2_UNORDERED", 0);
+  s->opt_seeds_ready = env_int("FGNN_CHAIN_SEEDS_READY", 0);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -179,13 +186,18 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
-  if (cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered && env_int("FGNN_CHAIN_FLAGS", 1) != 0 &&
+  if (cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered && env_int("FGNN_CHAIN_FLAGS", 0) != 0 &&
       s->in_cap[0] <= 131072) {  // <= 2048 workgroups arrive per launch (sample_khop.hip picks 64 seeds per workgroup)
     if (hipMalloc(&s->d_chain, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(s->d_chain, 0, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess) {
       fgnn_sampler_destroy(s);
       return fail(FGNN_EHIP);
     }
+  }
+  if (s->opt_chain_priority == 3 && cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered &&
+      hipStreamCreateWithFlags(&s->chain_all, hipStreamNonBlocking) != hipSuccess) {
+    fgnn_sampler_destroy(s);
+    return fail(FGNN_EHIP);
   }
   for (auto &sl : s->slot) {
     int err = FGNN_OK;
@@ -195,7 +207,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
     for (hipEvent_t *e : {&sl.done, &sl.csr, &sl.entered})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    if (s->opt_chain_priority != 0) {
+    if (s->opt_chain_priority == 1 || s->opt_chain_priority == 2) {
       int lo = 0, hi = 0;  // numerically lower = higher priority
       ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
       ok = ok && hipStreamCreateWithPriority(&sl.chain_st, hipStreamNonBlocking, hi) == hipSuccess;
@@ -228,6 +240,7 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
     if (sl.chain_st) (void)hipStreamDestroy(sl.chain_st);
   }
   if (s->d_chain) (void)hipFree(s->d_chain);
+  if (s->chain_all) (void)hipStreamDestroy(s->chain_all);
   delete s;
 }
 
@@ -373,7 +386,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     return FGNN_EINVAL;
   const hipStream_t caller_st = static_cast<hipStream_t>(stream);
   hipStream_t st = caller_st;
-  if (hipStream_t c = s->slot[seq % kSlots].chain_st) {
+  if (hipStream_t c = s->chain_all ? s->chain_all : s->slot[seq % kSlots].chain_st) {
     st = c;
     stream = c;
   }
@@ -399,7 +412,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
   SeqGuard guard{s, seq, st, caller_st};
   fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
-  if (st != caller_st) {  // whatever the caller enqueued before this call (the seeds, the batch buffer's last use)
+  if (st != caller_st && !s->opt_seeds_ready) {  // whatever the caller enqueued before this call (the seeds, the batch buffer's last use)
     FGNN_HIP_CHECK(hipEventRecord(sl.entered, caller_st));
     FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.entered, 0));
   }
@@ -417,7 +430,7 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
     }
     // (the wait above keeps the ENQUEUE order, which the device hand-off's forward progress rests on as well)
-    if (!s->d_chain) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
+    if (!s->d_chain && !s->chain_all) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
   int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
@@ -489,9 +502,9 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (rc != FGNN_OK) return rc;
     if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
       if (s->d_chain && ordered) guard.chain_published = true;  // by the launch just enqueued
-      if (!s->d_chain || s->opt_chain_priority == 2) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+      if (!s->d_chain || s->opt_chain_priority >= 2) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
       guard.mark_csr();
-      if (st != caller_st && s->opt_chain_priority == 2) {
+      if (st != caller_st && s->opt_chain_priority >= 2) {
         // mode 2: only the order chain itself ran at high priority; the last layer's insert and dedup, which nothing
         // of the next batch waits for, go back to the caller's stream
         FGNN_HIP_CHECK(hipStreamWaitEvent(caller_st, sl.csr, 0));

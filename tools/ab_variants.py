@@ -69,11 +69,24 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        variants.append(dict(name=spec or "base", sampler=s, seq=0,
+        variants.append(dict(name=spec or "base", sampler=s, seq=0, env=env,
                              batches=[s.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(nbuf)],
                              ms={m: [] for m in a.modes.split(",")}, edges=0))
 
     def region(v, n, mode):
+        # switches that the library reads per CALL (the gather's tuning knobs) are in force while this variant runs
+        saved = {k: os.environ.get(k) for k in v["env"]}
+        os.environ.update(v["env"])
+        try:
+            return region_(v, n, mode)
+        finally:
+            for k, val in saved.items():
+                if val is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = val
+
+    def region_(v, n, mode):
         first = v["seq"]
         edges = 0
         for i in range(first, first + n):
