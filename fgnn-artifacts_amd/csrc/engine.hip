@@ -55,6 +55,7 @@ struct fgnn_sampler {
   int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
+  int opt_defer_fix = 0;        // FGNN_DEFER_FIX: a layer's remap fix-up is launched behind the NEXT layer's sampler kernel
   int opt_seeds_ready = 0;      // FGNN_CHAIN_SEEDS_READY: with a chain stream, do not order it behind the caller's stream
                                 // (the caller guarantees seeds and batch buffer are ready when it calls)
   // FGNN_CHAIN_FLAGS=1 (off by default: measured slower than events, profiles/r03_ab3_chain_flags_v3.txt): khop2's
@@ -163,6 +164,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   s->opt_split_l0 = env_int("FGNN_KHOP_SPLIT_L0", -1);
   s->opt_unordered = env_int("FGNN_KHOP2_UNORDERED", 0);
   s->opt_seeds_ready = env_int("FGNN_CHAIN_SEEDS_READY", 0);
+  s->opt_defer_fix = env_int("FGNN_DEFER_FIX", 0);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -445,6 +447,8 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (rc != FGNN_OK) return rc;
   }
 
+  // a remap fix-up owed from the previous layer (FGNN_DEFER_FIX): launched behind this layer's sampler kernel
+  struct { bool owed = false; const size_t *d_n = nullptr; size_t cap = 0; uint32_t *mapped = nullptr; } fix;
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
   size_t cur_n_host = num_seeds;
@@ -513,13 +517,25 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
         guard.st = caller_st;
       }
     }
+    if (fix.owed) {  // the previous layer's fix-up: off the order chain, behind this layer's sampler
+      fix.owed = false;
+      rc = fgnn::hashtable_map_fix(ht, 0, fix.d_n, fix.cap, fix.mapped, stream);
+      if (rc != FGNN_OK) return rc;
+    }
     const bool inserted = (s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0) && !split;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
+    bool defer = s->opt_defer_fix != 0 && ordered && l > 0;
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted, nullptr, /*final_fill=*/l == 0, resolved);
+                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &defer);
     if (rc != FGNN_OK) return rc;
+    if (defer) {
+      fix.owed = true;
+      fix.d_n = d_ne;
+      fix.cap = ecap;
+      fix.mapped = out->row[l];
+    }
     in_cap += ecap;
     cur = out->input_nodes;
     d_cur_n = fgnn_hashtable_d_num_items(ht);

@@ -652,7 +652,13 @@ struct LayerSummary {
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                 ScanWsHost *scan, bool final_fill = false, bool resolved = false);
+                                 ScanWsHost *scan, bool final_fill = false, bool resolved = false,
+                                 bool *defer_fix = nullptr);
+// defer_fix (in: the caller would like to launch the remap fix-up itself, later; out: it has to): the fix-up only
+// rewrites `mapped` entries from other `mapped` entries -- nothing of the NEXT layer's sampling reads it, so a caller
+// with an order chain to keep short (khop2) launches it behind the next sampler kernel
+int hashtable_map_fix(const fgnn_hashtable *ht, size_t num_items, const size_t *d_num_items, size_t num_items_cap,
+                      uint32_t *mapped, void *stream);
 // can the last fill of `cap` items go through the resolving insert (disp[] allocated, one-launch count+assign)?
 bool hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts

@@ -551,8 +551,10 @@ bool fgnn::hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap) {
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                       ScanWsHost *scan, bool final_fill, bool resolved) {
+                                       ScanWsHost *scan, bool final_fill, bool resolved, bool *defer_fix) {
   if (!ht) return FGNN_EINVAL;
+  const bool want_defer = defer_fix && *defer_fix;
+  if (defer_fix) *defer_fix = false;  // true on return: the caller owes a hashtable_map_fix() launch
   // resolved: pos[] holds insert outcomes (sample_khop_fused(..., resolve = true)); only the one-launch path reads them
   if (resolved && !(already_inserted && final_fill && mapped && ht->disp)) return FGNN_EINVAL;
   if (!scan) scan = ht->scan;  // hashtable_can_resolve looks at ht->scan: the descriptors used must be those
@@ -589,9 +591,12 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
                          scan->next(1, grid), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
-      if (mapped)
+      if (mapped && want_defer) {
+        *defer_fix = true;
+      } else if (mapped) {
         hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
                            mapped);
+      }
       return launch_status(__func__);
     }
   }
@@ -605,6 +610,15 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
           ht->max_items, summary);
   if (mapped) FGNN_HT(ht_map_pos_kernel, tv, num_items, d_num_items, cap, pos, mapped);
 #undef FGNN_HT
+  return launch_status(__func__);
+}
+
+int fgnn::hashtable_map_fix(const fgnn_hashtable *ht, size_t num_items, const size_t *d_num_items, size_t num_items_cap,
+                            uint32_t *mapped, void *stream) {
+  const size_t cap = d_num_items ? num_items_cap : num_items;
+  if (!ht || !mapped || cap == 0) return FGNN_EINVAL;
+  hipLaunchKernelGGL(ht_map_fix_kernel, dim3(div_up(cap, (size_t)kBlock)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), ht_view(ht), num_items, d_num_items, cap, mapped);
   return launch_status(__func__);
 }
 

@@ -40,10 +40,20 @@ def _digest(bt, m, num_layers):
     return tuple(head) + (int((flat * (w * 0x9E3779B1 + 7)).sum().item()),)
 
 
-def _run(hip, indptr, indices, table, train, fanouts, bs, n_streams, tenant):
+def _run(hip, indptr, indices, table, train, fanouts, bs, n_streams, tenant, env=None, num_batches=None):
     dev = indptr.device
     d_indices = indices.clone()  # khop2 swaps entries in place: every run starts from the same CSR
-    sampler = hip.Sampler(indptr, d_indices, fanouts, bs, sample_type=hip.KHOP2, seed=SEED)
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})  # the batch driver reads its switches when a sampler is created
+    try:
+        sampler = hip.Sampler(indptr, d_indices, fanouts, bs, sample_type=hip.KHOP2, seed=SEED)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    NUM_BATCHES = num_batches or globals()["NUM_BATCHES"]
     nbuf = 2 * n_streams
     batches = [sampler.new_batch(0, hip.F32, hip.I64) for _ in range(nbuf)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
@@ -119,6 +129,30 @@ def test_single_pass_kernels_under_coresidency():
         helps = int(hip.load().fgnn_debug_scan_helps())
         print("helped tiles:", helps)
         assert helps > 1000, "the helping path was not exercised"
+
+
+@pytest.mark.parametrize("env", [{"FGNN_CHAIN_FLAGS": "1"}, {"FGNN_CHAIN_PRIORITY": "3"},
+                                 {"FGNN_CHAIN_PRIORITY": "3", "FGNN_CHAIN_SEEDS_READY": "1"}, {"FGNN_CHAIN_PRIORITY": "1"}])
+def test_alternative_batch_orderings_are_identical(env):
+    """khop2's cross-batch order (in-place CSR swaps, cuda_sampling_khop2.cu:74-83) kept by other means than the default
+    event between consecutive batches' streams -- the device-side hand-off (FGNN_CHAIN_FLAGS=1: the last sampler launch
+    of a batch publishes, the first of the next one polls), one stream for the order chain of all batches
+    (FGNN_CHAIN_PRIORITY=3), high-priority chain streams (=1): 500 overlapping batches on three streams must equal the
+    same batches one at a time, digest by digest, and leave the same CSR.  (Measured and not the default:
+    profiles/r03_*.)"""
+    from fgnn_hip import lib as hip, rmat
+    hip.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    num_node, num_edge, bs, fanouts = 400_000, 8_000_000, 2000, [25, 10]
+    indptr, indices, _ = rmat.rmat_csr(num_node, num_edge, 42, dev)
+    train = rmat.train_set(num_node, 100_000, 1, dev)
+    table = torch.full((num_node,), -1, dtype=torch.int32, device=dev)
+    serial, csr_serial, _ = _run(hip, indptr, indices, table, train, fanouts, bs, 1, False, num_batches=500)
+    other, csr_other, _ = _run(hip, indptr, indices, table, train, fanouts, bs, 3, False, env=env, num_batches=500)
+    bad = [i for i, (a, b) in enumerate(zip(serial, other)) if a != b]
+    assert not bad, "batches %s differ under %s" % (bad[:10], env)
+    assert torch.equal(csr_serial, csr_other)
 
 
 def test_helping_path_is_exact():
