@@ -55,7 +55,11 @@ struct fgnn_sampler {
   int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
-  int opt_defer_fix = 0;        // FGNN_DEFER_FIX: a layer's remap fix-up is launched behind the NEXT layer's sampler kernel
+  // FGNN_DEFER_FIX (default 1; khop2 only): a layer's remap fix-up is launched behind the NEXT layer's sampler kernel --
+  // nothing of that sampler reads the remapped edges, and the fix-up leaves khop2's cross-batch order chain
+  // (interleaved A/B, profiles/r03_ab5_defer_fix.txt: whole path 0.1227 -> 0.1200 ms per batch, sampler-side stage
+  // 0.0931 -> 0.0881)
+  int opt_defer_fix = 1;
   int opt_seeds_ready = 0;      // FGNN_CHAIN_SEEDS_READY: with a chain stream, do not order it behind the caller's stream
                                 // (the caller guarantees seeds and batch buffer are ready when it calls)
   // FGNN_CHAIN_FLAGS=1 (off by default: measured slower than events, profiles/r03_ab3_chain_flags_v3.txt): khop2's
@@ -164,7 +168,7 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   s->opt_split_l0 = env_int("FGNN_KHOP_SPLIT_L0", -1);
   s->opt_unordered = env_int("FGNN_KHOP2_UNORDERED", 0);
   s->opt_seeds_ready = env_int("FGNN_CHAIN_SEEDS_READY", 0);
-  s->opt_defer_fix = env_int("FGNN_DEFER_FIX", 0);
+  s->opt_defer_fix = env_int("FGNN_DEFER_FIX", 1);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;

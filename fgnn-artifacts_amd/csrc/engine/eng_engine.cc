@@ -627,7 +627,8 @@ void Engine::SampleOnceArch5() {
   a.ship_cache_index = use_cache ? 1 : 0;
   a.have_data = RC().sample_type == kRandomWalk ? 1 : 0;
   a.slot = DeviceVisible(slot);
-  a.payload = mq_->ClaimDeviceSlot(ring_id_, s.mq_key);  // null: no device ring, or none of its slots is free
+  // null: no device ring, or none of its slots is free (counted per sampler either way: samgraph_ext_queue_stats)
+  a.payload = mq_->ClaimDeviceSlot(ring_id_ >= 0 ? ring_id_ : (RC().run_arch == kArch5 ? worker_id_ : 0), s.mq_key);
   a.slot_bytes = mq_->SlotBytes();
   a.h_meta = reinterpret_cast<uint32_t *>(fgnn_batch_host_meta(s.fb));
   const bool check = handoff_check_left_ > 0;

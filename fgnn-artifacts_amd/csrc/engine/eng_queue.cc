@@ -109,8 +109,13 @@ void MemoryQueue::ServiceSpills(int ring) {
 }
 
 void *MemoryQueue::ClaimDeviceSlot(int ring, size_t key) {
-  if (ring < 0 || ring >= kMaxRings || !owns_ring_[ring]) return nullptr;
+  if (ring < 0 || ring >= kMaxRings) return nullptr;
   RingInfo &r = meta_->rings[ring];
+  if (!owns_ring_[ring]) {  // no HBM ring (SAMGRAPH_DEVICE_RING_SLOTS=0, or refused): counted all the same
+    meta_->payload_loc[key % meta_->max_size] = 0;
+    ++r.sent_host;
+    return nullptr;
+  }
   for (uint32_t i = 0; i < r.slots && !*(volatile int *)&meta_->ipc_broken; ++i) {
     if (__atomic_load_n(&r.busy[i], __ATOMIC_ACQUIRE) == 0) {  // single claimer per ring: no CAS needed
       __atomic_store_n(&r.busy[i], 1u, __ATOMIC_RELAXED);
