@@ -395,6 +395,20 @@ bool fgnn::gather_takes_tail(const void *out, const void *src, size_t n_cap, siz
          reinterpret_cast<uintptr_t>(src) % 16 == 0 && n_cap > 0 && n_cap * (row_bytes / 16) < 0xffffffffull;
 }
 
+// is `p` host memory the GPU reads over the host link?  (one runtime query per distinct pointer and thread)
+static bool pointer_is_host(const void *p) {
+  static thread_local const void *last = nullptr;
+  static thread_local bool last_host = false;
+  if (p == last) return last_host;
+  hipPointerAttribute_t a;
+  bool host = false;
+  if (hipPointerGetAttributes(&a, p) == hipSuccess) host = a.type == hipMemoryTypeHost;
+  else (void)hipGetLastError();
+  last = p;
+  last_host = host;
+  return host;
+}
+
 int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                          const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
                          void *stream, const GatherTail *tail_in) {
@@ -427,10 +441,18 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
       return FGNN_OK;
     }
     const size_t total = cap * cpr;
+    // Rows read from HOST memory (registered / pinned: the trainers' miss rows) come over the host link at ~55 GB/s; a
+    // grid sized for HBM (1024 persistent workgroups, ~1 M loads in flight) parks that many slow reads in the memory
+    // pipeline and everything else on the GPU queues behind them -- the next batch's sampling chain made no progress
+    // while a miss gather ran (N = 1 extract leg: 0.394 ms per batch = sample 0.10 + miss gather 0.28, back to back).
+    // The link needs ~0.2 MB in flight: a few dozen workgroups saturate it and leave the chip to the other batches.
+    const bool host_src = pointer_is_host(src);
     // tuning knobs (read per call: only used by profiles/ sweeps)
     const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
     const int unroll = e_u ? atoi(e_u) : 4;
     const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4, cus = (size_t)device_cu_count();
+    const char *e_h = getenv("FGNN_GATHER_HOST_WGS");
+    const size_t host_wgs = e_h ? (size_t)atoi(e_h) : 64;  // 0: no special case
     // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
     // loads (profiles/r01_gather_sweep.csv)
     const bool nt = e_nt ? atoi(e_nt) != 0 : true;
@@ -442,6 +464,7 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
   do {                                                                                                           \
     size_t blocks = div_up(total, (size_t)kBlock * U);                                                           \
     if (blocks > cus * wg_per_cu) blocks = cus * wg_per_cu;                                                      \
+    if (host_src && host_wgs && blocks > host_wgs) blocks = host_wgs;                                            \
     if (nts) hipLaunchKernelGGL((gather_rows16_kernel<U, C, N, true>), dim3(blocks), dim3(kBlock), 0, s,          \
                        static_cast<chunk16 *>(out), static_cast<const chunk16 *>(src), src_index, dst_index, n,  \
                        d_n, cap, cpr, src_row_mask, tail);                                                       \

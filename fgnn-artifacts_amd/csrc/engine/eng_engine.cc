@@ -642,10 +642,10 @@ void Engine::SampleOnceArch5() {
   if (check) {  // checksum of the packed words, appended behind them in the slot the payload went to
     uint32_t *where = static_cast<uint32_t *>(a.payload ? a.payload : a.slot);
     SAM_FGNN(LaunchMessageChecksum(where, s.d_msg_words, 0, 0, nullptr, s.st));
-    // SAMGRAPH_HANDOFF_CHECK_SELFTEST=corrupt: one payload word is overwritten AFTER the checksum was taken, as a
-    // broken mapping would deliver it -- the receivers must refuse the message (tests prove the check can fail)
+    // SAMGRAPH_HANDOFF_CHECK_SELFTEST=corrupt: the stored checksum is flipped after it was taken, so the message no
+    // longer verifies (its arrays stay intact) -- the receivers must refuse it (tests prove the check can fail)
     static const bool corrupt = [] { const char *e = getenv("SAMGRAPH_HANDOFF_CHECK_SELFTEST"); return e && !strcmp(e, "corrupt"); }();
-    if (corrupt) SAM_HIP(hipMemsetAsync(where + sizeof(TransData) / 4 + 1, 0x5a, 4, s.st));
+    if (corrupt) SAM_FGNN(LaunchMessageChecksum(where, s.d_msg_words, 0, 2, nullptr, s.st));
   }
   SAM_FGNN(fgnn_batch_meta_copied(s.fb));  // by the pack kernel
   SAM_FGNN(fgnn_batch_finish(s.fb, s.st));
@@ -839,15 +839,23 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     graph_bytes += v.num_edge * (hdr.have_data ? 12 : 8);
   }
   SAM_CHECK_LE((size_t)((const char *)p - msg), mq_->SlotBytes());
-  x.checking = mq_->IsChecked(mq_key);
-  if (x.checking) {
+  if (mq_->IsChecked(mq_key)) {
     // the sender's checksum, recomputed through the very address the arrays are read from (the sampler's HBM slot
-    // mapped over xGMI, or the pinned host slot): a mapping that reads garbage must not pass as a slow but valid run
+    // mapped over xGMI, or the pinned host slot) BEFORE anything trusts the payload: a mapping that reads garbage must
+    // neither pass as a slow but valid run nor feed garbage indices to the gathers below (warm-up messages only: the
+    // synchronisation costs nothing that is measured)
     if (!x.d_check) SAM_HIP(hipMalloc(&x.d_check, sizeof(uint32_t)));
     SAM_HIP(hipMemsetAsync(x.d_check, 0, sizeof(uint32_t), tstream_));
     const char *base = payload_on_device ? payload : static_cast<const char *>(mq_->DeviceVisiblePtr(msg));
     SAM_FGNN(LaunchMessageChecksum(reinterpret_cast<uint32_t *>(const_cast<char *>(base)), nullptr,
                                    (size_t)((const char *)p - msg) / sizeof(uint32_t), 1, x.d_check, tstream_));
+    uint32_t bad = 0;
+    SAM_HIP(hipMemcpyAsync(&bad, x.d_check, sizeof(bad), hipMemcpyDeviceToHost, tstream_));
+    SAM_HIP(hipStreamSynchronize(tstream_));
+    mq_->CountCheck(mq_key, bad == 0);
+    SAM_CHECK(bad == 0) << "hand-off check: message " << mq_key << " (batch key " << hdr.key
+                        << ") does not verify on the receiving GPU -- the payload read through the "
+                        << "mapped slot differs from what the sampler packed";
   }
   SAM_FGNN(LaunchUnpack(ua, tstream_));
 
@@ -925,15 +933,6 @@ void Engine::TrainerComplete(ExtractCtx &x) {
   Timer t_sync;
   SAM_HIP(hipStreamSynchronize(tstream_));
   xstat_.sync += t_sync.Passed();
-  if (x.checking) {
-    uint32_t bad = 0;
-    SAM_HIP(hipMemcpy(&bad, x.d_check, sizeof(bad), hipMemcpyDeviceToHost));
-    mq_->CountCheck(mq_key, bad == 0);
-    SAM_CHECK(bad == 0) << "hand-off check: message " << mq_key << " (batch key " << b->key
-                        << ") does not verify on the receiving GPU -- the payload read through the "
-                        << "mapped slot differs from what the sampler packed";
-    x.checking = false;
-  }
   mq_->Release(mq_key);
   pool_->Submit(b);
 

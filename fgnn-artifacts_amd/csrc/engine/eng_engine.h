@@ -164,7 +164,6 @@ class Engine {
     Timer t_copy;
     bool timed_gathers = false;
     uint32_t *d_check = nullptr;  // SAMGRAPH_HANDOFF_CHECK: result word of the verification kernel
-    bool checking = false;
   };
   ExtractCtx xctx_[kExtractDepth];
   // where the extraction thread's time goes (reported at shutdown, log level info)
