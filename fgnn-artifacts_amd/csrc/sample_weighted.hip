@@ -82,31 +82,13 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *_
 // lanes of ONE wavefront (64 / F seeds per wave), so "is this draw equal to the seed's next one" is a lane shuffle and
 // the per-seed count a ballot -- no second pass over the draws.  Also covers the padding up to `cap` like the count
 // kernel (keys / counts / order of unused seed slots).
-// Short rows, cooperatively (MODE 0): the F lanes that hold a seed's draws first copy the row's prefix sums into LDS
-// -- len / F independent loads per lane, ONE memory round trip, every line of the row requested once -- and then run
-// the very same binary search on the LDS copy.  A lane searching on its own pays one dependent round trip per level
-// and the F searches of a seed ask for the row's lines again and again (the draw kernel ran at the chip's random-request
-// rate: 122 us for the twitter shape's last layer).  Rows longer than the group's LDS share, or than 16 F entries
-// (beyond that the copy costs more requests than the searches), take the per-lane path.
-constexpr uint32_t kCoopWordsPerWave = 2048;  // 8 KiB of LDS per wave for row copies
-
-__device__ __forceinline__ uint32_t coop_row_cap(uint32_t F) {
-  const uint32_t G = (uint32_t)kWave / F;
-  uint32_t t = kCoopWordsPerWave / G;
-  uint32_t p = 16;
-  while (p * 2 <= t && p < 256) p *= 2;  // power of two, 16 .. 256
-  const uint32_t by_fanout = 16u * F;
-  return p < by_fanout ? p : by_fanout;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
     const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const float *__restrict__ prefix,
     const uint32_t *__restrict__ alias, const uint32_t *__restrict__ input, size_t n_host, const uint32_t *d_n,
     size_t cap, uint32_t F, uint32_t *__restrict__ tmp_dst, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ cnt, uint32_t *bitmap, uint32_t *__restrict__ order, uint64_t seed, uint64_t batch_key,
-    uint32_t tag, uint32_t coop) {
-  __shared__ float sh_rows[MODE == 0 ? kWavesPerBlock * kCoopWordsPerWave : 1];
+    uint32_t tag) {
   const size_t n = resolve_count(n_host, d_n, cap);
   const uint32_t G = (uint32_t)kWave / F;               // seeds per wave (F <= 64)
   const uint32_t lane = (uint32_t)lane_id();
@@ -114,8 +96,6 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
   const bool lane_used = g < G;
   const unsigned long long gmask = lane_used ? (((F == 64u) ? ~0ull : ((1ull << F) - 1ull)) << (g * F)) : 0ull;
   const size_t waves = (size_t)gridDim.x * kWavesPerBlock;
-  const uint32_t row_cap = (MODE == 0 && coop) ? coop_row_cap(F) : 0u;
-  float *my_row = sh_rows + (MODE == 0 ? (size_t)wave_id() * kCoopWordsPerWave + (size_t)g * (kCoopWordsPerWave / G) : 0);
   for (size_t w = (size_t)blockIdx.x * kWavesPerBlock + wave_id(); w * G < cap; w += waves) {
     const size_t i = w * G + g;
     const bool seed_here = lane_used && i < cap;
@@ -126,32 +106,10 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
       len = indptr[rid + 1] - off;
     }
     uint32_t pick = FGNN_EMPTY_KEY;
-    const bool coop_row = MODE == 0 && seed_here && i < n && len >= 2 && len <= row_cap;
-    if (MODE == 0 && row_cap) {
-      if (coop_row)
-        for (uint32_t k = j; k < len; k += F) my_row[k] = prefix[off + k];
-      // the copy is read by the other lanes of the same wave: LDS instructions of a wave execute in order
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (coop_row) {
-      // weighted_pick<0> on the LDS copy: same draws, same comparisons in the same order
-      const float x = uniform_float(philox_u32(seed, batch_key, tag, (uint32_t)i, j)) * my_row[len - 1];
-      uint32_t hi = 0;
-      if (!(x <= my_row[0])) {
-        uint32_t lo = 0;
-        hi = len - 1;
-        while (hi - lo >= 2) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (my_row[mid] >= x) hi = mid; else lo = mid;
-        }
-      }
-      pick = indices[off + hi];
-      tmp_dst[i * F + j] = pick;
-    } else if (seed_here && i < n) {
+    if (seed_here && i < n) {
       pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag);
       tmp_dst[i * F + j] = pick;
     }
-    if (MODE == 0 && row_cap) __builtin_amdgcn_wave_barrier();  // the copy is overwritten by the next round
     // a draw is dropped when it equals the seed's NEXT draw; the last one is always kept (count_edge, prefix.cu:94-112)
     const uint32_t nxt = __shfl_down(pick, 1, kWave);
     const bool keep = seed_here && i < n && len != 0 && (j + 1 == F || pick != nxt);
@@ -515,16 +473,13 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
   uint32_t *bitmap = rank ? rank->bitmap : nullptr;
   if (F <= (uint32_t)kWave) {
     // draws + per-seed counts + ranking bits in one launch
-    // FGNN_WEIGHTED_COOP=0: every draw searches global memory on its own (A/B of the cooperative short-row path)
-    const char *e_coop = getenv("FGNN_WEIGHTED_COOP");
-    const uint32_t coop = e_coop ? (uint32_t)(atoi(e_coop) != 0) : 1u;
     const size_t seeds_per_wg = (size_t)kWavesPerBlock * ((size_t)kWave / F);
     size_t blocks = div_up(cap, seeds_per_wg);
     if (blocks > 256 * 32) blocks = 256 * 32;
 #define FGNN_DRAWC(M)                                                                                            \
   hipLaunchKernelGGL((weighted_draw_count_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, \
                      alias, input, num_input, d_num_input, cap, F, tmp_dst, keys, vals, cnt, bitmap, order, seed,    \
-                     batch_key, tag, coop)
+                     batch_key, tag)
     if (mode == 1) FGNN_DRAWC(1);
     else if (mode == 2) FGNN_DRAWC(2);
     else FGNN_DRAWC(0);
