@@ -71,6 +71,70 @@ struct FuseArgs {               // dedup insert fused into phase B (engine path)
   BatchStart start;             // start.n2o != null: this is the first launch of a batch
 };
 
+// khop0 on hub rows.  The reservoir draws one number per row ELEMENT (khop0.cu:41-90); a row of 10^5..10^6 entries
+// (R-MAT hubs sit in nearly every frontier) walked by the one workgroup that owns its seed was the kernel's critical
+// path.  Rows beyond kSplitRow entries are therefore drawn by the WHOLE chip before the sampler runs: a scan lists
+// them (hub index per seed), khop0_hub_kernel strides all workgroups over each listed row's Philox blocks and keeps,
+// per output slot, the largest winning element in a small global table; the sampler copies those winners instead of
+// drawing.  Same draws, same winners (max is order-free): bit-identical.
+constexpr uint32_t kSplitRow = 16384;
+struct HubSplit {
+  uint32_t *of_seed;   // [cap] hub index of seed i, or kEmpty; null: no split (scratch too small, or khop2)
+  uint32_t *count;     // [1] hubs claimed (may exceed cap_hubs: the surplus stays with the sampler)
+  uint32_t *list;      // [cap_hubs][3] seed position, row offset, row length
+  uint32_t *win;       // [cap_hubs][F] slot winners, initialised to the slot's own position
+  uint32_t cap_hubs;
+};
+
+__global__ __launch_bounds__(256) void khop0_hub_scan_kernel(const uint32_t *__restrict__ indptr,
+                                                             const uint32_t *__restrict__ input, size_t num_input,
+                                                             const uint32_t *d_num_input, size_t cap, uint32_t F,
+                                                             HubSplit hub) {
+  const size_t n = resolve_count(num_input, d_num_input, cap);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  uint32_t h = FGNN_EMPTY_KEY;
+  if (i < n) {
+    const uint32_t rid = input[i];
+    const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
+    if (len > kSplitRow && len > F) {
+      h = atomicAdd(hub.count, 1u);
+      if (h < hub.cap_hubs) {
+        hub.list[3 * h] = (uint32_t)i;
+        hub.list[3 * h + 1] = off;
+        hub.list[3 * h + 2] = len;
+        for (uint32_t q = 0; q < F; ++q) hub.win[(size_t)h * F + q] = q;
+      } else {
+        h = FGNN_EMPTY_KEY;
+      }
+    }
+  }
+  hub.of_seed[i] = h;
+}
+
+__global__ __launch_bounds__(256) void khop0_hub_kernel(HubSplit hub, uint32_t F, uint64_t seed, uint64_t batch_key,
+                                                        uint32_t tag) {
+  const uint32_t claimed = *hub.count;
+  const uint32_t nh = claimed < hub.cap_hubs ? claimed : hub.cap_hubs;
+  const uint32_t lanes = gridDim.x * 256u, lane = blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t h = 0; h < nh; ++h) {
+    const uint32_t item = hub.list[3 * h], klen = hub.list[3 * h + 2];
+    uint32_t *win = hub.win + (size_t)h * F;
+    // a lane handles 4 consecutive elements (one Philox block), exactly as the sampler's own reservoir does
+    for (uint32_t jb = (F >> 2) + lane; (jb << 2) < klen; jb += lanes) {
+      const u32x4 blk = philox_block(seed, batch_key, tag, item, jb);
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t j = (jb << 2) + u;
+        if (j >= F && j < klen) {
+          const uint32_t kk = pick_word(blk, u) % (j + 1);
+          if (kk < F) atomicMax(&win[kk], j);
+        }
+      }
+    }
+  }
+}
+
 // S seeds per workgroup handled by T >= S threads: the per-seed phases (0, A, C) use the first S threads, the
 // per-edge phase B uses all T, so a small frontier still gives every CU several waves to overlap latencies.
 template <int S, int T, bool KHOP2, int FMAX>
@@ -81,12 +145,13 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
                                                         uint32_t tag, FuseArgs fuse, uint32_t ablate, ScanWs scan,
-                                                        size_t *d_num_out, ChainSync chain) {
+                                                        size_t *d_num_out, ChainSync chain, HubSplit hub) {
   constexpr int NW = T / kWave;
   static_assert(T >= S && T % kWave == 0, "threads per workgroup");
   extern __shared__ uint32_t dyn[];
   __shared__ uint32_t sh_scan[NW];
   __shared__ uint32_t sh_off[S], sh_len[S], sh_rid[S], sh_lo[S + 1];
+  __shared__ uint32_t sh_hub[KHOP2 ? 1 : S];  // khop0: hub index of the seed (row drawn by khop0_hub_kernel), or kEmpty
 
   uint32_t *sh_o = dyn;                         // [F][S] khop2: origin position, then fetched value
   uint32_t *sh_s = dyn + (size_t)F * S;         // [F][S] khop2: swap-log position s_j
@@ -154,6 +219,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     sh_len[k] = len;
     sh_rid[k] = rid;
     sh_lo[k] = lo;
+    if (!KHOP2) sh_hub[k] = (hub.of_seed && i < n) ? hub.of_seed[i] : FGNN_EMPTY_KEY;
   }
   if (tid == 0) sh_lo[S] = total;
   // single pass: the tile's edge count is known here, long before its offset is needed (after phase A)
@@ -276,7 +342,13 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
     for (int row = 0; row < S; ++row) {
       const uint32_t klen = sh_len[row];
-      if (klen > kHugeRow) reservoir(row, klen, (uint32_t)tid, T);  // workgroup-uniform
+      if (klen <= kHugeRow) continue;  // workgroup-uniform
+      const uint32_t h = sh_hub[row];
+      if (h == FGNN_EMPTY_KEY) {
+        reservoir(row, klen, (uint32_t)tid, T);
+      } else {  // drawn by the whole chip beforehand: the winners are in the hub table
+        for (uint32_t q = tid; q < F; q += T) sh_o[q * S + row] = hub.win[(size_t)h * F + q];
+      }
     }
   }
   // khop2's batch order, handed over on the device (fgnn_device.h, ChainSync): everything above reads immutable
@@ -447,6 +519,33 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     return FGNN_ENOSPC;
   }
   const size_t lds = words_per_seed * S * sizeof(uint32_t);
+  // khop0: rows beyond kSplitRow entries are drawn by the whole chip first (HubSplit), when the scratch has room for
+  // the hub tables: they sit right below the sampler's block offsets (fused: behind the dedup's part of the scratch)
+  HubSplit hub{nullptr, nullptr, nullptr, nullptr, 0};
+  if (!KHOP2 && !(ablate & 16u)) {
+    const size_t used_front = fuse_ht ? (cap * fanout + div_up(cap * fanout, (size_t)64) + 72) : 0;  // pos[] + dedup sums
+    const size_t words_total = ws_bytes / sizeof(uint32_t);
+    const size_t tail = fuse_ht ? nb + 4 : 0;            // fused: sampler sums at the very end
+    const size_t head = fuse_ht ? used_front : nb + 8;   // plain: sampler sums at the start
+    if (words_total > head + tail + cap + 16) {
+      const size_t room = words_total - head - tail - cap - 16;
+      size_t hubs = room / (F + 3);
+      if (hubs > 1024) hubs = 1024;
+      if (hubs >= 8) {
+        uint32_t *base = static_cast<uint32_t *>(ws) + head;
+        hub.of_seed = base;
+        hub.count = base + cap;
+        hub.list = base + cap + 8;
+        hub.win = hub.list + 3 * hubs;
+        hub.cap_hubs = (uint32_t)hubs;
+        FGNN_HIP_CHECK(hipMemsetAsync(hub.count, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(khop0_hub_scan_kernel, dim3(div_up(cap, (size_t)256)), dim3(256), 0, stream, indptr, input,
+                           num_input, d_num_input, cap, F, hub);
+        hipLaunchKernelGGL(khop0_hub_kernel, dim3((unsigned)device_cu_count() * 4), dim3(256), 0, stream, hub, F, seed,
+                           batch_key, tag);
+      }
+    }
+  }
   ScanWs scan{nullptr, nullptr, 0, 0, nullptr, nullptr, 0, kScanHelpAfterPolls, nullptr};
   bool want_scan = scan_host && nb <= scan_host->ws.max_tiles;
 
@@ -472,7 +571,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     }                                                                                                          \
     hipLaunchKernelGGL((khop_sample_kernel<SS, 256, KHOP2, FM>), dim3(nb), dim3(256), lds, stream, indptr, indices, \
                        input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag, fuse, ablate, scan, d_num_out, chain);                                  \
+                       batch_key, tag, fuse, ablate, scan, d_num_out, chain, hub);                             \
   } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \

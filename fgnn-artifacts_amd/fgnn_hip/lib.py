@@ -126,6 +126,8 @@ def sample_khop(kind, indptr, indices, inp, fanout, seed, batch_key, layer, src_
     d_num_out = torch.zeros(1, dtype=torch.int64, device=dev)
     if ws is None:
         ws = scratch(n, dev)
+        if kind == "khop0":  # room for the hub tables: rows beyond 16 K entries are then drawn by the whole chip
+            ws = torch.empty(ws.numel() + 4 * (n + 16 + 1024 * (fanout + 3)), dtype=torch.uint8, device=dev)
     fn = L.fgnn_sample_khop0 if kind == "khop0" else L.fgnn_sample_khop2
     code = fn(_ptr(indptr), _ptr(indices), _ptr(inp), C.c_size_t(n), _ptr(d_num_input), C.c_size_t(n),
               C.c_size_t(fanout), _ptr(out_src), _ptr(out_dst), _ptr(d_num_out), C.c_int(src_mode), C.c_uint64(seed),

@@ -76,7 +76,9 @@ int fgnn_sanity_check_batch(uint32_t *seen_bits, size_t num_node, const uint32_t
 
 /* GPUSampleKHop0 (cuda_sampling_khop0.cu:178-253): fixed-fanout uniform sampling without
  * replacement by reservoir, compacted COO in seed-major order.  *d_num_out (size_t, device) gets the
- * edge count. */
+ * edge count.  With ws_bytes >= fgnn_scratch_bytes(cap) + 4 * (cap + 16 + 1024 * (fanout + 3)) rows of more than 16 384
+ * entries are drawn by all workgroups of the GPU before the sampler runs (one draw per row element, khop0.cu:41-90: a
+ * hub row of 10^6 entries is otherwise one workgroup's job); smaller scratch: same results, the owner walks the row. */
 int fgnn_sample_khop0(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input,
                       size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
                       uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
