@@ -114,22 +114,50 @@ __global__ __launch_bounds__(256) void khop0_hub_scan_kernel(const uint32_t *__r
 
 __global__ __launch_bounds__(256) void khop0_hub_kernel(HubSplit hub, uint32_t F, uint64_t seed, uint64_t batch_key,
                                                         uint32_t tag) {
+  // The Philox blocks of ALL listed rows form one flat index space (a first version walked the rows one after the other:
+  // a dependent list read and a nearly empty grid per short hub, 0.26 -> 0.53 ms per step): every workgroup builds the
+  // prefix of the rows' block counts in LDS, a lane finds the row of each of its blocks by binary search there.
+  __shared__ uint32_t sh_pref[1024 + 1];
+  __shared__ uint32_t sh_scan[256 / kWave];
   const uint32_t claimed = *hub.count;
-  const uint32_t nh = claimed < hub.cap_hubs ? claimed : hub.cap_hubs;
-  const uint32_t lanes = gridDim.x * 256u, lane = blockIdx.x * 256u + threadIdx.x;
-  for (uint32_t h = 0; h < nh; ++h) {
-    const uint32_t item = hub.list[3 * h], klen = hub.list[3 * h + 2];
-    uint32_t *win = hub.win + (size_t)h * F;
-    // a lane handles 4 consecutive elements (one Philox block), exactly as the sampler's own reservoir does
-    for (uint32_t jb = (F >> 2) + lane; (jb << 2) < klen; jb += lanes) {
-      const u32x4 blk = philox_block(seed, batch_key, tag, item, jb);
+  const uint32_t nh = claimed < hub.cap_hubs ? claimed : hub.cap_hubs;  // <= 1024
+  if (nh == 0) return;
+  const uint32_t first_blk = F >> 2;
+  uint32_t running = 0;
+  for (uint32_t h0 = 0; h0 < nh; h0 += 256) {
+    const uint32_t h = h0 + threadIdx.x;
+    uint32_t nblk = 0;
+    if (h < nh) {
+      const uint32_t klen = hub.list[3 * h + 2];
+      const uint32_t last_blk = (klen + 3) >> 2;  // blocks [first_blk, last_blk) hold elements F .. klen - 1
+      nblk = last_blk > first_blk ? last_blk - first_blk : 0;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<256 / kWave>(nblk, sh_scan, &tot);
+    if (h < nh) sh_pref[h] = running + ex;
+    running += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sh_pref[nh] = running;
+  __syncthreads();
+  const uint32_t total = sh_pref[nh];
+  const uint32_t lanes = gridDim.x * 256u;
+  for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < total; w += lanes) {
+    uint32_t a = 0, b = nh;  // sh_pref[a] <= w < sh_pref[b]
+    while (b - a > 1) {
+      const uint32_t mid = (a + b) >> 1;
+      if (sh_pref[mid] <= w) a = mid; else b = mid;
+    }
+    const uint32_t item = hub.list[3 * a], klen = hub.list[3 * a + 2];
+    const uint32_t jb = first_blk + (w - sh_pref[a]);
+    uint32_t *win = hub.win + (size_t)a * F;
+    const u32x4 blk = philox_block(seed, batch_key, tag, item, jb);
 #pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t j = (jb << 2) + u;
-        if (j >= F && j < klen) {
-          const uint32_t kk = pick_word(blk, u) % (j + 1);
-          if (kk < F) atomicMax(&win[kk], j);
-        }
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t j = (jb << 2) + u;
+      if (j >= F && j < klen) {
+        const uint32_t kk = pick_word(blk, u) % (j + 1);
+        if (kk < F) atomicMax(&win[kk], j);
       }
     }
   }
