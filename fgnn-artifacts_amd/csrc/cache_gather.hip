@@ -411,7 +411,7 @@ static bool pointer_is_host(const void *p) {
 
 int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                          const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
-                         void *stream, const GatherTail *tail_in) {
+                         void *stream, const GatherTail *tail_in, size_t host_grid) {
   auto s = static_cast<hipStream_t>(stream);
   const GatherTail tail = tail_in ? *tail_in : GatherTail{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   if (tail_in && !gather_takes_tail(out, src, d_n ? n_cap : n, dim, dtype)) return FGNN_EINVAL;
@@ -441,18 +441,21 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
       return FGNN_OK;
     }
     const size_t total = cap * cpr;
-    // Rows read from HOST memory (registered / pinned: the trainers' miss rows) come over the host link at ~55 GB/s; a
-    // grid sized for HBM (1024 persistent workgroups, ~1 M loads in flight) parks that many slow reads in the memory
-    // pipeline and everything else on the GPU queues behind them -- the next batch's sampling chain made no progress
-    // while a miss gather ran (N = 1 extract leg: 0.394 ms per batch = sample 0.10 + miss gather 0.28, back to back).
-    // The link needs ~0.2 MB in flight: a few dozen workgroups saturate it and leave the chip to the other batches.
-    const bool host_src = pointer_is_host(src);
+    // Rows read from HOST memory (registered / pinned: miss rows) come over the host link at ~50 GB/s, and the grid of
+    // such a launch is a trade: sized like an HBM gather (1024 persistent workgroups, ~1 M loads in flight) it keeps
+    // the link busiest -- a GPU that only extracts (an arch5 trainer, four batches in flight) pulls 50.6 GB/s against
+    // 47.1 with 64 workgroups (profiles/r03_trainer_sweep.txt) -- but those slow reads sit in the memory pipeline in
+    // front of every other kernel's misses: on a GPU that ALSO samples, the next batch's sampling chain ran 2-6x slower
+    // beside a miss gather (profiles/r03_extract_timeline.txt) and 64 workgroups gave the whole leg 0.334 ms per batch
+    // instead of 0.390 (profiles/r03_extract_sweep.txt).  The caller says which GPU it is on: `host_grid` workgroups
+    // for host-source launches, 0 = the HBM-sized grid (FGNN_GATHER_HOST_WGS overrides both, for sweeps).
+    const bool host_src = (host_grid != 0 || getenv("FGNN_GATHER_HOST_WGS")) && pointer_is_host(src);
     // tuning knobs (read per call: only used by profiles/ sweeps)
     const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
     const int unroll = e_u ? atoi(e_u) : 4;
     const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4, cus = (size_t)device_cu_count();
     const char *e_h = getenv("FGNN_GATHER_HOST_WGS");
-    const size_t host_wgs = e_h ? (size_t)atoi(e_h) : 64;  // 0: no special case
+    const size_t host_wgs = e_h ? (size_t)atoi(e_h) : host_grid;  // 0: no special case
     // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
     // loads (profiles/r01_gather_sweep.csv)
     const bool nt = e_nt ? atoi(e_nt) != 0 : true;

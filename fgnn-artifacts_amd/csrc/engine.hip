@@ -686,7 +686,8 @@ extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, 
   if (full_feat)  // CombineMissData with the row fetch fused in
     rc = fgnn::gather_rows_ex(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss, b->feat_rows_cap,
                               b->feat_dim, b->feat_dtype, b->feat_row_mask, stream,
-                              tailed && !cache_rows ? &tail : nullptr);
+                              tailed && !cache_rows ? &tail : nullptr,
+                              fgnn::kSharedGpuHostGrid);  // this GPU samples too: a host-source launch stays small
   if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
   if (rc == FGNN_OK && cache_rows)  // CombineCacheData
     rc = fgnn::gather_rows_ex(b->feat, cache_rows, b->cidx[2], b->cidx[3], 0, &b->d_meta->num_cache, b->feat_rows_cap,

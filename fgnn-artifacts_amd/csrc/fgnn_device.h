@@ -678,7 +678,9 @@ struct GatherTail {
 bool gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype);
 int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                    const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask, void *stream,
-                   const GatherTail *tail);
+                   const GatherTail *tail, size_t host_grid = 0);
+// workgroups of a host-source gather on a GPU that also runs the sampling chain (see gather_rows_ex)
+constexpr size_t kSharedGpuHostGrid = 64;
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,

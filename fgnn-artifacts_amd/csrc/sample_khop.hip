@@ -78,28 +78,6 @@ struct FuseArgs {               // dedup insert fused into phase B (engine path)
 // per output slot, the largest winning element in a small global table; the sampler copies those winners instead of
 // drawing.  Same draws, same winners (max is order-free): bit-identical.
 constexpr uint32_t kSplitRow = 16384;
-
-// r % m, exact, for the reservoir's draw % (j + 1).  The hardware has no integer divide: `%` by a variable is a ~35
-// instruction sequence, and khop0 pays it once per row ELEMENT (4 x 10^8 per papers100M batch on hub-heavy R-MAT
-// frontiers: the sampler is ALU-bound there).  For m >= 2^13 the quotient estimate from one float reciprocal is within
-// one of the truth (conversions, reciprocal and product each err by <= 2^-23 relative: |error| <= 2^10.8 / m < 0.25),
-// so a multiply-subtract and a correction step give the exact remainder in ~10 instructions.
-constexpr uint32_t kFastRemFrom = 1u << 13;
-__device__ __forceinline__ uint32_t urem_big(uint32_t r, uint32_t m) {
-  const float q = __uint2float_rz(r) * __builtin_amdgcn_rcpf(__uint2float_rz(m));
-  uint32_t rem = r - (uint32_t)q * m;  // mod 2^32; the true value lies in (-2 m, 2 m), m <= 2^31
-  if ((int32_t)rem < 0) {
-    rem += m;
-    if ((int32_t)rem < 0) rem += m;
-  } else if (rem >= m) {
-    rem -= m;
-    if (rem >= m) rem -= m;
-  }
-  return rem;
-}
-__device__ __forceinline__ uint32_t reservoir_slot(uint32_t draw, uint32_t j) {  // draw % (j + 1)
-  return j + 1 >= kFastRemFrom ? urem_big(draw, j + 1) : draw % (j + 1);
-}
 struct HubSplit {
   uint32_t *of_seed;   // [cap] hub index of seed i, or kEmpty; null: no split (scratch too small, or khop2)
   uint32_t *count;     // [1] hubs claimed (may exceed cap_hubs: the surplus stays with the sampler)
@@ -178,7 +156,7 @@ __global__ __launch_bounds__(256) void khop0_hub_kernel(HubSplit hub, uint32_t F
     for (uint32_t u = 0; u < 4; ++u) {
       const uint32_t j = (jb << 2) + u;
       if (j >= F && j < klen) {
-        const uint32_t kk = reservoir_slot(pick_word(blk, u), j);
+        const uint32_t kk = pick_word(blk, u) % (j + 1);
         if (kk < F) atomicMax(&win[kk], j);
       }
     }
@@ -380,7 +358,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
         for (uint32_t u = 0; u < 4; ++u) {
           const uint32_t j = (jb << 2) + u;
           if (j >= F && j < klen) {
-            const uint32_t kk = reservoir_slot(pick_word(blk, u), j);
+            const uint32_t kk = pick_word(blk, u) % (j + 1);
             if (kk < F) atomicMax(&sh_o[kk * S + row], j);
           }
         }
