@@ -1,4 +1,4 @@
-# usage: bash tools/r03_ab_generic.sh <tag> "<variants>" [ab_variants.py args]: batch-driver parity under each variant, then the A/B
+# usage: bash tools/ab_variants.sh <tag> "<variants>" [ab_variants.py args]: batch-driver parity under each variant, then the A/B
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 ulimit -c 0
 tag=$1; variants=$2; shift 2

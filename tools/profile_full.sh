@@ -1,4 +1,4 @@
-# usage: bash tools/r02_full.sh <tag> [pytest|nopytest]  -- GPU box: whole GPU suite, default bench, rocprof stats + serial
+# usage: bash tools/profile_full.sh <tag> [pytest|nopytest]  -- GPU box: whole GPU suite, default bench, rocprof stats + serial
 # timeline of the same command, PMC passes (separate), then the 1S+1T pipeline with both ranks on the one GPU
 tag=$1; what=${2:-pytest}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

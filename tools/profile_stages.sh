@@ -1,4 +1,4 @@
-# usage: bash tools/r02_stages.sh <tag>  -- GPU box: the two stages of the N >= 2 pipeline each ALONE (bench.py --decoupled: the
+# usage: bash tools/profile_stages.sh <tag>  -- GPU box: the two stages of the N >= 2 pipeline each ALONE (bench.py --decoupled: the
 # sampler process fills the ring, then the trainer process drains it; both ranks on the one GPU of the box, never at the
 # same time), with the engine's own host-side split (log level info), and one arch5 sampler under rocprofv3
 tag=$1
