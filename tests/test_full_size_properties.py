@@ -289,14 +289,16 @@ def test_full_size_random_walk_invariants():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("fanout", [[10, 5], [25, 10]])
-def test_products_shape_bit_exact_and_invariants(oracle, fanout):
+@pytest.mark.parametrize("kind,fanout", [("khop2", [10, 5]), ("khop2", [25, 10]), ("khop0", [10, 5])])
+def test_products_shape_bit_exact_and_invariants(oracle, kind, fanout):
     """BASELINE configs 1 and 2 at full size on the GPU box (products shape: N=2 449 029, E~123.7 M, D=100, C=47,
     batch 8000; fanout [10,5] = config 1's sampling work, [25,10] = config 2; datagen/products.py:92-98): this graph is
     small enough to bring to the host, so on top of the size-independent invariants the whole batch -- blocks, unique
     list, cache split, D=100 feature rows (25 sixteen-byte chunks: the gather's odd-width path), labels and khop2's
     mutated CSR -- is compared BIT-EXACTLY with the oracle's restatement of DoGPUSample (cuda_loops.cc:50-267) over
-    three consecutive batches (the CSR mutation carries)."""
+    three consecutive batches (the CSR mutation carries).  khop0: the R-MAT hubs of this graph (rows of 10^4..10^5
+    entries in every frontier) go through the hub split of the FUSED sampler -- listed by a scan, drawn by all
+    workgroups, winners copied by the owner -- and must still equal the oracle's one-draw-per-element reservoir."""
     sys.path.insert(0, ROOT)
     import bench
     from fgnn_hip import lib
@@ -319,7 +321,10 @@ def test_products_shape_bit_exact_and_invariants(oracle, fanout):
     h_table = table.cpu().numpy().view(np.uint32)
     np.testing.assert_array_equal(h_table, oracle.cache_table_build(rank.cpu().numpy().view(np.uint32), N // 5, N))
     d_indices = indices.clone()
-    sampler = lib.Sampler(indptr, d_indices, fanout, B, sample_type=lib.KHOP2, seed=0x5A4D47)
+    st, ost = (lib.KHOP2, oracle.KHOP2) if kind == "khop2" else (lib.KHOP0, oracle.KHOP0)
+    sampler = lib.Sampler(indptr, d_indices, fanout, B, sample_type=st, seed=0x5A4D47)
+    deg_max = int(((indptr[1:].long() - indptr[:-1].long()) & 0xFFFFFFFF).max())
+    assert deg_max > 16384  # the graph does have rows beyond the split threshold
     rng = oracle.make_rng(oracle.RNG_PHILOX, 0x5A4D47)
     oht = oracle.HashTable(N, oracle.predict_num_nodes(B, fanout))
     ip = indptr.long() & 0xFFFFFFFF
@@ -332,7 +337,7 @@ def test_products_shape_bit_exact_and_invariants(oracle, fanout):
         m = bt.wait()
         assert m.overflow == 0 and m.num_output == hi - lo
         h_seeds = seeds.cpu().numpy().view(np.uint32)
-        want = oracle.do_sample(h_indptr, h_indices, h_seeds, fanout, oracle.KHOP2, rng, 7 + b, oht)
+        want = oracle.do_sample(h_indptr, h_indices, h_seeds, fanout, ost, rng, 7 + b, oht)
         nodes = bt.input_nodes().cpu().numpy().view(np.uint32)
         np.testing.assert_array_equal(nodes, want["input_nodes"])
         prev_src = None
@@ -354,4 +359,4 @@ def test_products_shape_bit_exact_and_invariants(oracle, fanout):
         assert bt.feat().cpu().numpy().tobytes() == oracle.extract(h_feat, nodes).tobytes()
         np.testing.assert_array_equal(bt.label().cpu().numpy(), h_label[h_seeds])
     np.testing.assert_array_equal(d_indices.cpu().numpy().view(np.uint32), h_indices)  # khop2's swaps, all three batches
-    assert (h_indices != indices.cpu().numpy().view(np.uint32)).any()
+    assert (h_indices != indices.cpu().numpy().view(np.uint32)).any() == (kind == "khop2")  # khop0 never writes the CSR
