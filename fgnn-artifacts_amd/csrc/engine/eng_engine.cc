@@ -405,14 +405,17 @@ void Engine::SampleInit(int worker_id, Context ctx) {
                                RC().batch_size, worker_id, (int)RC().num_sample_worker, stream_, arch6));
   if (RC().option_sanity_check && !arch6) shuffler_->EnableSanityCheck(ds_.num_node);
   pool_.reset(new GraphPool(RC().max_copying_jobs));
-  // Batches between sample_once (enqueued) and the publisher thread (completed + published): 6 batch buffers over 3
-  // streams.  The chains of three consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to stay
-  // ordered with events; one batch alone cannot fill the chip, four contend); a batch buffer is reused in stream
-  // order, so the host may run three more batches ahead instead of waiting for a publication every call (with 3
-  // buffers the sampler measured 142 us per papers100M batch, 60 of them waiting here, the GPU idle 21 % of the time)
+  // Batches between sample_once (enqueued) and the publisher thread (completed + published): 6 batch buffers over 2
+  // streams.  The chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to stay ordered
+  // with events; one batch alone cannot fill the chip); a batch buffer is reused in stream order, so the host may run
+  // further ahead instead of waiting for a publication every call (with 3 buffers the sampler measured 142 us per
+  // papers100M batch, 60 of them waiting here, the GPU idle 21 % of the time).  Two streams, not three: the sampler
+  // side is bound by khop2's order chain, and a third batch in flight only slows the chain's kernels down
+  // (profiles/r03_sampler_streams_sweep.txt: 81.2 us per batch with 2 streams / 6 buffers, 85.4 with 3 / 6, 88.6 with
+  // 4 / 8, 121.7 with 1 / 2)
   const char *e_slots = getenv("SAMGRAPH_SAMPLER_SLOTS"), *e_streams = getenv("SAMGRAPH_SAMPLER_STREAMS");
-  const size_t n_streams = e_streams && atoi(e_streams) > 0 ? (size_t)atoi(e_streams) : 3;
-  slots_.resize(e_slots && atoi(e_slots) > 0 ? (size_t)atoi(e_slots) : 2 * n_streams);
+  const size_t n_streams = e_streams && atoi(e_streams) > 0 ? (size_t)atoi(e_streams) : 2;
+  slots_.resize(e_slots && atoi(e_slots) > 0 ? (size_t)atoi(e_slots) : 3 * n_streams);
   for (size_t i = 0; i < slots_.size(); ++i) {
     Slot &s = slots_[i];
     int err = 0;
