@@ -70,10 +70,6 @@ struct fgnn_sampler {
   // dedup between them) of ALL batches -- stream order instead of an event between consecutive batches; the rest of a
   // batch runs on the caller's stream behind the slot's `csr` event
   hipStream_t chain_all = nullptr;
-  // FGNN_GATHER_STREAM=1: fgnn_sampler_run_batch enqueues the feature / label gather of every batch on ONE stream of
-  // the sampler's own, behind the batch's cache split (one event hop, off khop2's order chain): the caller's streams
-  // carry the latency-bound sampling stages only and never queue a batch behind another batch's gather
-  hipStream_t gather_st = nullptr;
 };
 
 struct fgnn_batch {
@@ -89,7 +85,6 @@ struct fgnn_batch {
   void *ws;                               // scratch for the cache split
   size_t ws_bytes;
   hipEvent_t done;
-  hipEvent_t sampled;                     // FGNN_GATHER_STREAM: sampling + cache split of the batch are enqueued
   hipEvent_t t0, t1, t2;                  // optional (fgnn_batch_enable_timing): t0..t1 bracket the feature gather of
                                           // fgnn_batch_extract / the miss-row gather of fgnn_batch_extract_cached,
                                           // t1..t2 the cached-row gather
@@ -210,11 +205,6 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     fgnn_sampler_destroy(s);
     return fail(FGNN_EHIP);
   }
-  if (env_int("FGNN_GATHER_STREAM", 0) != 0 &&
-      hipStreamCreateWithFlags(&s->gather_st, hipStreamNonBlocking) != hipSuccess) {
-    fgnn_sampler_destroy(s);
-    return fail(FGNN_EHIP);
-  }
   for (auto &sl : s->slot) {
     int err = FGNN_OK;
     sl.ht = fgnn_hashtable_create_ex(s->max_nodes, s->max_edge_cap, &err);  // fills are at most a layer's edges
@@ -257,7 +247,6 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   }
   if (s->d_chain) (void)hipFree(s->d_chain);
   if (s->chain_all) (void)hipStreamDestroy(s->chain_all);
-  if (s->gather_st) (void)hipStreamDestroy(s->gather_st);
   delete s;
 }
 
@@ -287,7 +276,6 @@ extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
     delete b->scan;
   }
   if (b->done) (void)hipEventDestroy(b->done);
-  if (b->sampled) (void)hipEventDestroy(b->sampled);
   if (b->t0) (void)hipEventDestroy(b->t0);
   if (b->t1) (void)hipEventDestroy(b->t1);
   if (b->t2) (void)hipEventDestroy(b->t2);
@@ -335,7 +323,6 @@ extern "C" fgnn_batch *fgnn_batch_create(const fgnn_sampler *s, size_t feat_dim,
   b->scan = new (std::nothrow) fgnn::ScanWsHost();
   ok = ok && b->scan && b->scan->create(4096) == FGNN_OK;
   ok = ok && hipEventCreateWithFlags(&b->done, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&b->sampled, hipEventDisableTiming) == hipSuccess;
   if (!ok) return fail(FGNN_EHIP, b);
   if (hipMemset(b->d_meta, 0, sizeof(fgnn_batch_meta)) != hipSuccess) return fail(FGNN_EHIP, b);
   std::memset(b->h_meta, 0, sizeof(fgnn_batch_meta));
@@ -590,12 +577,6 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
                                       const void *feat, const void *label, void *stream) {
   int rc = fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
   if (rc == FGNN_OK && cache_table) rc = fgnn_batch_cache_index(out, cache_table, stream);
-  if (rc == FGNN_OK && s->gather_st && (feat || label)) {
-    // the gather goes to the sampler's gather stream: the caller's stream is free for its next batch's sampling
-    FGNN_HIP_CHECK(hipEventRecord(out->sampled, static_cast<hipStream_t>(stream)));
-    FGNN_HIP_CHECK(hipStreamWaitEvent(s->gather_st, out->sampled, 0));
-    stream = s->gather_st;
-  }
   if (rc == FGNN_OK && (feat || label)) rc = fgnn_batch_extract(out, feat, label, stream);
   if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
   return rc;
