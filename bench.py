@@ -1291,6 +1291,9 @@ def run_pipeline_rank(args, rank, world):
             dist.ReduceOp.SUM)
         dist.barrier()  # every trainer has verified what it was going to verify
         rings = be.queue_stats(S) if rank == 0 else None  # shared counters: any process of the job can read them
+        # where every rank's GPU hangs (NUMA node of its PCIe root) next to where the shared host feature table lives
+        gnodes = [None] * world
+        dist.all_gather_object(gnodes, None if args.rehearse else gpu_numa_node(dev_id))
         be.shutdown()
         dist.barrier()
         if rank == 0:
@@ -1343,6 +1346,10 @@ def run_pipeline_rank(args, rank, world):
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
                     "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff,
+                    "numa": {"gpu_node_of_rank": gnodes, "nodes_with_memory": numa_nodes_with_memory(),
+                             "host_feat_policy": os.environ.get("SAMGRAPH_HOST_FEAT_NUMA",
+                                                                "interleave over the nodes with memory (default)"),
+                             "note": "every trainer pulls its miss rows out of ONE shared host table (DESIGN 6)"},
                     "n1_point_of_this_curve": "N = 1 runs config 2's shape (features HBM-resident, no hand-off); the "
                                               "like-for-like N = 1 point of THIS pipeline (host-memory features behind a "
                                               f"{args.cache_ratio} cache, one GPU doing both halves) is the N = 1 line's "
