@@ -455,6 +455,7 @@ def run_single(args):
     # misses from host memory, hits from the HBM cache)
     mode = ["full"]
     leg = {}
+    stage_streams = [len(streams)]  # streams the batches rotate over (the sampler-side stage uses fewer, see below)
 
     def worker(t, first, last, timed):
         torch.cuda.set_device(dev)
@@ -474,7 +475,7 @@ def run_single(args):
             if i - first >= NBUF:           # buffer reuse: collect the summary of the batch that used it
                 collect(bt)
             step, seeds = seeds_of(i)
-            st = streams[i % len(streams) if NT > 1 or SPT > 1 else 0]
+            st = streams[i % stage_streams[0] if NT > 1 or SPT > 1 else 0]
             t_h = time.perf_counter()
             if mode[0] == "full":
                 sampler.run_batch(i, seeds, step, bt, table, feat, label, stream=st)
@@ -542,6 +543,11 @@ def run_single(args):
     sample_stage = None
     if not args.timed_only:
         mode[0] = "sample"
+        # two batch streams like an arch5 sampler process (eng_engine.cc: SampleInit): without the gather the stage is
+        # bound by khop2's order chain, and a third batch in flight only slows the chain's kernels
+        # (profiles/r03_sampler_streams_sweep.txt)
+        if NT == 1 and SPT > 2:
+            stage_streams[0] = 2
         n_stage = min(args.steps, 64)
         run_region(next_seq, next_seq + 8, False)
         next_seq += 8
@@ -557,8 +563,11 @@ def run_single(args):
         sample_stage = {"edges_per_s": stage_edges / t_stage, "ms_per_step": t_stage / n_stage * 1e3, "steps": n_stage,
                         "algorithmic_bytes_per_step": stage_bytes,
                         "hbm_frac": stage_bytes / (t_stage / n_stage) / 1e9 / HBM_PEAK_GBS,
-                        "note": "sample + dedup + remap + cache-index split only (no feature gather), same overlap"}
+                        "streams": stage_streams[0],
+                        "note": "sample + dedup + remap + cache-index split only (no feature gather), batches over "
+                                "the two streams an arch5 sampler process uses"}
         mode[0] = "full"
+        stage_streams[0] = len(streams)
     metas.clear()
     gather_ms.clear()
     # the gather with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency from
