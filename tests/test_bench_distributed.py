@@ -113,3 +113,18 @@ def test_step_ranges_cover_epoch():
                 f, c = bench.local_step_range(steps, r, world)
                 seen += list(range(f, f + c))
             assert seen == list(range(steps))
+
+
+def test_numa_helpers_on_this_host():
+    """bench.py's NUMA diagnostics (extract leg, N >= 2 line): nodes with memory from sysfs, page placement through
+    move_pages in query mode -- on whatever host this runs (one node is fine)."""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = bench.numa_nodes_with_memory()
+    assert nodes and nodes[0] == 0 and nodes == sorted(nodes)
+    a = np.ones(1 << 20, dtype=np.uint8)  # touched: the pages exist
+    hist = bench.pages_by_numa_node(a.ctypes.data, a.nbytes, samples=64)
+    assert hist is None or (sum(hist.values()) == 64 and all(int(k) in nodes or int(k) < 0 for k in hist))
+    assert bench.gpu_numa_node(0) is None or isinstance(bench.gpu_numa_node(0), int)
