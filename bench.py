@@ -431,8 +431,12 @@ def run_single(args):
     SPT = 1 if args.no_overlap else max(1, args.streams_per_thread)
     NBUF = 2 * NT * SPT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
-    for bt in batches:
-        bt.enable_timing(True)  # HIP events around the feature gather, on the stream it is launched on
+    # HIP events around the feature gather, on the stream it is launched on -- on every THIRD batch (buffers 0 and 4 of
+    # six: streams 0 and 1): the two event records per batch cost the step 3 % when every batch carries them
+    # (interleaved A/B, tools/ab_variants.py --timing-variant: 0.1186 -> 0.1222 ms), and the timed region is what
+    # `value` is computed from; a third of the launches (~250 per run) is sample enough for their average
+    for k, bt in enumerate(batches):
+        bt.enable_timing(k % 6 in (0, 4) or len(batches) < 6)
     # Batches go round-robin over NT x SPT HIP streams (batch i -> stream i % (NT*SPT), enqueued by host thread i % NT;
     # one thread is enough: enqueueing a batch takes ~0.06-0.1 ms): whole batches overlap -- the latency-bound
     # sampling/dedup chain of one with the bandwidth-bound gather of another.  fgnn_sampler_run_batch is thread-safe
@@ -670,6 +674,9 @@ def run_single(args):
                      if pmc_file else None,
                      "traffic_over_algorithmic_per_kernel": per_kernel,
                      "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
+                     "timed_launches": len(gather_ms),
+                     "timing": "HIP events on the launch's own stream around every third batch's gather inside the timed "
+                               "window (event records on every batch cost the step 3 %)",
                      "algorithmic_bytes_per_launch": gather_feat_bytes / len(metas),
                      "serial": serial, "torch_copy_GBps": copy_gbs,
                      "torch_copy_GBps_spread": {"min": min(copies), "max": max(copies), "samples": copies}},

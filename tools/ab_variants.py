@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--graph", default="rmat")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--timing-variant", action="store_true",
+                    help="adds a copy of the first variant whose batches record HIP events around the gather (what "
+                         "bench.py does for its roofline line): what the two event records per batch cost")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -71,6 +74,17 @@ def main():
                 os.environ[k] = v
         variants.append(dict(name=spec or "base", sampler=s, seq=0, env=env,
                              batches=[s.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(nbuf)],
+                             ms={m: [] for m in a.modes.split(",")}, edges=0))
+
+    if a.timing_variant:
+        v0 = variants[0]
+        s2 = lib.Sampler(indptr, indices, w["fanout"], bs, sample_type=bench.SAMPLE_TYPES[w["sample_type"]],
+                         seed=0x5A4D47, prob_prefix=prefix, walk_len=w.get("walk_len", 3), num_walks=w.get("num_walks", 4),
+                         restart_prob=w.get("restart_prob", 0.5))
+        bts = [s2.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(nbuf)]
+        for bt in bts:
+            bt.enable_timing(True)
+        variants.append(dict(name=v0["name"] + " + gather timing events", sampler=s2, seq=0, env=v0["env"], batches=bts,
                              ms={m: [] for m in a.modes.split(",")}, edges=0))
 
     def region(v, n, mode):
