@@ -497,6 +497,25 @@ def run_single(args):
             cached_ms.extend(cm)
 
     def run_region(first, last, timed):
+        if NT == 1:
+            # ONE native call enqueues and collects the whole range (fgnn_sampler_run_range: the reference's loop is a
+            # C++ thread too, cuda_loops_arch1.cc:38-84) -- no Python, ctypes or GIL work between two batches
+            sts = streams[:stage_streams[0]] if SPT > 1 else streams[:1]
+            if mode[0] == "cached":
+                ms, tm, busy = sampler.run_range(first, last - first, train, bs, batches, sts, cache_table=leg["table"],
+                                                 label=label, cache_rows=leg["cache_rows"], full_feat=leg["host_feat"],
+                                                 cached=True)
+            else:
+                ms, tm, busy = sampler.run_range(first, last - first, train, bs, batches, sts, cache_table=table,
+                                                 feat=feat if mode[0] == "full" else None,
+                                                 label=label if mode[0] == "full" else None)
+            host_busy[0] += busy
+            if timed:
+                metas.extend(ms)
+                gather_ms.extend(t[0] if mode[0] == "full" else -1.0 for t in tm)
+                if mode[0] == "cached":
+                    cached_ms.extend(tm)
+            return
         ths = [threading.Thread(target=worker, args=(t, first, last, timed)) for t in range(NT)]
         for th in ths:
             th.start()

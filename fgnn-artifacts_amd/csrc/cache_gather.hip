@@ -105,12 +105,17 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
                                                                    uint32_t *__restrict__ cache_src,
                                                                    uint32_t *__restrict__ cache_dst,
                                                                    uint32_t *__restrict__ d_counts, ScanWs scan,
-                                                                   uint32_t ablate, unsigned long long *stamp) {
+                                                                   unsigned long long *stamp, uint32_t own_blocks,
+                                                                   FixTail fix FGNN_ABLATE_PARAM) {
+  if (blockIdx.x >= own_blocks) {  // the last fill's remap fix-up riding along (FixTail, fgnn_device.h)
+    run_fix_tail(fix, own_blocks);
+    return;
+  }
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile[2];
   if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = wall_clock64();  // fgnn_batch_meta::t_sampled
   const uint32_t n = (uint32_t)resolve_count(n_host, d_n, cap);  // cap < 2^32 (host check)
-  const uint32_t per_round = kBlock * gridDim.x;
+  const uint32_t per_round = kBlock * own_blocks;
   const uint32_t rounds = n ? (n - 1) / per_round + 1 : 1u;  // <= 32 by the host's grid choice
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
@@ -323,13 +328,14 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
                                   const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
                                   uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts,
                                   void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan,
-                                  unsigned long long *stamp) {
+                                  unsigned long long *stamp, const FixTail *carry_fix) {
   auto s = static_cast<hipStream_t>(stream);
   size_t cap = d_num_nodes ? num_nodes_cap : num_nodes;
   if (!d_counts) return FGNN_EINVAL;
+  const FixTail carry = carry_fix && carry_fix->mapped ? *carry_fix : no_fix_tail();
   if (cap == 0) {
     FGNN_HIP_CHECK(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint32_t), s));
-    return FGNN_OK;
+    return carry.mapped ? hashtable_map_fix(carry, stream) : FGNN_OK;
   }
   if (!table || !nodes || !miss_src || !miss_dst || !cache_src || !cache_dst || cap > 0xffffffffull)
     return FGNN_EINVAL;
@@ -351,14 +357,19 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
     if (grid > scan->ws.max_tiles) grid = scan->ws.max_tiles;
     if (grid > nb1) grid = nb1;
     if (grid > 0 && div_up(cap, grid * kBlock) <= 32) {
-      const char *e_ab = getenv("FGNN_SPLIT_ABLATE");  // profiling only; results are wrong when set
-      const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
-      if (const char *e_g = getenv("FGNN_SPLIT_GRID")) grid = (size_t)atoi(e_g) < grid ? (size_t)atoi(e_g) : grid;
-      hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid), dim3(kBlock), 0, s, table, nodes, num_nodes,
-                         d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
-                         scan->next(2, grid), ablate, stamp);
+#ifdef FGNN_PROFILING
+      const uint32_t ablate = (uint32_t)tune_int("FGNN_SPLIT_ABLATE", 0);  // results are wrong when set
+      if (const int g = tune_int("FGNN_SPLIT_GRID", 0)) grid = (size_t)g < grid ? (size_t)g : grid;
+#endif
+      hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid + carry.blocks), dim3(kBlock), 0, s, table, nodes,
+                         num_nodes, d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
+                         scan->next(2, grid), stamp, (uint32_t)grid, carry FGNN_ABLATE_ARG(ablate));
       return launch_status(__func__);
     }
+  }
+  if (carry.mapped) {
+    const int rc = hashtable_map_fix(carry, stream);
+    if (rc != FGNN_OK) return rc;
   }
   if (ipt == 1)
     hipLaunchKernelGGL((cache_count_kernel<1>), dim3(nb), dim3(kBlock), 0, s, table, nodes, num_nodes, d_num_nodes, cap,
@@ -395,18 +406,14 @@ bool fgnn::gather_takes_tail(const void *out, const void *src, size_t n_cap, siz
          reinterpret_cast<uintptr_t>(src) % 16 == 0 && n_cap > 0 && n_cap * (row_bytes / 16) < 0xffffffffull;
 }
 
-// is `p` host memory the GPU reads over the host link?  (one runtime query per distinct pointer and thread)
+// is `p` host memory the GPU reads over the host link?  Asked per launch that could be one (a registered table may be
+// freed and its address reused for device memory: no caching by pointer value); a microsecond next to a launch whose
+// rows cross the host link
 static bool pointer_is_host(const void *p) {
-  static thread_local const void *last = nullptr;
-  static thread_local bool last_host = false;
-  if (p == last) return last_host;
   hipPointerAttribute_t a;
-  bool host = false;
-  if (hipPointerGetAttributes(&a, p) == hipSuccess) host = a.type == hipMemoryTypeHost;
-  else (void)hipGetLastError();
-  last = p;
-  last_host = host;
-  return host;
+  if (hipPointerGetAttributes(&a, p) == hipSuccess) return a.type == hipMemoryTypeHost;
+  (void)hipGetLastError();
+  return false;
 }
 
 int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
@@ -448,21 +455,18 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
     // front of every other kernel's misses: on a GPU that ALSO samples, the next batch's sampling chain ran 2-6x slower
     // beside a miss gather (profiles/r03_extract_timeline.txt) and 64 workgroups gave the whole leg 0.334 ms per batch
     // instead of 0.390 (profiles/r03_extract_sweep.txt).  The caller says which GPU it is on: `host_grid` workgroups
-    // for host-source launches, 0 = the HBM-sized grid (FGNN_GATHER_HOST_WGS overrides both, for sweeps).
-    const bool host_src = (host_grid != 0 || getenv("FGNN_GATHER_HOST_WGS")) && pointer_is_host(src);
-    // tuning knobs (read per call: only used by profiles/ sweeps)
-    const char *e_u = getenv("FGNN_GATHER_UNROLL"), *e_w = getenv("FGNN_GATHER_WG_PER_CU"), *e_nt = getenv("FGNN_GATHER_NT");
-    const int unroll = e_u ? atoi(e_u) : 4;
-    const size_t wg_per_cu = e_w ? (size_t)atoi(e_w) : 4, cus = (size_t)device_cu_count();
-    const char *e_h = getenv("FGNN_GATHER_HOST_WGS");
-    const size_t host_wgs = e_h ? (size_t)atoi(e_h) : host_grid;  // 0: no special case
+    // for host-source launches, 0 = the HBM-sized grid.  (The sweeps' knobs -- FGNN_GATHER_HOST_WGS / _UNROLL /
+    // _WG_PER_CU / _NT / _NTS -- exist in the profiling build only.)
+    const size_t host_wgs = (size_t)tune_int("FGNN_GATHER_HOST_WGS", (int)host_grid);  // 0: no special case
+    const bool host_src = host_wgs != 0 && pointer_is_host(src);
+    const int unroll = tune_int("FGNN_GATHER_UNROLL", 4);
+    const size_t wg_per_cu = (size_t)tune_int("FGNN_GATHER_WG_PER_CU", 4), cus = (size_t)device_cu_count();
     // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
     // loads (profiles/r01_gather_sweep.csv)
-    const bool nt = e_nt ? atoi(e_nt) != 0 : true;
-    const char *e_nts = getenv("FGNN_GATHER_NTS");
+    const bool nt = tune_int("FGNN_GATHER_NT", 1) != 0;
     // non-temporal stores too: 256 MB of gathered rows left as dirty lines in the Infinity Cache slow down the
     // cold random reads of the next batch's sampling chain (whole step 0.228 -> 0.207 ms)
-    const bool nts = e_nts ? atoi(e_nts) != 0 : true;
+    const bool nts = tune_int("FGNN_GATHER_NTS", 1) != 0;
 #define FGNN_GATHER3(U, C, N)                                                                                    \
   do {                                                                                                           \
     size_t blocks = div_up(total, (size_t)kBlock * U);                                                           \

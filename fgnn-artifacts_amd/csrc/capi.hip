@@ -27,7 +27,11 @@ unsigned long long *scan_help_counter() {
   }
   return g_helps[dev];
 }
+static int g_scan_help_after = -1;
+int scan_help_after_override() { return g_scan_help_after; }
 }  // namespace fgnn
+
+extern "C" void fgnn_debug_set_scan_help_after(int polls) { fgnn::g_scan_help_after = polls; }
 
 extern "C" size_t fgnn_debug_phase_log_bytes(void) {
   return (size_t)fgnn::kPhaseLogKinds * fgnn::kPhaseLogTiles * 8 * sizeof(unsigned long long);

@@ -4,6 +4,7 @@
 //
 // Everything a batch needs is enqueued on one stream with device-resident sizes; the host gets one
 // pinned fgnn_batch_meta per batch.  Bit-identical to oracle fgnn_oracle_do_sample.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -13,7 +14,9 @@
 
 #include "fgnn_device.h"
 
-constexpr int kSlots = 4;  // batches that may be in flight at once (each on its own stream if the caller wishes)
+constexpr int kSlots = 6;  // batches that may be in flight at once (each on its own stream if the caller wishes); a
+                           // multiple of 1, 2, 3 and 6 streams, so that a caller rotating over that many streams
+                           // brings every slot back on the stream that used it last (no event between its uses)
 
 struct fgnn_sampler {
   fgnn_sampler_config cfg;
@@ -22,20 +25,18 @@ struct fgnn_sampler {
   size_t edge_cap[FGNN_MAX_LAYERS];       // worst-case #edges of layer l
   size_t max_edge_cap;
   size_t ws_bytes;
-  // Per in-flight batch ("slot" = sequence number % kSlots): its own dedup table, scratch and temporaries.
-  // A table is wiped right after its last use in the batch (end of the sampling chain) instead of at the start
-  // of the next batch (cuda_hashtable.cu:714-723): the 64 MiB memset is bandwidth work that overlaps the
-  // latency-bound kernels of the batches running on the other streams.
+  // Per in-flight batch ("slot" = sequence number % kSlots): its own dedup table, scratch and temporaries.  The table
+  // is reset right after its last use in the batch (a generation bump, hashtable.hip).
   struct Slot {
     fgnn_hashtable *ht = nullptr;
     uint32_t *tmp_dst = nullptr;          // [max_edge_cap] sampled neighbours (global ids)
     void *ws = nullptr;                   // kernel scratch
+    // `done`: the slot's last batch has finished its sampling stage; `csr`: it has enqueued its last sampler kernel
+    // (khop2 only).  Both are recorded only once somebody has needed them (see `cross_slot` / `cross_csr`).
     hipEvent_t done = nullptr, csr = nullptr;
-    // FGNN_CHAIN_PRIORITY (see fgnn_sampler_sample_ordered): the sampling stage of the slot's batches runs on this
-    // high-priority stream, the caller's stream keeps the cache split and the bandwidth-bound gather
-    hipStream_t chain_st = nullptr;
-    hipEvent_t entered = nullptr;
+    hipStream_t last_st = nullptr;        // stream of the slot's last batch
     bool was_used = false;
+    bool done_recorded = false, csr_recorded = false;  // the event covers the slot's last batch
     fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
     uint32_t *rank_bitmap = nullptr;      // with-replacement samplers: seed ranking bitmap over the node ids (all zero
                                           // between batches), fgnn::RankWs
@@ -49,27 +50,16 @@ struct fgnn_sampler {
   uint64_t next_seq = 0;                  // for the unordered entry point
   uint64_t returned = 0;                  // calls [0, returned) have returned
   uint64_t csr_passed = 0;                // calls [0, csr_passed) have enqueued their last sampler kernel
-  bool done_flag[kSlots] = {false, false, false, false};
-  bool csr_flag[kSlots] = {false, false, false, false};
-  // switches, read from the environment at create time (see env_int)
-  int opt_chain_priority = 0;   // FGNN_CHAIN_PRIORITY
-  int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 (0: fused last layer)
-  int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED (profiling only: wrong results under overlap)
-  // FGNN_DEFER_FIX (default 1; khop2 only): a layer's remap fix-up is launched behind the NEXT layer's sampler kernel --
-  // nothing of that sampler reads the remapped edges, and the fix-up leaves khop2's cross-batch order chain
-  // (interleaved A/B, profiles/r03_ab5_defer_fix.txt: whole path 0.1227 -> 0.1200 ms per batch, sampler-side stage
-  // 0.0931 -> 0.0881)
-  int opt_defer_fix = 1;
-  int opt_seeds_ready = 0;      // FGNN_CHAIN_SEEDS_READY: with a chain stream, do not order it behind the caller's stream
-                                // (the caller guarantees seeds and batch buffer are ready when it calls)
-  // FGNN_CHAIN_FLAGS=1 (off by default: measured slower than events, profiles/r03_ab3_chain_flags_v3.txt): khop2's
-  // batch order handed over on the device (fgnn_device.h, ChainSync) instead of an event between the batches' streams;
-  // kChainWords zeroed words, null otherwise
-  uint32_t *d_chain = nullptr;
-  // FGNN_CHAIN_PRIORITY=3: ONE stream carries the order chain (every sampler launch up to the last layer's, and the
-  // dedup between them) of ALL batches -- stream order instead of an event between consecutive batches; the rest of a
-  // batch runs on the caller's stream behind the slot's `csr` event
-  hipStream_t chain_all = nullptr;
+  bool done_flag[kSlots] = {};
+  bool csr_flag[kSlots] = {};
+  // Events cost host time per batch (a record and a wait each), and most callers never need them: a single-stream
+  // caller orders everything by the stream, a caller rotating over 2, 3 or 6 streams meets every slot on its own
+  // stream again.  So a slot's `done` (and the CSR hand-over `csr`) is recorded per batch only after the first time a
+  // batch found its slot (its predecessor) on ANOTHER stream; that first time is served by recording the event late,
+  // on the other stream (it then covers more than needed: correct, once).
+  std::atomic<bool> cross_slot{false}, cross_csr{false};
+  int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 = 0 (profiling build): fused last layer
+  int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED = 1 (profiling build): wrong results under overlap
 };
 
 struct fgnn_batch {
@@ -102,18 +92,6 @@ namespace {
 // marks the batch so that the host does not take the truncated tensor for the whole one (fgnn_hip.h, `overflow`)
 __global__ void batch_rows_overflow_kernel(fgnn_batch_meta *m, uint32_t cap) {
   if (m->num_input > cap) m->overflow = 1u;
-}
-
-// FGNN_CHAIN_PRIORITY=1: a batch's sampling stage (samplers, dedup, remap -- everything up to the table's generation
-// bump) is enqueued on a high-priority stream of its sampler slot; the caller's stream, which then carries only the
-// cache split and the feature gather, waits for the slot's `done` event.  The latency-bound kernels of khop2's
-// cross-batch order chain are then dispatched ahead of the bandwidth-bound gathers of the other batches in flight
-// whenever wave slots free up.  0 (default): everything on the caller's stream.
-// (switches of this file are read when a sampler is created, not cached per process: an A/B tool can create one
-// sampler per setting over the same graph, tools/ab_variants.py)
-int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return e && *e ? atoi(e) : dflt;
 }
 
 size_t dtype_size(int dtype) {
@@ -164,11 +142,8 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   auto *s = new (std::nothrow) fgnn_sampler();
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
-  s->opt_chain_priority = env_int("FGNN_CHAIN_PRIORITY", 0);
-  s->opt_split_l0 = env_int("FGNN_KHOP_SPLIT_L0", -1);
-  s->opt_unordered = env_int("FGNN_KHOP2_UNORDERED", 0);
-  s->opt_seeds_ready = env_int("FGNN_CHAIN_SEEDS_READY", 0);
-  s->opt_defer_fix = env_int("FGNN_DEFER_FIX", 1);
+  s->opt_split_l0 = fgnn::tune_int("FGNN_KHOP_SPLIT_L0", -1);
+  s->opt_unordered = fgnn::tune_int("FGNN_KHOP2_UNORDERED", 0);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
   s->max_edge_cap = 0;
@@ -192,32 +167,14 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
     if (cfg->sample_type == FGNN_RANDOM_WALK) need = fgnn_random_walk_scratch_bytes(s->in_cap[l], cfg->fanout[l]);
     if (need > s->ws_bytes) s->ws_bytes = need;
   }
-  if (cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered && env_int("FGNN_CHAIN_FLAGS", 0) != 0 &&
-      s->in_cap[0] <= 131072) {  // <= 2048 workgroups arrive per launch (sample_khop.hip picks 64 seeds per workgroup)
-    if (hipMalloc(&s->d_chain, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(s->d_chain, 0, fgnn::kChainWords * sizeof(uint32_t)) != hipSuccess) {
-      fgnn_sampler_destroy(s);
-      return fail(FGNN_EHIP);
-    }
-  }
-  if (s->opt_chain_priority == 3 && cfg->sample_type == FGNN_KHOP2 && !s->opt_unordered &&
-      hipStreamCreateWithFlags(&s->chain_all, hipStreamNonBlocking) != hipSuccess) {
-    fgnn_sampler_destroy(s);
-    return fail(FGNN_EHIP);
-  }
   for (auto &sl : s->slot) {
     int err = FGNN_OK;
     sl.ht = fgnn_hashtable_create_ex(s->max_nodes, s->max_edge_cap, &err);  // fills are at most a layer's edges
     bool ok = sl.ht != nullptr;
     ok = ok && hipMalloc(&sl.tmp_dst, s->max_edge_cap * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&sl.ws, s->ws_bytes) == hipSuccess;
-    for (hipEvent_t *e : {&sl.done, &sl.csr, &sl.entered})
+    for (hipEvent_t *e : {&sl.done, &sl.csr})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-    if (s->opt_chain_priority == 1 || s->opt_chain_priority == 2) {
-      int lo = 0, hi = 0;  // numerically lower = higher priority
-      ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
-      ok = ok && hipStreamCreateWithPriority(&sl.chain_st, hipStreamNonBlocking, hi) == hipSuccess;
-    }
     ok = ok && sl.scan_sample.create(s->max_nodes / 64 + 2) == FGNN_OK;
     if (cfg->num_node && (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX || cfg->sample_type == FGNN_KHOP1 ||
                           cfg->sample_type == FGNN_WEIGHTED_KHOP)) {
@@ -241,12 +198,9 @@ extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
     if (sl.tmp_dst) (void)hipFree(sl.tmp_dst);
     if (sl.rank_bitmap) (void)hipFree(sl.rank_bitmap);
     if (sl.ws) (void)hipFree(sl.ws);
-    for (hipEvent_t e : {sl.done, sl.csr, sl.entered})
+    for (hipEvent_t e : {sl.done, sl.csr})
       if (e) (void)hipEventDestroy(e);
-    if (sl.chain_st) (void)hipStreamDestroy(sl.chain_st);
   }
-  if (s->d_chain) (void)hipFree(s->d_chain);
-  if (s->chain_all) (void)hipStreamDestroy(s->chain_all);
   delete s;
 }
 
@@ -337,28 +291,32 @@ struct SeqGuard {
   fgnn_sampler *s;
   uint64_t seq;
   hipStream_t st;
-  hipStream_t caller_st;
   bool csr_marked = false;
-  bool chain_published = false;  // device hand-off: this batch's turn has been (or will be, by an enqueued launch) passed on
-  bool finished = false;  // the success path has reset the slot's table and recorded its events itself
+  bool finished = false;  // the success path has reset the slot's table and closed the slot itself
+  // end of the slot's use by this batch: remember the stream, record `done` if slots have been seen to change streams
+  void close_slot() {
+    fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+    sl.done_recorded = s->cross_slot.load(std::memory_order_relaxed) && hipEventRecord(sl.done, st) == hipSuccess;
+    sl.last_st = st;
+    sl.was_used = true;
+  }
+  // the batch's last sampler kernel has been enqueued on `st` (khop2): record the hand-over event if batches have been
+  // seen to follow each other on different streams, then let the next call go on
+  void pass_csr(bool record_allowed) {
+    if (csr_marked) return;
+    fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+    sl.csr_recorded = record_allowed && s->cross_csr.load(std::memory_order_relaxed) &&
+                      hipEventRecord(sl.csr, st) == hipSuccess;
+    sl.last_st = st;  // read by the next call (under the mutex released in mark_csr)
+    mark_csr();
+  }
   // An early error return leaves the slot's table with this batch's pending buckets and notes: the slot's next batch
-  // must not dedup against them, and must still find the slot's events recorded.
+  // must not dedup against them.
   void abandon() {
     fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
     (void)fgnn::hashtable_next_generation(sl.ht, st, false);
-    pass_chain();
-    if (s->cfg.sample_type == FGNN_KHOP2 && !csr_marked) (void)hipEventRecord(sl.csr, st);
-    (void)hipEventRecord(sl.done, st);
-    if (st != caller_st) (void)hipStreamWaitEvent(caller_st, sl.done, 0);
-    sl.was_used = true;
-  }
-  // device hand-off: a batch that launches no publishing sampler kernel (no seeds, an error on the way) still waits
-  // for its predecessor and publishes its own number, or every later batch would time out
-  void pass_chain() {
-    if (!s->d_chain || chain_published) return;
-    chain_published = true;
-    const fgnn::ChainSync c{s->d_chain, nullptr, (uint32_t)seq, (uint32_t)seq + 1u, seq > 0 ? 1u : 0u, 1u};
-    (void)fgnn::launch_chain_pass(c, st);
+    pass_csr(s->cfg.sample_type == FGNN_KHOP2);
+    close_slot();
   }
   void mark_csr() {
     if (csr_marked) return;
@@ -384,59 +342,51 @@ struct SeqGuard {
   }
 };
 
-}  // namespace
-
-extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
-                                           uint64_t batch_key, fgnn_batch *out, void *stream) {
+// DoGPUSample (cuda_loops.cc:50-267) for batch `seq`.  owed_fix != null: the caller takes over the last layer's remap
+// fix-up (it lets a later launch of the batch carry it, FixTail); null: the batch's edge lists are final on return.
+int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                fgnn_batch *out, void *stream, fgnn::FixTail *owed_fix) {
+  if (owed_fix) *owed_fix = fgnn::no_fix_tail();
   if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
     return FGNN_EINVAL;
-  const hipStream_t caller_st = static_cast<hipStream_t>(stream);
-  hipStream_t st = caller_st;
-  if (hipStream_t c = s->chain_all ? s->chain_all : s->slot[seq % kSlots].chain_st) {
-    st = c;
-    stream = c;
-  }
+  const hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t L = s->cfg.num_layers;
-  // FGNN_KHOP2_UNORDERED=1 (profiling only; results then depend on the overlap): drop khop2's batch-order chain
-  const bool unordered = s->opt_unordered != 0;
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
-  const bool ordered = mutates && !unordered;
-  // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one (FGNN_KHOP_SPLIT_L0=0: fused).
-  // khop2 rewrites CSR rows, so the sampler kernels of consecutive batches form ONE chain however the batches overlap:
-  // layer-(L-1) sampler -> its dedup -> ... -> layer-0 sampler -> next batch.  The layer-0 launch is the long one, and
-  // half of it is the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's
-  // sampling starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more
-  // launch and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt)
-  const int split_env = s->opt_split_l0;
+  const bool ordered = mutates && s->opt_unordered == 0;
   {
-    // the slot is free once call seq - kSlots has returned (its device work is ordered by the events below)
+    // the slot is free once call seq - kSlots has returned (its device work is ordered below)
     std::unique_lock<std::mutex> lk(s->mu);
     // sequence numbers must be consecutive and used once; a gap would wait forever, so give up loudly instead
     if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return seq < s->returned + kSlots; })) return FGNN_EINVAL;
     if (seq < s->returned) return FGNN_EINVAL;
   }
-  SeqGuard guard{s, seq, st, caller_st};
+  SeqGuard guard{s, seq, st};
   fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
   fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
-  if (st != caller_st && !s->opt_seeds_ready) {  // whatever the caller enqueued before this call (the seeds, the batch buffer's last use)
-    FGNN_HIP_CHECK(hipEventRecord(sl.entered, caller_st));
-    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.entered, 0));
-  }
   fgnn_hashtable *ht = sl.ht;
   uint32_t *tmp_dst = sl.tmp_dst;
   void *ws = sl.ws;
   out->num_output = num_seeds;
   out->meta_copied = false;
-  // the slot's scratch was last used kSlots batches ago, possibly on another stream
-  if (sl.was_used) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+  // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
+  // stream, by the slot's event otherwise
+  if (sl.was_used && sl.last_st != st) {
+    if (!sl.done_recorded) FGNN_HIP_CHECK(hipEventRecord(sl.done, sl.last_st));  // late: covers more than needed, once
+    s->cross_slot.store(true, std::memory_order_relaxed);
+    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+  }
   if (ordered && seq > 0) {
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
     {
       std::unique_lock<std::mutex> lk(s->mu);
       if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
     }
-    // (the wait above keeps the ENQUEUE order, which the device hand-off's forward progress rests on as well)
-    if (!s->d_chain && !s->chain_all) FGNN_HIP_CHECK(hipStreamWaitEvent(st, s->slot[(seq - 1) % kSlots].csr, 0));
+    fgnn_sampler::Slot &prev = s->slot[(seq - 1) % kSlots];
+    if (prev.last_st != st) {
+      if (!prev.csr_recorded) FGNN_HIP_CHECK(hipEventRecord(prev.csr, prev.last_st));  // late, once (see cross_csr)
+      s->cross_csr.store(true, std::memory_order_relaxed);
+      FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
+    }
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
   int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
@@ -451,8 +401,9 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
     if (rc != FGNN_OK) return rc;
   }
 
-  // a remap fix-up owed from the previous layer (FGNN_DEFER_FIX): launched behind this layer's sampler kernel
-  struct { bool owed = false; const size_t *d_n = nullptr; size_t cap = 0; uint32_t *mapped = nullptr; } fix;
+  // a layer's remap fix-up is not launched by itself: the next fill's insert launch carries it (FixTail) -- nothing of
+  // the next layer's sampling reads the remapped edges -- and the last layer's goes to the caller or runs at the end
+  fgnn::FixTail owed = fgnn::no_fix_tail();
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
   size_t cur_n_host = num_seeds;
@@ -466,8 +417,9 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
         s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
     {
       // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
-      // FGNN_RANK_BITMAP=0 (A/B only): order the seeds with rocPRIM's radix sort like the stateless C entry points
-      static const bool use_rank = [] { const char *e = getenv("FGNN_RANK_BITMAP"); return !(e && atoi(e) == 0); }();
+      // FGNN_RANK_BITMAP=0 (profiling build, A/B only): order the seeds with rocPRIM's radix sort like the stateless
+      // C entry points
+      static const bool use_rank = fgnn::tune_int("FGNN_RANK_BITMAP", 1) != 0;
       const fgnn::RankWs rank{use_rank ? sl.rank_bitmap : nullptr, &sl.scan_sample};
       rc = fgnn::sample_with_replacement_ex(
           s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
@@ -489,75 +441,70 @@ extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const 
       // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
       const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
       const bool first = start_in_sampler && l == (long)L - 1;
-      // device hand-off of khop2's batch order: the batch's first sampler launch waits for batch seq - 1, its last
-      // one publishes seq + 1
-      fgnn::ChainSync chain{ordered ? s->d_chain : nullptr, &out->d_meta->overflow, (uint32_t)seq, (uint32_t)seq + 1u,
-                            (l == (long)L - 1 && seq > 0) ? 1u : 0u, l == 0 ? 1u : 0u};
-      // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
-      // (not when this launch also inserts the seeds: their local ids would replace pending edges without a note)
-      split = ordered && l == 0 && !first && split_env != 0;
+      // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one.  khop2 rewrites CSR rows,
+      // so the sampler kernels of consecutive batches form ONE chain however the batches overlap: layer-(L-1) sampler
+      // -> its dedup -> ... -> layer-0 sampler -> next batch.  The layer-0 launch is the long one, and half of it is
+      // the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's sampling
+      // starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more launch
+      // and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt).  Not when this launch also inserts
+      // the seeds: their local ids would replace pending edges without a note.
+      split = ordered && l == 0 && !first && s->opt_split_l0 != 0;
       if (split)
         rc = fgnn::sample_khop_plain(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
                                      out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
-                                     stream, &sl.scan_sample, &chain);
+                                     stream, &sl.scan_sample);
       else {
-      resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
-      rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l],
-                             tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes, stream,
-                             &sl.scan_sample, first ? &start : nullptr, resolved, &chain);
+        // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
+        resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
+        rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
+                               out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes,
+                               stream, &sl.scan_sample, first ? &start : nullptr, resolved);
       }
     }
     if (rc != FGNN_OK) return rc;
-    if (mutates && l == 0) {  // last sampler kernel of this batch: the next batch may touch the CSR now
-      if (s->d_chain && ordered) guard.chain_published = true;  // by the launch just enqueued
-      if (!s->d_chain || s->opt_chain_priority >= 2) FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
-      guard.mark_csr();
-      if (st != caller_st && s->opt_chain_priority >= 2) {
-        // mode 2: only the order chain itself ran at high priority; the last layer's insert and dedup, which nothing
-        // of the next batch waits for, go back to the caller's stream
-        FGNN_HIP_CHECK(hipStreamWaitEvent(caller_st, sl.csr, 0));
-        st = caller_st;
-        stream = caller_st;
-        guard.st = caller_st;
-      }
-    }
-    if (fix.owed) {  // the previous layer's fix-up: off the order chain, behind this layer's sampler
-      fix.owed = false;
-      rc = fgnn::hashtable_map_fix(ht, 0, fix.d_n, fix.cap, fix.mapped, stream);
-      if (rc != FGNN_OK) return rc;
-    }
-    const bool inserted = (s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0) && !split;
+    if (mutates && l == 0) guard.pass_csr(true);  // last sampler kernel of this batch: the next batch may touch the CSR
+    const bool inserted = khop_fused && !split;
     // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
-    bool defer = s->opt_defer_fix != 0 && ordered && l > 0;
+    fgnn::FixTail mine = fgnn::no_fix_tail();
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &defer);
+                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed);
     if (rc != FGNN_OK) return rc;
-    if (defer) {
-      fix.owed = true;
-      fix.d_n = d_ne;
-      fix.cap = ecap;
-      fix.mapped = out->row[l];
-    }
+    owed = mine;
     in_cap += ecap;
     cur = out->input_nodes;
     d_cur_n = fgnn_hashtable_d_num_items(ht);
     cur_n_host = 0;
   }
-  if (mutates && num_seeds == 0) {
-    if (ordered) guard.pass_chain();
-    FGNN_HIP_CHECK(hipEventRecord(sl.csr, st));
+  if (mutates) guard.pass_csr(true);  // (a batch without seeds still takes its turn)
+  if (owed.mapped) {
+    if (owed_fix) *owed_fix = owed;
+    else if ((rc = fgnn::hashtable_map_fix(owed, stream)) != FGNN_OK) return rc;
   }
-  // wipe the table for the slot's next batch (Reset, cuda_hashtable.cu:714-723), then mark the slot reusable
   // Reset (cuda_hashtable.cu:714-723) for the slot's next batch: a generation bump, no memory traffic
   rc = fgnn::hashtable_next_generation(ht, stream, false);
   if (rc != FGNN_OK) return rc;
-  FGNN_HIP_CHECK(hipEventRecord(sl.done, st));
-  if (st != caller_st) FGNN_HIP_CHECK(hipStreamWaitEvent(caller_st, sl.done, 0));
-  sl.was_used = true;
+  guard.close_slot();
   guard.finished = true;
   return launch_status(__func__);
+}
+
+int batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream, const fgnn::FixTail *carry) {
+  b->meta_copied = false;
+  fgnn::ScanErrorSink sink(&b->d_meta->overflow);
+  // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
+  return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
+                                       b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
+                                       b->ws_bytes, stream, b->scan,
+                                       reinterpret_cast<unsigned long long *>(&b->d_meta->t_sampled), carry);
+}
+
+}  // namespace
+
+extern "C" int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                           uint64_t batch_key, fgnn_batch *out, void *stream) {
+  return sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, nullptr);
 }
 
 extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
@@ -575,8 +522,10 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
 extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                                       uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
                                       const void *feat, const void *label, void *stream) {
-  int rc = fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
-  if (rc == FGNN_OK && cache_table) rc = fgnn_batch_cache_index(out, cache_table, stream);
+  fgnn::FixTail owed = fgnn::no_fix_tail();
+  // with a cache split to follow, the last layer's remap fix-up rides on that launch
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr);
+  if (rc == FGNN_OK && cache_table) rc = batch_cache_index(out, cache_table, stream, &owed);
   if (rc == FGNN_OK && (feat || label)) rc = fgnn_batch_extract(out, feat, label, stream);
   if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
   return rc;
@@ -584,13 +533,7 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
 
 extern "C" int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream) {
   if (!b || !cache_table) return FGNN_EINVAL;
-  b->meta_copied = false;
-  fgnn::ScanErrorSink sink(&b->d_meta->overflow);
-  // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
-  return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
-                                       b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
-                                       b->ws_bytes, stream, b->scan,
-                                       reinterpret_cast<unsigned long long *>(&b->d_meta->t_sampled));
+  return batch_cache_index(b, cache_table, stream, nullptr);
 }
 
 extern "C" int fgnn_batch_enable_timing(fgnn_batch *b, int on) {
@@ -710,10 +653,62 @@ extern "C" int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, cons
                                              const void *cache_rows, const void *full_feat, const void *label,
                                              void *stream) {
   if (!cache_table) return FGNN_EINVAL;
-  int rc = fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
-  if (rc == FGNN_OK) rc = fgnn_batch_cache_index(out, cache_table, stream);
+  fgnn::FixTail owed = fgnn::no_fix_tail();
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, &owed);
+  if (rc == FGNN_OK) rc = batch_cache_index(out, cache_table, stream, &owed);
   if (rc == FGNN_OK) rc = fgnn_batch_extract_cached(out, cache_rows, full_feat, label, stream);
   if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
+  return rc;
+}
+
+// The batch loop of one GPU that samples and extracts, in native code: what the reference's loop threads do
+// (RunSampleCopySubLoopOnce, cuda_loops_arch1.cc:38-84: next batch of the shuffled train set -> DoGPUSample ->
+// DoGPUFeatureExtract -> Submit), with the batches rotating over the plan's buffers and streams so that whole batches
+// overlap.  One host thread; a buffer is collected (its summary copied out) right before it is reused and at the end.
+extern "C" int fgnn_sampler_run_range(fgnn_sampler *s, const fgnn_run_plan *p, uint64_t first_seq, size_t count,
+                                      fgnn_batch_meta *h_metas, float *h_gather_ms, double *h_enqueue_s) {
+  if (!s || !p || !p->batches || !p->streams || p->num_batches == 0 || p->num_streams == 0 || !p->d_train ||
+      p->batch_size == 0 || p->batch_size > s->cfg.max_batch_size || p->num_train == 0 || (count && !h_metas))
+    return FGNN_EINVAL;
+  if (p->cached && !p->cache_table) return FGNN_EINVAL;
+  const size_t steps = (p->num_train + p->batch_size - 1) / p->batch_size;
+  double busy = 0.0;
+  auto collect = [&](uint64_t i) -> int {
+    fgnn_batch *b = p->batches[i % p->num_batches];
+    const int rc = fgnn_batch_wait(b, &h_metas[i - first_seq]);
+    if (rc != FGNN_OK) return rc;
+    if (h_gather_ms) {
+      float *t = h_gather_ms + 2 * (i - first_seq);
+      t[0] = t[1] = -1.0f;
+      if (p->cached) (void)fgnn_batch_extract_cached_ms(b, t);
+      else t[0] = fgnn_batch_gather_ms(b);
+    }
+    return FGNN_OK;
+  };
+  int rc = FGNN_OK;
+  for (uint64_t i = first_seq; i < first_seq + count && rc == FGNN_OK; ++i) {
+    if (i - first_seq >= p->num_batches && (rc = collect(i - p->num_batches)) != FGNN_OK) break;
+    const size_t step = (size_t)(i % steps);
+    const size_t b0 = step * p->batch_size;
+    const size_t n = p->num_train - b0 < p->batch_size ? p->num_train - b0 : p->batch_size;
+    fgnn_batch *b = p->batches[i % p->num_batches];
+    void *st = p->streams[i % p->num_streams];
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p->cached)
+      rc = fgnn_sampler_run_batch_cached(s, i, p->d_train + b0, n, step, b, p->cache_table, p->cache_rows, p->full_feat,
+                                         p->label, st);
+    else
+      rc = fgnn_sampler_run_batch(s, i, p->d_train + b0, n, step, b, p->cache_table, p->feat, p->label, st);
+    busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // drain: every buffer that still holds an uncollected batch (also after an error: the buffers are reusable afterwards)
+  const uint64_t enq_end = first_seq + count;
+  const uint64_t drain0 = count > p->num_batches ? enq_end - p->num_batches : first_seq;
+  for (uint64_t i = drain0; i < enq_end; ++i) {
+    const int rc2 = rc == FGNN_OK ? collect(i) : fgnn_batch_wait(p->batches[i % p->num_batches], nullptr);
+    if (rc == FGNN_OK) rc = rc2;
+  }
+  if (h_enqueue_s) *h_enqueue_s = busy;
   return rc;
 }
 

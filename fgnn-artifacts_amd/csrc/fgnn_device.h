@@ -62,6 +62,26 @@ inline int launch_status(const char *what) {
   return FGNN_OK;
 }
 
+// ---- build flavours --------------------------------------------------------------------------------------------
+// The shipped library (libfgnn_hip.so) reads NO tuning or ablation switch from the environment: a stray variable must
+// not change -- let alone corrupt -- a training run.  The A/B and ablation knobs the tools/ scripts use exist only in
+// the profiling build (make prof -> lib/libfgnn_hip_prof.so, -DFGNN_PROFILING); there `tune_int` reads FGNN_* variables
+// and the kernels take an `ablate` mask.  In the release build `tune_int` is the default and `ablate` a constant 0, so
+// the compiler drops the branches.
+#ifdef FGNN_PROFILING
+inline int tune_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+#define FGNN_ABLATE_PARAM , uint32_t ablate
+#define FGNN_ABLATE_ARG(x) , (uint32_t)(x)
+#else
+inline int tune_int(const char *, int dflt) { return dflt; }
+constexpr uint32_t ablate = 0u;
+#define FGNN_ABLATE_PARAM
+#define FGNN_ABLATE_ARG(x)
+#endif
+
 // ---- Philox4x32-10, addressed exactly like oracle/fgnn_oracle.c:fgnn_philox_draw ------------
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -361,6 +381,7 @@ __device__ __forceinline__ void phase_mark(const ScanWs &w, uint32_t tile, int p
 }
 unsigned long long *phase_log_base();  // capi.hip
 unsigned long long *scan_help_counter();  // capi.hip: device word counting helped tiles (allocated on first use)
+int scan_help_after_override();           // capi.hip: -1 unless fgnn_debug_set_scan_help_after() was called
 // Where a timed-out cross-workgroup wait is reported for launches made by this host thread: the batch driver points
 // it at the batch summary's `overflow` word (so the host sees it with the batch), otherwise the descriptors' own word.
 uint32_t *&scan_error_sink();           // capi.hip (thread-local)
@@ -571,8 +592,9 @@ struct ScanWsHost {
     // (the A/B switch that put tickets into EVERY single-pass kernel, profiles/r02_ticket_ab.txt, is gone: kernels that
     // take tile = blockIdx.x never draw from the counter, so advancing the base for them left base and counter out of
     // step for the next ticketed launch on the slot)
-    // FGNN_SCAN_HELP_AFTER=<polls>: 0 makes every wait that is not satisfied at once take the helping path (tests)
-    static const int help_after = [] { const char *e = getenv("FGNN_SCAN_HELP_AFTER"); return e ? atoi(e) : -1; }();
+    // fgnn_debug_set_scan_help_after(polls): 0 makes every wait that is not satisfied at once take the helping path
+    // (tests/test_coresidency_gpu.py)
+    const int help_after = scan_help_after_override();
     if (help_after >= 0) v.help_after = (uint32_t)help_after;
     v.helps = scan_help_counter();
     if (use_ticket) ws.ticket_base += (uint32_t)grid;  // wraps with the 32-bit device counter
@@ -584,63 +606,48 @@ struct ScanWsHost {
   }
 };
 
-// ---- khop2's cross-batch order chain, handed over on the DEVICE -------------------------------------------------
-// khop2 rewrites CSR rows in place (cuda_sampling_khop2.cu:74-83), so the sampler kernels of consecutive batches must
-// run in batch order however the batches overlap on their streams.  Ordering them with an event between two streams
-// costs 20-40 us per batch on this runtime (profiles/r03_ab1_priority_unordered.txt: sampler-side stage 0.094 ms per
-// batch ordered, 0.067 with the order dropped), more than the chain's own kernels.  Instead the LAST sampler launch of
-// batch b publishes b + 1 in a device word once all its workgroups have written their rows back, and the FIRST sampler
-// launch of batch b + 1 -- enqueued with no stream dependency on batch b -- polls that word right before its first
-// read of the CSR.  Forward progress: the host enqueues the waiting launch only after the publishing launch (and hence
-// everything the publisher depends on); hardware queues are in order, so no launch the publisher needs can sit behind
-// a waiter; waiters hold a few hundred wave slots at most.  A waiter that outlasts kChainTimeoutTicks marks the batch
-// invalid (`error`) and goes on -- it never hangs.
-constexpr int kChainGroups = 32;
-constexpr size_t kChainWords = 2 + kChainGroups;                  // flag | top | per-group arrival counters
-constexpr unsigned long long kChainTimeoutTicks = 300000000ull;   // 3 s of the 100 MHz wall clock
-struct ChainSync {
-  uint32_t *words;     // null: no hand-off (khop0, stateless entry points, event-ordered samplers)
-  uint32_t *error;     // batch summary's overflow word
-  uint32_t wait_for;   // do_wait: proceed once the published count has reached this (batches are numbered from 0)
-  uint32_t publish;    // do_publish: the count to publish when the whole grid is done (wait_for + 1)
-  uint32_t do_wait, do_publish;
+// ---- remap fix-up as a tail of another launch ---------------------------------------------------------------------
+// The entries of a layer's remapped edge list that ht_count_assign_kernel could not resolve (duplicates inside the fill:
+// pend|owner's item index) are resolved from the owner's own entry -- ht_map_fix_kernel's job, a few microseconds of
+// work that used to cost a launch per layer.  In the batch driver it rides along as extra workgroups of a launch that
+// follows anyway (the next fill's first dedup kernel, the cache split): `blocks` workgroups behind the host kernel's
+// own grid walk the list with a stride.  mapped == null: no tail.
+struct FixTail {
+  uint32_t *mapped;
+  const size_t *d_n;   // device count (null: n_host)
+  size_t n_host, cap;
+  uint32_t pend;       // the table's pending flag (HtView::pend)
+  uint32_t blocks;     // workgroups of kBlock threads appended to the host kernel's grid
 };
-
-// Cache discipline: the rows are ordinary memory in the per-XCD L2s, so the hand-off needs one L2 write-back per
-// publishing workgroup (after every wave's stores have reached the L2: s_waitcnt vmcnt(0) + barrier, then ONE lane's
-// agent-scope release fence) and one invalidate per waiting wave AFTER the wait (polls are relaxed loads).  A first
-// version that polled with acquire loads (an invalidate per poll) and fenced in every lane (four write-backs per
-// workgroup, 5 500 per launch) was correct but took the step from 0.119 to 0.198 ms
-// (profiles/r03_ab2_chain_flags_v1_fenced.txt).
-__device__ __forceinline__ void chain_wait(const ChainSync &c) {  // one lane per workgroup, a barrier behind it
-  const unsigned long long t0 = wall_clock64();
-  for (;;) {
-    const uint32_t v = __hip_atomic_load(&c.words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int32_t)(v - c.wait_for) >= 0) return;
-    __builtin_amdgcn_s_sleep(32);
-    if (wall_clock64() - t0 > kChainTimeoutTicks) {
-      if (c.error) atomicOr(c.error, 1u);
-      return;
+inline FixTail no_fix_tail() { return FixTail{nullptr, nullptr, 0, 0, 0, 0}; }
+// one hop, except after a resolving insert: the item pointed at may itself have lost the key later and then points on
+// (its entry may be mid-update by its own lane -- either state leads to the owner); every hop leads to a strictly
+// smaller item index (a key is only ever taken over by an earlier item), so the walk ends at the owner
+__device__ __forceinline__ void map_fix_item(uint32_t *mapped, uint32_t pend, size_t i) {
+  uint32_t m = mapped[i];
+  if ((m & pend) && m != FGNN_EMPTY_KEY) {
+    uint32_t at = (uint32_t)i;
+    while ((m & pend) && m != FGNN_EMPTY_KEY) {
+      const uint32_t j = m & (pend - 1u);
+      if (j >= at) break;  // cannot happen with consistent notes; never loop on garbage
+      at = j;
+      m = mapped[j];
     }
+    mapped[i] = m;
   }
 }
-
-// called by one lane of every workgroup that had a tile (tile <= last_tile), once the row stores of all its lanes have
-// completed (workgroup-scope release + barrier).  Two levels of counters: a single word would take (grid x ~30 ns) of
-// same-address atomics.
-__device__ __forceinline__ void chain_arrive(const ChainSync &c, uint32_t tile, uint32_t last_tile) {
-  const uint32_t g = tile % kChainGroups;
-  const uint32_t group_size = (last_tile - g) / kChainGroups + 1;  // tiles t <= last_tile with t % groups == g (g <= last_tile)
-  const uint32_t ngroups = last_tile + 1 < (uint32_t)kChainGroups ? last_tile + 1 : (uint32_t)kChainGroups;
-  uint32_t *sub = c.words + 2 + g;
-  if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != group_size) return;
-  __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next publishing launch
-  if (__hip_atomic_fetch_add(&c.words[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != ngroups) return;
-  __hip_atomic_store(&c.words[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&c.words[0], c.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// called by the workgroups blockIdx.x >= first_block of a host kernel launched with first_block + tail.blocks workgroups
+__device__ __forceinline__ void run_fix_tail(const FixTail &t, uint32_t first_block) {
+  size_t n = t.d_n ? *t.d_n : t.n_host;
+  if (n > t.cap) n = t.cap;
+  const size_t stride = (size_t)t.blocks * blockDim.x;
+  for (size_t i = (size_t)(blockIdx.x - first_block) * blockDim.x + threadIdx.x; i < n; i += stride)
+    map_fix_item(t.mapped, t.pend, i);
 }
-// a batch without a sampler launch (no seeds, or given up on an error) still takes its turn: wait, then publish
-int launch_chain_pass(const ChainSync &c, hipStream_t stream);  // sample_khop.hip
+inline uint32_t fix_tail_blocks(size_t cap) {
+  const size_t b = (cap + kBlock - 1) / kBlock;
+  return (uint32_t)(b < 512 ? b : 512);
+}
 
 struct ScanWsHost;
 // where the dedup's last pass leaves the sizes of the layer it just closed (all device pointers, nullable)
@@ -653,12 +660,13 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                  ScanWsHost *scan, bool final_fill = false, bool resolved = false,
-                                 bool *defer_fix = nullptr);
-// defer_fix (in: the caller would like to launch the remap fix-up itself, later; out: it has to): the fix-up only
-// rewrites `mapped` entries from other `mapped` entries -- nothing of the NEXT layer's sampling reads it, so a caller
-// with an order chain to keep short (khop2) launches it behind the next sampler kernel
-int hashtable_map_fix(const fgnn_hashtable *ht, size_t num_items, const size_t *d_num_items, size_t num_items_cap,
-                      uint32_t *mapped, void *stream);
+                                 FixTail *owed_fix = nullptr, const FixTail *carry_fix = nullptr);
+// owed_fix (non-null: the caller takes the remap fix-up of THIS fill over; filled in, mapped == null if none is owed):
+// the fix-up only rewrites `mapped` entries from other `mapped` entries -- nothing of the next layer's sampling reads
+// it, so the batch driver lets it ride on a later launch (FixTail) instead of giving it a launch of its own.
+// carry_fix (non-null, mapped != null): an EARLIER fill's owed fix-up; appended to this fill's insert launch when the
+// call launches one (already_inserted == false), launched on its own otherwise -- handled either way.
+int hashtable_map_fix(const FixTail &fix, void *stream);  // an owed fix-up as a launch of its own
 // can the last fill of `cap` items go through the resolving insert (disp[] allocated, one-launch count+assign)?
 bool hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts
@@ -682,10 +690,12 @@ int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const 
 // workgroups of a host-source gather on a GPU that also runs the sampling chain (see gather_rows_ex)
 constexpr size_t kSharedGpuHostGrid = 64;
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
+// carry_fix: an owed remap fix-up; rides on the one-launch split, launched on its own on the three-launch path
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,
                             uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts, void *ws, size_t ws_bytes,
-                            void *stream, ScanWsHost *scan, unsigned long long *stamp = nullptr);
+                            void *stream, ScanWsHost *scan, unsigned long long *stamp = nullptr,
+                            const FixTail *carry_fix = nullptr);
 // fgnn_sample_weighted_khop_hash_dedup with the slot's look-back descriptors (scan == null: descriptors in ws)
 int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
                       const uint32_t *alias_table, const uint32_t *input, size_t num_input, const uint32_t *d_num_input,
@@ -732,11 +742,11 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
                       void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start = nullptr,
-                      bool resolve = false, const ChainSync *chain = nullptr);
+                      bool resolve = false);
 int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                      void *stream, ScanWsHost *scan, const ChainSync *chain = nullptr);
+                      void *stream, ScanWsHost *scan);
 // resolve: the fill is the batch's last (hashtable_fill_duplicates_ex(..., final_fill, resolved = true) must follow):
 // ws[e] receives the insert's OUTCOME (ht_insert_resolve) instead of the bucket.  Needs ht->disp.
 

@@ -117,7 +117,11 @@ template <int IPT>
 __global__ __launch_bounds__(kBlock) void ht_insert_kernel(HtView t, const uint32_t *__restrict__ items, size_t n_host,
                                                            const size_t *d_n, size_t cap,
                                                            uint32_t *__restrict__ pos, uint32_t *d_num_items,
-                                                           uint32_t *disp) {
+                                                           uint32_t *disp, uint32_t own_blocks, FixTail fix) {
+  if (blockIdx.x >= own_blocks) {  // an earlier fill's remap fix-up riding along (FixTail, fgnn_device.h)
+    run_fix_tail(fix, own_blocks);
+    return;
+  }
   const size_t n = resolve_count64(n_host, d_n, cap);
   const size_t tile0 = (size_t)blockIdx.x * (kBlock * IPT);
   if (blockIdx.x == 0 && threadIdx.x == 0) d_num_items[1] = d_num_items[0];  // count before this fill
@@ -331,28 +335,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
 // the remap entries ht_count_assign_kernel could not resolve: duplicates inside the fill whose owner had not
 // been numbered yet.  The unresolved entry holds pend|owner's item index, and the owner's own remap entry (written
 // by the previous kernel) is its local id: one read of a small array instead of a 64 MiB table probe.
-__global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(HtView t, size_t n_host, const size_t *d_n, size_t cap,
-                                                            uint32_t *mapped) {
-  const size_t n = resolve_count64(n_host, d_n, cap);
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) {
-    uint32_t m = mapped[i];
-    if ((m & t.pend) && m != FGNN_EMPTY_KEY) {
-      // one hop, except after a resolving insert: the item pointed at may itself have lost the key later and then
-      // points on (its entry may be mid-update by its own lane -- either state leads to the owner)
-      // every hop leads to a strictly smaller item index (a key is only ever taken over by an earlier item), so the
-      // walk ends at the owner after at most as many hops as the key changed hands
-      uint32_t at = (uint32_t)i;
-      while ((m & t.pend) && m != FGNN_EMPTY_KEY) {
-        const uint32_t j = m & (t.pend - 1u);
-        if (j >= at) break;  // cannot happen with consistent notes; never loop on garbage
-        at = j;
-        m = mapped[j];
-      }
-      mapped[i] = m;
-    }
-  }
-}
+__global__ __launch_bounds__(kBlock) void ht_map_fix_kernel(FixTail fix) { run_fix_tail(fix, 0); }
 
 // pass 4: mapped[i] = local id of items[i] (bucket known)
 template <int IPT>
@@ -541,25 +524,23 @@ static size_t count_assign_grid(size_t cap, const fgnn::ScanWsHost *scan) {
 }
 
 bool fgnn::hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap) {
-  static const bool enabled = [] {  // A/B switch (tools/ab_env.sh), read once
-    const char *e = getenv("FGNN_HT_RESOLVE");
-    return !(e && atoi(e) == 0);
-  }();
+  static const bool enabled = tune_int("FGNN_HT_RESOLVE", 1) != 0;  // A/B switch, profiling build only
   return enabled && ht && ht->disp && ht->scan && cap > 0 && cap <= ht->max_fill_items && count_assign_grid(cap, ht->scan) > 0;
 }
 
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
-                                       ScanWsHost *scan, bool final_fill, bool resolved, bool *defer_fix) {
+                                       ScanWsHost *scan, bool final_fill, bool resolved, FixTail *owed_fix,
+                                       const FixTail *carry_fix) {
   if (!ht) return FGNN_EINVAL;
-  const bool want_defer = defer_fix && *defer_fix;
-  if (defer_fix) *defer_fix = false;  // true on return: the caller owes a hashtable_map_fix() launch
+  if (owed_fix) *owed_fix = no_fix_tail();  // mapped != null on return: the caller owes this fill's fix-up
+  FixTail carry = carry_fix && carry_fix->mapped ? *carry_fix : no_fix_tail();
   // resolved: pos[] holds insert outcomes (sample_khop_fused(..., resolve = true)); only the one-launch path reads them
   if (resolved && !(already_inserted && final_fill && mapped && ht->disp)) return FGNN_EINVAL;
   if (!scan) scan = ht->scan;  // hashtable_can_resolve looks at ht->scan: the descriptors used must be those
   size_t cap = d_num_items ? num_items_cap : num_items;
-  if (cap == 0) return FGNN_OK;
+  if (cap == 0) return carry.mapped ? hashtable_map_fix(carry, stream) : FGNN_OK;
   if (!items || cap > ht->max_fill_items) return FGNN_EINVAL;  // pending indices must fit the value field
   auto s = static_cast<hipStream_t>(stream);
   const HtView tv = ht_view(ht);
@@ -580,22 +561,29 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   if (!already_inserted) {
     // the last fill of a batch done here (samplers that do not insert themselves) resolves too
     resolved = final_fill && mapped && scan == ht->scan && hashtable_can_resolve(ht, cap);
-    FGNN_HT(ht_insert_kernel, tv, items, num_items, d_num_items, cap, pos, ht->d_num_items,
-            resolved ? ht->disp : static_cast<uint32_t *>(nullptr));
+    uint32_t *const disp = resolved ? ht->disp : nullptr;
+    const unsigned grid = (unsigned)(nb + carry.blocks);
+    if (ipt == 1)
+      hipLaunchKernelGGL((ht_insert_kernel<1>), dim3(grid), dim3(kBlock), 0, s, tv, items, num_items, d_num_items, cap,
+                         pos, ht->d_num_items, disp, (uint32_t)nb, carry);
+    else
+      hipLaunchKernelGGL((ht_insert_kernel<kItemsPerThread>), dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
+                         d_num_items, cap, pos, ht->d_num_items, disp, (uint32_t)nb, carry);
+  } else if (carry.mapped) {
+    const int rc = hashtable_map_fix(carry, stream);
+    if (rc != FGNN_OK) return rc;
   }
   if (!scan) scan = ht->scan;
   if (scan) {
-    const size_t nb1 = div_up(cap, (size_t)kBlock);
     const size_t grid = count_assign_grid(cap, scan);
     if (grid > 0) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
                          scan->next(1, grid), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
-      if (mapped && want_defer) {
-        *defer_fix = true;
-      } else if (mapped) {
-        hipLaunchKernelGGL(ht_map_fix_kernel, dim3(nb1), dim3(kBlock), 0, s, tv, num_items, d_num_items, cap,
-                           mapped);
+      if (mapped) {
+        const FixTail fix{mapped, d_num_items, num_items, cap, tv.pend, fix_tail_blocks(cap)};
+        if (owed_fix) *owed_fix = fix;
+        else return hashtable_map_fix(fix, stream);
       }
       return launch_status(__func__);
     }
@@ -613,12 +601,9 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   return launch_status(__func__);
 }
 
-int fgnn::hashtable_map_fix(const fgnn_hashtable *ht, size_t num_items, const size_t *d_num_items, size_t num_items_cap,
-                            uint32_t *mapped, void *stream) {
-  const size_t cap = d_num_items ? num_items_cap : num_items;
-  if (!ht || !mapped || cap == 0) return FGNN_EINVAL;
-  hipLaunchKernelGGL(ht_map_fix_kernel, dim3(div_up(cap, (size_t)kBlock)), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), ht_view(ht), num_items, d_num_items, cap, mapped);
+int fgnn::hashtable_map_fix(const FixTail &fix, void *stream) {
+  if (!fix.mapped || fix.blocks == 0) return FGNN_EINVAL;
+  hipLaunchKernelGGL(ht_map_fix_kernel, dim3(fix.blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), fix);
   return launch_status(__func__);
 }
 

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ block_offsets,
                                                         uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                         int src_mode, uint64_t seed, uint64_t batch_key,
-                                                        uint32_t tag, FuseArgs fuse, uint32_t ablate, ScanWs scan,
-                                                        size_t *d_num_out, ChainSync chain, HubSplit hub) {
+                                                        uint32_t tag, FuseArgs fuse, ScanWs scan, size_t *d_num_out,
+                                                        HubSplit hub FGNN_ABLATE_PARAM) {
   constexpr int NW = T / kWave;
   static_assert(T >= S && T % kWave == 0, "threads per workgroup");
   extern __shared__ uint32_t dyn[];
@@ -379,14 +379,7 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
       }
     }
   }
-  // khop2's batch order, handed over on the device (fgnn_device.h, ChainSync): everything above reads immutable
-  // inputs only; the rows themselves are first read below
-  const bool chain_reads = KHOP2 && chain.words && chain.do_wait;
-  const bool chain_writes = KHOP2 && chain.words && chain.do_publish;
-  if (chain_reads && tid == 0) chain_wait(chain);  // relaxed polls: no cache maintenance while waiting
   __syncthreads();
-  // ONE acquire per wave once the wait is over: rows cached before the predecessor's write-back are dropped
-  if (chain_reads) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   phase_mark(scan, tile, 1);
 
   // ---- phase B: one lane per output edge, 4 edges per lane in flight ---------------------------
@@ -482,19 +475,6 @@ __global__ __launch_bounds__(T) void khop_sample_kernel(const uint32_t *__restri
     }
   }
   phase_mark(scan, tile, 4);
-  if (chain_writes) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores have reached the L2 of its XCD ...
-    __syncthreads();                     // ... and so have those of every wave of the workgroup (one CU, one L2)
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // ONE write-back of that L2 per workgroup, then arrive
-      chain_arrive(chain, tile, last_tile);
-    }
-  }
-}
-
-__global__ void chain_pass_kernel(ChainSync chain) {
-  if (chain.do_wait) chain_wait(chain);
-  if (chain.do_publish) __hip_atomic_store(&chain.words[0], chain.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool KHOP2>
@@ -502,14 +482,12 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
                 const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                 size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws,
                 size_t ws_bytes, hipStream_t stream, fgnn_hashtable *fuse_ht = nullptr,
-                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr, bool resolve = false,
-                const ChainSync *chain_in = nullptr) {
+                ScanWsHost *scan_host = nullptr, const BatchStart *start = nullptr, bool resolve = false) {
   if (fanout == 0 || fanout > 0x7fffffffu) return FGNN_EINVAL;
   if (!d_num_input) cap = num_input;
-  const ChainSync chain = chain_in ? *chain_in : ChainSync{nullptr, nullptr, 0, 0, 0, 0};
   if (cap == 0) {
     if (d_num_out) FGNN_HIP_CHECK(hipMemsetAsync(d_num_out, 0, sizeof(size_t), stream));
-    return chain.words ? launch_chain_pass(chain, stream) : FGNN_OK;  // no launch: the batch still takes its turn
+    return FGNN_OK;
   }
   if (cap > 0xffffffffull) return FGNN_EINVAL;
   const uint32_t F = (uint32_t)fanout;
@@ -519,14 +497,13 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
   // small workgroups for small frontiers: the kernel is latency-bound, more resident waves hide more of it
   int S = 256;
   while (S > 64 && (words_per_seed * S * 4 > 120 * 1024 || cap / S < 2048)) S >>= 1;
-  if (const char *e_s = getenv("FGNN_KHOP_S")) {  // tuning knob (profiles/ sweeps only)
-    const int v = atoi(e_s);
+  if (const int v = tune_int("FGNN_KHOP_S", 0))  // profiling build only
     if (v == 64 || v == 128 || v == 256) S = v;
-  }
   if (words_per_seed * S * 4 > 150 * 1024) return FGNN_EINVAL;  // fanout > ~200 (khop2) unsupported
   const size_t nb = div_up(cap, (size_t)S);
-  const char *e_ab = getenv("FGNN_KHOP_ABLATE");  // profiling only (tools/khop_ablate.py); results are wrong when set
-  const uint32_t ablate = e_ab ? (uint32_t)atoi(e_ab) : 0u;
+#ifdef FGNN_PROFILING
+  const uint32_t ablate = (uint32_t)tune_int("FGNN_KHOP_ABLATE", 0);  // tools/khop_ablate.py; results are wrong when set
+#endif
   FuseArgs fuse{HtView{nullptr, 0, 0, 1, 0, 0}, nullptr, nullptr, nullptr,
                 BatchStart{nullptr, nullptr, nullptr, 0, 0, 0}};
   uint32_t *sums = static_cast<uint32_t *>(ws);
@@ -599,7 +576,7 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
     }                                                                                                          \
     hipLaunchKernelGGL((khop_sample_kernel<SS, 256, KHOP2, FM>), dim3(nb), dim3(256), lds, stream, indptr, indices, \
                        input, num_input, d_num_input, cap, F, sums, out_src, out_dst, src_mode, seed,          \
-                       batch_key, tag, fuse, ablate, scan, d_num_out, chain, hub);                             \
+                       batch_key, tag, fuse, scan, d_num_out, hub FGNN_ABLATE_ARG(ablate));                    \
   } while (0)
 #define FGNN_LAUNCH_KHOP(SS)                                                                                   \
   do {                                                                                                         \
@@ -620,23 +597,16 @@ int launch_khop(const uint32_t *indptr, uint32_t *indices, const uint32_t *input
 
 }  // namespace
 
-int launch_chain_pass(const ChainSync &c, hipStream_t stream) {
-  if (!c.words) return FGNN_OK;
-  hipLaunchKernelGGL(chain_pass_kernel, dim3(1), dim3(1), 0, stream, c);
-  return launch_status(__func__);
-}
-
 int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, fgnn_hashtable *ht,
-                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start, bool resolve,
-                      const ChainSync *chain) {
+                      void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan, const BatchStart *start, bool resolve) {
   if (!ht) return FGNN_EINVAL;
   if (start && (d_num_input || !start->n2o)) return FGNN_EINVAL;  // the first launch takes the seeds with a host count
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                    d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
-                                   resolve, chain)
+                                   resolve)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                     d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, ht, scan, start,
                                     resolve);
@@ -647,11 +617,10 @@ int sample_khop_fused(bool khop2, const uint32_t *indptr, uint32_t *indices, con
 int sample_khop_plain(bool khop2, const uint32_t *indptr, uint32_t *indices, const uint32_t *input, size_t num_input,
                       const uint32_t *d_num_input, size_t cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst,
                       size_t *d_num_out, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                      void *stream, ScanWsHost *scan, const ChainSync *chain) {
+                      void *stream, ScanWsHost *scan) {
   auto st = static_cast<hipStream_t>(stream);
   return khop2 ? launch_khop<true>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
-                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan,
-                                   nullptr, false, chain)
+                                   d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan)
                : launch_khop<false>(indptr, indices, input, num_input, d_num_input, cap, fanout, out_src, out_dst,
                                     d_num_out, FGNN_SRC_LOCAL, seed, batch_key, layer, ws, ws_bytes, st, nullptr, scan);
 }

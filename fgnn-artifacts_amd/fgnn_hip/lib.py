@@ -11,7 +11,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip.so")
+# FGNN_HIP_LIB: another build of the library -- tools/ use lib/libfgnn_hip_prof.so (`make -C csrc prof`), the only build
+# whose kernels read A/B switches and ablation masks from the environment
+LIB_PATH = os.environ.get("FGNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip.so")
 
 SRC_GLOBAL, SRC_LOCAL = 0, 1
 EMPTY = 0xFFFFFFFF
@@ -20,7 +22,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
          torch.int8: I8, torch.int64: I64}
 
 EXPORTS = [
-    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_debug_set_scan_help_after", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
@@ -66,6 +68,12 @@ def load():
         L.fgnn_hashtable_n2o.argtypes = [C.c_void_p]
         L.fgnn_hashtable_d_num_items.restype = C.c_void_p
         L.fgnn_hashtable_d_num_items.argtypes = [C.c_void_p]
+        L.fgnn_debug_set_scan_help_after.restype = None
+        L.fgnn_debug_set_scan_help_after.argtypes = [C.c_int]
+        # tests force the helping path of the single-pass kernels for a whole process (tests/test_coresidency_gpu.py);
+        # the library itself reads nothing from the environment
+        if os.environ.get("FGNN_SCAN_HELP_AFTER") is not None:
+            L.fgnn_debug_set_scan_help_after(int(os.environ["FGNN_SCAN_HELP_AFTER"]))
         _lib = L
     return _lib
 
@@ -423,6 +431,7 @@ EXPORTS += [
     "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta", "fgnn_batch_host_meta", "fgnn_batch_meta_copied",
+    "fgnn_sampler_run_range",
 ]
 
 
@@ -432,6 +441,13 @@ class SamplerConfig(C.Structure):
                 ("fanout", C.c_size_t * MAX_LAYERS), ("max_batch_size", C.c_size_t), ("seed", C.c_uint64),
                 ("walk_len", C.c_size_t), ("num_walks", C.c_size_t), ("restart_prob", C.c_double),
                 ("prob_table", C.c_void_p), ("alias_table", C.c_void_p)]
+
+
+class RunPlan(C.Structure):
+    _fields_ = [("d_train", C.c_void_p), ("num_train", C.c_size_t), ("batch_size", C.c_size_t),
+                ("batches", C.c_void_p), ("num_batches", C.c_size_t), ("streams", C.c_void_p),
+                ("num_streams", C.c_size_t), ("cache_table", C.c_void_p), ("feat", C.c_void_p), ("label", C.c_void_p),
+                ("cached", C.c_int), ("cache_rows", C.c_void_p), ("full_feat", C.c_void_p)]
 
 
 class BatchMeta(C.Structure):
@@ -528,6 +544,38 @@ class Sampler:
                                              C.c_uint64(batch_key), batch.h, _ptr(cache_table), _ptr(feat),
                                              _ptr(label), st), "fgnn_sampler_run_batch")
 
+
+    def run_range(self, first_seq, count, train, batch_size, batches, streams, cache_table=None, feat=None, label=None,
+                  cache_rows=None, full_feat=None, cached=False):
+        """fgnn_sampler_run_range: batches first_seq .. first_seq+count-1 enqueued and collected by ONE native call (the
+        reference's C++ loop thread, cuda_loops_arch1.cc:38-84).  Returns (metas, times, host_enqueue_seconds); times[i]
+        = (ms, ms) HIP-event times of batch i, -1 where not timed.  Raises on a flagged batch."""
+        _need_gpu(train)
+        L = load()
+        plan = RunPlan()
+        plan.d_train, plan.num_train, plan.batch_size = train.data_ptr(), train.numel(), batch_size
+        arr_b = (C.c_void_p * len(batches))(*[b.h for b in batches])
+        arr_s = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
+        plan.batches, plan.num_batches = C.cast(arr_b, C.c_void_p), len(batches)
+        plan.streams, plan.num_streams = C.cast(arr_s, C.c_void_p), len(streams)
+        plan.cache_table = cache_table.data_ptr() if cache_table is not None else None
+        plan.feat = feat.data_ptr() if feat is not None else None
+        plan.label = label.data_ptr() if label is not None else None
+        plan.cached = 1 if cached else 0
+        plan.cache_rows = cache_rows.data_ptr() if cache_rows is not None else None
+        plan.full_feat = full_feat.data_ptr() if full_feat is not None else None
+        metas = (BatchMeta * max(count, 1))()
+        times = (C.c_float * (2 * max(count, 1)))()
+        busy = C.c_double(0.0)
+        _check(L.fgnn_sampler_run_range(self.h, C.byref(plan), C.c_uint64(first_seq), C.c_size_t(count), metas, times,
+                                        C.byref(busy)), "fgnn_sampler_run_range")
+        out = [metas[i] for i in range(count)]
+        for m in out:
+            if m.overflow:
+                raise FgnnError(f"batch {m.key} is invalid (overflow flag {m.overflow})")
+        for i in range(max(0, count - len(batches)), count):  # the buffers hold the last batches: views stay usable
+            batches[(first_seq + i) % len(batches)].meta = out[i]
+        return out, [(times[2 * i], times[2 * i + 1]) for i in range(count)], busy.value
 
     def run_batch_cached(self, seq, seeds, batch_key, batch, cache_table, cache_rows, full_feat, label=None,
                          stream=None):

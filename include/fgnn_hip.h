@@ -58,6 +58,10 @@ int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream);
 /* Diagnostics: how many tile aggregates of the single-pass kernels were recomputed by a waiting workgroup instead of
  * being read from the tile itself (current device, since the process started; synchronises).  0 on an idle GPU. */
 unsigned long long fgnn_debug_scan_helps(void);
+/* Diagnostics (tests): polls of one look-back descriptor before a waiting workgroup starts recomputing the missing
+ * aggregate itself; 0 forces the helping path on every wait not satisfied at once, a negative value restores the
+ * default.  Affects launches made after the call.  (The library reads no switch from the environment.) */
+void fgnn_debug_set_scan_help_after(int polls);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);
@@ -323,7 +327,7 @@ int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_see
                         fgnn_batch *out, void *stream);
 /* Thread-safe, explicitly ordered variant for overlapping batches: `seq` = 0,1,2,... is the batch's position
  * in the run; calls may come from several host threads (one per stream) in any timing, the library makes
- * khop2's in-place CSR swaps happen in `seq` order and keeps at most 4 batches in flight.  fgnn_sampler_sample
+ * khop2's in-place CSR swaps happen in `seq` order and keeps at most 6 batches in flight.  fgnn_sampler_sample
  * is this with an internal counter (do not mix the two on one sampler). */
 int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                                 uint64_t batch_key, fgnn_batch *out, void *stream);
@@ -331,6 +335,31 @@ int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d
 int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                            uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table, const void *feat,
                            const void *label, void *stream);
+/* The batch loop of a GPU that samples and extracts, as ONE native call per range of batches (the reference runs this
+ * loop in C++ threads: RunSampleCopySubLoopOnce, cuda_loops_arch1.cc:38-84; per batch: the next batch_size ids of the
+ * shuffled train set -> DoGPUSample -> DoGetCacheMissIndex -> DoGPUFeatureExtract -> Submit).  Batch i (= its `seq`)
+ * takes step i % steps_per_epoch of d_train (the last step of an epoch is short), batch_key = that step, output buffer
+ * batches[i % num_batches], stream streams[i % num_streams]: whole batches overlap on the GPU, khop2's CSR swaps stay
+ * in batch order.  cached == 0: fgnn_sampler_run_batch(cache_table, feat, label); cached != 0:
+ * fgnn_sampler_run_batch_cached(cache_table, cache_rows, full_feat, label).  The call returns when every batch of the
+ * range has finished: h_metas[count] receives the summaries in order, h_gather_ms (NULL or float[count][2]) the
+ * HIP-event times of the batches whose buffers have timing enabled ({gather, -1} or {miss gather, cached gather}; -1
+ * where not timed), *h_enqueue_s (NULL ok) the host time spent enqueueing. Sequence numbers must continue those of
+ * earlier calls on the sampler.  num_streams of 1, 2, 3 or 6 needs no event between a slot's uses. */
+typedef struct {
+  const uint32_t *d_train;
+  size_t num_train, batch_size;
+  fgnn_batch **batches;
+  size_t num_batches;
+  void **streams;
+  size_t num_streams;
+  const uint32_t *cache_table;
+  const void *feat, *label;
+  int cached;
+  const void *cache_rows, *full_feat;
+} fgnn_run_plan;
+int fgnn_sampler_run_range(fgnn_sampler *s, const fgnn_run_plan *plan, uint64_t first_seq, size_t count,
+                           fgnn_batch_meta *h_metas, float *h_gather_ms, double *h_enqueue_s);
 /* DoGetCacheMissIndex on input_nodes against a direct-map table u32[num_node]. */
 int fgnn_batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream);
 /* DoGPUFeatureExtract: feat_out[i,:] = feat[input_nodes[i],:], label_out[i] = label[output_nodes[i]].

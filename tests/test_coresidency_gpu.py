@@ -7,7 +7,8 @@ workgroup terminates whatever else is on the GPU.  Two tests:
   * hostile co-residency: three streams of overlapping batches plus a foreign kernel that parks itself on 3/4 of the
     chip's wave slots for 1.5 ms at a time, 2 000 batches -- no batch flagged, every batch bit-identical to the same
     batches run one at a time on an idle GPU (which the parity tests compare with the oracle);
-  * the helping path itself, forced: FGNN_SCAN_HELP_AFTER=0 makes every wait that is not satisfied by its first poll
+  * the helping path itself, forced: fgnn_debug_set_scan_help_after(0) (lib.py calls it when FGNN_SCAN_HELP_AFTER=0 is in
+    the environment; the library itself reads no variable) makes every wait that is not satisfied by its first poll
     recompute, and the batch-driver parity tests (oracle, bit-exact) plus the run above must still hold, with the
     help counter showing that the path ran.
 The reference never loses a batch (cuda_loops.cc:50-267)."""
@@ -40,23 +41,15 @@ def _digest(bt, m, num_layers):
     return tuple(head) + (int((flat * (w * 0x9E3779B1 + 7)).sum().item()),)
 
 
-def _run(hip, indptr, indices, table, train, fanouts, bs, n_streams, tenant, env=None, num_batches=None):
+def _run(hip, indptr, indices, table, train, fanouts, bs, n_streams, tenant, num_batches=None):
     dev = indptr.device
     d_indices = indices.clone()  # khop2 swaps entries in place: every run starts from the same CSR
-    saved = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})  # the batch driver reads its switches when a sampler is created
-    try:
-        sampler = hip.Sampler(indptr, d_indices, fanouts, bs, sample_type=hip.KHOP2, seed=SEED)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    sampler = hip.Sampler(indptr, d_indices, fanouts, bs, sample_type=hip.KHOP2, seed=SEED)
     NUM_BATCHES = num_batches or globals()["NUM_BATCHES"]
     nbuf = 2 * n_streams
     batches = [sampler.new_batch(0, hip.F32, hip.I64) for _ in range(nbuf)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    torch.cuda.synchronize()  # the CSR copy above ran on the default stream; the batch streams do not wait for it
     steps = train.numel() // bs
     stop = threading.Event()
     launched = [0]
@@ -131,15 +124,39 @@ def test_single_pass_kernels_under_coresidency():
         assert helps > 1000, "the helping path was not exercised"
 
 
-@pytest.mark.parametrize("env", [{"FGNN_CHAIN_FLAGS": "1"}, {"FGNN_CHAIN_PRIORITY": "3"},
-                                 {"FGNN_CHAIN_PRIORITY": "3", "FGNN_CHAIN_SEEDS_READY": "1"}, {"FGNN_CHAIN_PRIORITY": "1"}])
-def test_alternative_batch_orderings_are_identical(env):
-    """khop2's cross-batch order (in-place CSR swaps, cuda_sampling_khop2.cu:74-83) kept by other means than the default
-    event between consecutive batches' streams -- the device-side hand-off (FGNN_CHAIN_FLAGS=1: the last sampler launch
-    of a batch publishes, the first of the next one polls), one stream for the order chain of all batches
-    (FGNN_CHAIN_PRIORITY=3), high-priority chain streams (=1): 500 overlapping batches on three streams must equal the
-    same batches one at a time, digest by digest, and leave the same CSR.  (Measured and not the default:
-    profiles/r03_*.)"""
+def _run_range(hip, indptr, indices, table, train, fanouts, bs, n_streams, num_batches, chunk):
+    """the same batches through fgnn_sampler_run_range (the native batch loop), `chunk` batches per call"""
+    dev = indptr.device
+    d_indices = indices.clone()
+    sampler = hip.Sampler(indptr, d_indices, fanouts, bs, sample_type=hip.KHOP2, seed=SEED)
+    nbuf = 2 * n_streams
+    batches = [sampler.new_batch(0, hip.F32, hip.I64) for _ in range(nbuf)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    torch.cuda.synchronize()  # (the CSR copy ran on the default stream)
+    nt = train.numel() // bs * bs  # whole steps only, like _run
+    digests = []
+    for first in range(0, num_batches, chunk):
+        n = min(chunk, num_batches - first)
+        # a range's summaries come back together; the buffers hold its last `nbuf` batches
+        metas, _, busy = sampler.run_range(first, n, train[:nt], bs, batches, streams, cache_table=table)
+        assert busy > 0 and len(metas) == n
+        for i in range(max(0, n - nbuf), n):
+            bt = batches[(first + i) % nbuf]
+            digests.append((first + i, _digest(bt, metas[i], len(fanouts))))
+        for i, m in enumerate(metas):
+            assert int(m.key) == (first + i) % (nt // bs)
+    torch.cuda.synchronize()
+    return dict(digests), d_indices
+
+
+@pytest.mark.parametrize("n_streams", [1, 2, 3, 4, 5, 6])
+def test_any_number_of_streams_gives_the_serial_result(n_streams):
+    """khop2's cross-batch order (in-place CSR swaps, cuda_sampling_khop2.cu:74-83) and the reuse of the sampler's six
+    slots are ordered by the stream where a slot (a predecessor) comes back on the stream it ran on, by events where it
+    does not -- events that are only recorded once a batch has needed one (engine.hip, cross_slot / cross_csr).  1, 2, 3
+    and 6 streams never need a slot event, 4 and 5 do; every count above 1 needs the CSR event.  400 overlapping batches
+    must equal the same batches on one stream, digest by digest, and leave the same CSR -- through the per-batch call
+    from Python and through the native batch loop (fgnn_sampler_run_range) in ranges of 1, 7 and 64 batches."""
     from fgnn_hip import lib as hip, rmat
     hip.load()
     dev = torch.device("cuda", 0)
@@ -148,11 +165,22 @@ def test_alternative_batch_orderings_are_identical(env):
     indptr, indices, _ = rmat.rmat_csr(num_node, num_edge, 42, dev)
     train = rmat.train_set(num_node, 100_000, 1, dev)
     table = torch.full((num_node,), -1, dtype=torch.int32, device=dev)
-    serial, csr_serial, _ = _run(hip, indptr, indices, table, train, fanouts, bs, 1, False, num_batches=500)
-    other, csr_other, _ = _run(hip, indptr, indices, table, train, fanouts, bs, 3, False, env=env, num_batches=500)
+    table[::3] = torch.arange((num_node + 2) // 3, device=dev, dtype=torch.int32)
+    nb = 400
+    serial, csr_serial, _ = _run(hip, indptr, indices, table, train, fanouts, bs, 1, False, num_batches=nb)
+    other, csr_other, _ = _run(hip, indptr, indices, table, train, fanouts, bs, n_streams, False, num_batches=nb)
+    # _run numbers the batch keys 0, 1, 2, ... while the native loop uses the step inside the epoch: compare the native
+    # loop with itself on one stream, and the Python loop with itself
     bad = [i for i, (a, b) in enumerate(zip(serial, other)) if a != b]
-    assert not bad, "batches %s differ under %s" % (bad[:10], env)
+    assert not bad, "batches %s differ with %d streams" % (bad[:10], n_streams)
     assert torch.equal(csr_serial, csr_other)
+    ref, csr_ref = _run_range(hip, indptr, indices, table, train, fanouts, bs, 1, nb, 1)  # every batch digested
+    assert len(ref) == nb
+    for chunk in (1, 7, 64):
+        got, csr_got = _run_range(hip, indptr, indices, table, train, fanouts, bs, n_streams, nb, chunk)
+        bad = [i for i in got if got[i] != ref.get(i, got[i])]
+        assert not bad, "native loop: batches %s differ with %d streams, ranges of %d" % (bad[:10], n_streams, chunk)
+        assert torch.equal(csr_ref, csr_got)
 
 
 def test_helping_path_is_exact():
