@@ -8,7 +8,7 @@
 
 #include "fgnn_hip.h"
 
-namespace fgnn { struct ScanWsHost; }
+namespace fgnn { struct ScanWsHost; struct PartWs; }
 
 // OrderedHashTable state (hashtable.hip); the samplers insert into it directly (fused path)
 struct fgnn_hashtable {
@@ -30,6 +30,8 @@ struct fgnn_hashtable {
   // that item i took the key over from pending item j.  Generation-tagged like the buckets, zeroed with the table's
   // wipe.  Only allocated for tables made with a modest max_fill_items (the batch driver's); null otherwise.
   uint32_t *disp;
+  // the batch's last fill, hash-partitioned and deduplicated in LDS (hashtable_partition.hip); null: not available
+  fgnn::PartWs *part;
 };
 
 namespace fgnn {
@@ -667,6 +669,17 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
 // carry_fix (non-null, mapped != null): an EARLIER fill's owed fix-up; appended to this fill's insert launch when the
 // call launches one (already_inserted == false), launched on its own otherwise -- handled either way.
 int hashtable_map_fix(const FixTail &fix, void *stream);  // an owed fix-up as a launch of its own
+// hashtable_partition.hip: pass 1 of a batch's LAST fill without the global table -- keys partitioned by hash, every
+// bin deduplicated by one workgroup in LDS; pos[i] receives the exact outcome of item i (kPartIsOwner: first occurrence,
+// pend|j: duplicate of item j, else the local id the node already had).  Also sets d_num_items[1] like every pass 1.
+// pos[i] == kPartIsOwner stands for pend|i (item i is a first occurrence: the common case is marked in item order by the
+// scatter pass, only the others are scattered by the dedup pass)
+constexpr uint32_t kPartIsOwner = 0xFFFFFFFEu;
+PartWs *partition_create(size_t max_items, size_t max_fill_items);
+void partition_destroy(PartWs *w);
+bool partition_fits(const PartWs *w, const fgnn_hashtable *ht, size_t cap);
+int partition_fill(PartWs *w, const fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
+                   const size_t *d_num_items, size_t cap, uint32_t *pos, hipStream_t s, const FixTail &carry);
 // can the last fill of `cap` items go through the resolving insert (disp[] allocated, one-launch count+assign)?
 bool hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap);
 // Reset as the batch driver uses it: generation bump (wipe only on wrap), optionally without touching the counts

@@ -215,9 +215,11 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
                                                                  uint32_t *d_num_items, uint32_t *__restrict__ n2o,
                                                                  size_t max_items, LayerSummary summary,
                                                                  uint32_t *mapped, ScanWs scan, bool final_fill,
-                                                                 const uint32_t *__restrict__ disp) {
+                                                                 const uint32_t *__restrict__ disp, bool exact) {
   // disp != null (implies final_fill): pos[] holds the OUTCOMES of a resolving insert (fgnn_device.h), not buckets --
-  // the value the bucket read below would have returned, up to take-overs noted in disp[]: no table access at all
+  // the value the bucket read below would have returned, up to take-overs noted in disp[]: no table access at all.
+  // exact (implies final_fill, disp == null): pos[] holds the FINAL outcomes (the partitioned fill,
+  // hashtable_partition.hip): nothing to look up anywhere
   __shared__ uint32_t sh[kWavesPerBlock];
   __shared__ uint32_t sh_tile[2];
   const uint32_t n = (uint32_t)resolve_count64(n_host, d_n, cap);  // cap < 2^31 (host check)
@@ -245,7 +247,14 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
         ok[u] = r0 + u < rounds && i < n;
         bk[u] = ok[u] ? pos[i] : kNoBucket;
       }
-      if (disp) {
+      if (exact) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
+          v[u] = !ok[u] ? FGNN_EMPTY_KEY : bk[u] == kPartIsOwner ? (t.pend | (uint32_t)i) : bk[u];
+          bk[u] = 0;  // "has a bucket"
+        }
+      } else if (disp) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
@@ -408,6 +417,7 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max
   ht->gen = 0;
   ht->max_fill_items = max_fill_items;
   ht->disp = nullptr;
+  ht->part = nullptr;
   ht->scan = new ScanWsHost();
   if (ht->scan->create(4096) != FGNN_OK ||
       hipMalloc(&ht->table, cap * sizeof(unsigned long long)) != hipSuccess ||
@@ -425,6 +435,9 @@ extern "C" fgnn_hashtable *fgnn_hashtable_create_ex(size_t max_items, size_t max
       fgnn_hashtable_destroy(ht);
       return fail(FGNN_EHIP);
     }
+    // null: the last fill goes through the global table too (FGNN_HT_PARTITION=0: A/B switch of the profiling build,
+    // read per table so that one process can hold both kinds)
+    if (tune_int("FGNN_HT_PARTITION", 1) != 0) ht->part = partition_create(max_items, max_fill_items);
   }
   if (h_err) *h_err = FGNN_OK;
   return ht;
@@ -452,6 +465,7 @@ extern "C" void fgnn_hashtable_destroy(fgnn_hashtable *ht) {
   if (ht->n2o_owned) (void)hipFree(ht->n2o_owned);
   if (ht->d_num_items) (void)hipFree(ht->d_num_items);
   if (ht->disp) (void)hipFree(ht->disp);
+  partition_destroy(ht->part);
   if (ht->scan) {
     ht->scan->destroy();
     delete ht->scan;
@@ -558,7 +572,14 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     else hipLaunchKernelGGL((KERNEL<kItemsPerThread>), dim3(nb), dim3(kBlock), 0, s, __VA_ARGS__); \
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
-  if (!already_inserted) {
+  bool exact = false;
+  if (!already_inserted && final_fill && mapped && scan == ht->scan && partition_fits(ht->part, ht, cap) &&
+      count_assign_grid(cap, scan) > 0) {
+    // the batch's last fill: partitioned by hash, deduplicated in LDS, the global table untouched
+    const int rc = partition_fill(ht->part, ht, items, num_items, d_num_items, cap, pos, s, carry);
+    if (rc != FGNN_OK) return rc;
+    exact = true;
+  } else if (!already_inserted) {
     // the last fill of a batch done here (samplers that do not insert themselves) resolves too
     resolved = final_fill && mapped && scan == ht->scan && hashtable_can_resolve(ht, cap);
     uint32_t *const disp = resolved ? ht->disp : nullptr;
@@ -579,7 +600,8 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > 0) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(1, grid), final_fill && mapped != nullptr, resolved ? ht->disp : nullptr);
+                         scan->next(1, grid), final_fill && mapped != nullptr,
+                         resolved && !exact ? ht->disp : nullptr, exact);
       if (mapped) {
         const FixTail fix{mapped, d_num_items, num_items, cap, tv.pend, fix_tail_blocks(cap)};
         if (owed_fix) *owed_fix = fix;
@@ -588,7 +610,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
       return launch_status(__func__);
     }
   }
-  if (resolved) return FGNN_EINVAL;  // the caller checks can_resolve() before it asks the sampler for outcomes
+  if (resolved || exact) return FGNN_EINVAL;  // (both paths made sure of the one-launch grid before they started)
   // d_num_items[1] keeps the old count (set by the count kernel) for pass 3; d_num_items[0] advances in the scan
   FGNN_HT(ht_count_kernel, tv, num_items, d_num_items, cap, pos, sums, ht->d_num_items);
   if (launch_scan_block_sums(sums, nb, nullptr, nullptr, ht->d_num_items + 1, ht->d_num_items, s, nullptr,

@@ -62,6 +62,10 @@ unsigned long long fgnn_debug_scan_helps(void);
  * aggregate itself; 0 forces the helping path on every wait not satisfied at once, a negative value restores the
  * default.  Affects launches made after the call.  (The library reads no switch from the environment.) */
 void fgnn_debug_set_scan_help_after(int polls);
+/* Diagnostics (tests): distinct keys one bin of the partitioned last fill (hashtable_partition.hip) may hold in its LDS
+ * table before the bin falls back to the global table; a small value forces the fall-back path, a negative one
+ * restores the default (3/4 of the 8192 slots). */
+void fgnn_debug_set_partition_lds_limit(int distinct_keys);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);

@@ -633,6 +633,28 @@ def test_batch_driver_large_frontier(hip, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("limit", [0, 48])
+def test_partitioned_last_fill_falls_back_per_bin(hip, oracle, limit):
+    """The batch's last dedup fill is partitioned by hash and deduplicated per bin in an LDS table
+    (hashtable_partition.hip; reference: the global-table insert of cuda_hashtable.cu:176-211).  A bin with more
+    distinct keys than its LDS table may hold goes through the global table instead -- forced here for every bin
+    (limit 0) and for the fuller bins only (limit 48: LDS and global bins side by side in one fill); the batch-driver
+    parity tests (oracle, bit-exact: blocks, unique list, cache split, features) must hold unchanged.  The default
+    limit is what every other batch-driver test in this file runs with."""
+    L = hip.load()
+    L.fgnn_debug_set_partition_lds_limit(limit)
+    try:
+        test_batch_driver_matches_oracle(hip, oracle, "khop2", [25, 10], 3000, 128)
+        test_batch_driver_matches_oracle(hip, oracle, "khop2", [3], 17, 4)
+        test_batch_driver_other_samplers(hip, oracle, "weighted")
+        test_batch_driver_other_samplers(hip, oracle, "random_walk")
+        test_batch_driver_empty_and_isolated_batches(hip, oracle, "khop2")
+        test_batch_driver_hub_nodes_in_every_row(hip, oracle)
+    finally:
+        L.fgnn_debug_set_partition_lds_limit(-1)
+
+
+@pytest.mark.gpu
 def test_hash_dedup_large_frontier_two_pass(hip, oracle):
     """More than 2048 workgroups of seeds: the sampler takes the count / scan / emit route instead of the look-back."""
     from fgnn_hip import synth

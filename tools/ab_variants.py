@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of batch-driver switches over ONE generated graph: a sampler per variant (the C side reads its FGNN_* switches
-when a sampler is created), timed windows interleaved A B C A B C ... so that box drift hits every variant alike.
+"""A/B of batch-driver switches over ONE generated graph: a sampler per variant (the PROFILING build of the library --
+make -C fgnn-artifacts_amd/csrc prof; the shipped one has no switches -- reads its FGNN_* switches when a sampler is
+created), timed windows interleaved A B C A B C ... so that box drift hits every variant alike.
 
-  python3 tools/ab_variants.py --variants "base;FGNN_CHAIN_PRIORITY=1;FGNN_KHOP_SPLIT_L0=0,FGNN_CHAIN_PRIORITY=1" \
+  python3 tools/ab_variants.py --variants "base;FGNN_HT_PARTITION=0;FGNN_KHOP_SPLIT_L0=0" \
       [--rounds 5] [--steps 151] [--workload papers100M] [--modes full,sample] [--streams 3]
 
 Prints one line per variant and mode: median / min / max ms per step over the rounds.  The whole path is bench.py's
@@ -19,6 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("FGNN_HIP_LIB", os.path.join(ROOT, "fgnn-artifacts_amd", "lib", "libfgnn_hip_prof.so"))
 import bench  # noqa: E402
 from fgnn_hip import lib  # noqa: E402
 
@@ -101,25 +103,14 @@ def main():
                     os.environ[k] = val
 
     def region_(v, n, mode):
+        # the native batch loop (fgnn_sampler_run_range), like bench.py; the sampler-side stage on two streams
         first = v["seq"]
-        edges = 0
-        for i in range(first, first + n):
-            bt = v["batches"][i % nbuf]
-            if i - first >= nbuf:
-                m = bt.wait()
-                edges += sum(int(m.num_edge[l]) for l in range(m.num_layers))
-            step = i % spe
-            seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
-            st = streams[i % len(streams)]
-            if mode == "full":
-                v["sampler"].run_batch(i, seeds, step, bt, table, feat, label, stream=st)
-            else:
-                v["sampler"].run_batch(i, seeds, step, bt, table, None, None, stream=st)
-        for i in range(max(first, first + n - nbuf), first + n):
-            m = v["batches"][i % nbuf].wait()
-            edges += sum(int(m.num_edge[l]) for l in range(m.num_layers))
+        full = mode == "full"
+        sts = streams if full or len(streams) < 3 else streams[:2]
+        metas, _, _ = v["sampler"].run_range(first, n, train, bs, v["batches"], sts, cache_table=table,
+                                             feat=feat if full else None, label=label if full else None)
         v["seq"] = first + n
-        return edges
+        return sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
 
     for v in variants:
         region(v, a.warmup, "full")

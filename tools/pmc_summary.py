@@ -50,7 +50,7 @@ out["all_kernels_KB_per_launch"] = {k: {"launches": fetch[k][1], "FETCH_SIZE": f
 # bench.algorithmic_bytes computes them, per batch): the sampler launches carry the dedup's insert, so sampling and
 # dedup/remap are one stage here.  FETCH_SIZE is doubled only for the wide coalesced reads of the row gather; the
 # random 4/8-byte reads of the other kernels are 64-B requests and count as reported.
-STAGES = {"sample_dedup_remap": ("khop_sample_kernel", "ht_count_assign_kernel", "ht_map_fix_kernel", "ht_insert_kernel",
+STAGES = {"sample_dedup_remap": ("khop_sample_kernel", "ht_count_assign_kernel", "ht_map_fix_kernel", "ht_insert_kernel", "part_hist_kernel", "part_scatter_kernel", "part_dedup_kernel",
                                  "weighted_", "rank_", "hash_dedup_kernel", "random_walk_topk_kernel", "rw_emit_kernel"),
           "cache_split": ("cache_split_fused_kernel", "cache_count_kernel", "cache_split_kernel"),
           "gather": ("gather_rows16_kernel", "gather_rows_elem_kernel")}
