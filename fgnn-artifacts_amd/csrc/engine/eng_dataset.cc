@@ -1,5 +1,7 @@
 #include "eng_dataset.h"
 
+#include <algorithm>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -166,8 +168,14 @@ std::string PlaceHostTable(void *ptr, size_t bytes, const char *what) {
   int mode = 3;  // MPOL_INTERLEAVE
   std::string desc = "interleaved over " + std::to_string(nodes.size()) + " nodes";
   if (want.compare(0, 5, "node:") == 0) {
-    const int n = atoi(want.c_str() + 5);
-    mask[(n % 1024) / 64] |= 1ul << (n % 64);
+    char *end = nullptr;
+    const long n = strtol(want.c_str() + 5, &end, 10);
+    if (end == want.c_str() + 5 || *end != '\0' || n < 0 || std::find(nodes.begin(), nodes.end(), (int)n) == nodes.end()) {
+      SAM_LOG(kWarning) << what << ": SAMGRAPH_HOST_FEAT_NUMA=" << want << " does not name a NUMA node with memory; pages "
+                        << "go where they are first touched";
+      return "first touch (bad node in SAMGRAPH_HOST_FEAT_NUMA)";
+    }
+    mask[n / 64] |= 1ul << (n % 64);
     mode = 2;  // MPOL_BIND
     desc = "bound to node " + std::to_string(n);
   } else {

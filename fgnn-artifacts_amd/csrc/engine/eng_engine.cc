@@ -1081,6 +1081,10 @@ void Engine::Shutdown() {
     pub_cv_.notify_all();
     publish_thread_.join();
   }
+  // the shuffler's helper thread synchronises the batch streams before it recycles a seed array (eng_shuffler.cc,
+  // Prepare): it must be done before any of those streams is destroyed below -- a run that stops shortly after an epoch
+  // boundary would otherwise hand it a dead handle
+  if (shuffler_) shuffler_->Quiesce();
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto &sl : slots_)
     if (sl.st) (void)hipStreamSynchronize(sl.st);

@@ -1,4 +1,5 @@
 // eng_hooks.cc -- include/fgnn_engine_hooks.h
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -100,6 +101,39 @@ extern "C" int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t 
 // further one is taken only through TryRecv (published or nothing), with nothing held the consumer may block.  Must
 // terminate for any slot count >= 2 -- a consumer that blocked for a claimed-but-unpublished message while holding
 // slots would wait for a producer that waits for exactly those slots.
+// A receiver blocked on an empty ring and a sender blocked on a full one must both give up (abort, like a failed CHECK)
+// once the queue is marked aborted -- what samgraph_wait_one_child does when it sees a dead child.  Returns the number
+// of the two children that ended by SIGABRT within the time limit (2 = both).
+extern "C" int fgnn_host_queue_abort_selftest(void) {
+  MemoryQueue mq(256, 2);
+  pid_t receiver = fork();
+  if (receiver == 0) {
+    alarm(30);
+    size_t key;
+    (void)mq.Recv(&key);  // nothing is ever sent
+    _exit(0);
+  }
+  MemoryQueue full(256, 1);
+  pid_t sender = fork();
+  if (sender == 0) {
+    alarm(30);
+    size_t key;
+    (void)full.GetPtr(&key);
+    full.SimpleSend(key);
+    (void)full.GetPtr(&key);  // the only slot is never released
+    _exit(0);
+  }
+  usleep(200000);
+  mq.Abort();
+  full.Abort();
+  int aborted = 0;
+  for (pid_t pid : {receiver, sender}) {
+    int st = 0;
+    if (waitpid(pid, &st, 0) == pid && WIFSIGNALED(st) && WTERMSIG(st) == SIGABRT) ++aborted;
+  }
+  return aborted;
+}
+
 extern "C" int fgnn_host_queue_selftest_deep(size_t slots, size_t slot_bytes, size_t messages, int producers,
                                              int consumers, int depth) {
   if (producers < 1 || consumers < 1 || slot_bytes < 64 || depth < 1) return 2;

@@ -146,9 +146,11 @@ int samgraph_wait_one_child(void) {  // operation.cc:374-385
   pid_t pid = waitpid(-1, &child_stat, 0);
   if (WEXITSTATUS(child_stat) != 0) {
     SAM_LOG(kError) << "detect a terminated child " << pid << ", status is " << WEXITSTATUS(child_stat);
+    Engine::Get().AbortQueue();
     return 1;
   } else if (WIFSIGNALED(child_stat) && (WTERMSIG(child_stat) == SIGABRT)) {
     SAM_LOG(kError) << "detect an aborted child " << pid;
+    Engine::Get().AbortQueue();
     return 1;
   }
   return 0;

@@ -67,6 +67,7 @@ struct QueueMeta {                 // MQ_MetaData, memory_queue.h:65-115
   size_t rel_seq[kMaxSlots];        // generations of the slot released so far: message k may be written at k / N
   uint32_t payload_loc[kMaxSlots];  // 0: payload in the host slot; else ((ring + 1) << 8) | device slot
   int ipc_broken;                   // set by the first receiver that could not map a ring: samplers stop using theirs
+  int aborted;                      // a process of the job died (MemoryQueue::Abort): blocked peers give up loudly
   // SAMGRAPH_HANDOFF_CHECK: a message whose sender appended a checksum of its words behind it (pack.hip); the receiver
   // recomputes it THROUGH THE ADDRESS IT READS THE PAYLOAD FROM (mapped HBM slot, host slot) before it uses the batch
   uint32_t checked[kMaxSlots];      // 1: the message in the slot carries the trailer; + which sampler sent it
@@ -85,6 +86,9 @@ class MemoryQueue {
   const void *Recv(size_t *key);                     // blocks until a message is available
   bool TryRecv(const void **data, size_t *key);      // never blocks: takes the oldest message only if it is PUBLISHED
   void Release(size_t key);                          // SharedData::~SharedData
+  // a process of the job has died: every blocked GetPtr / Recv of every process logs and aborts instead of waiting for
+  // a message (or a release) that will never come -- the reference's semaphore waits hang in that case
+  void Abort() { __atomic_store_n(&meta_->aborted, 1, __ATOMIC_RELEASE); }
   // hand-off check bookkeeping (see QueueMeta)
   void MarkChecked(size_t key, int sender, bool on) {
     meta_->checked[key % meta_->max_size] = on ? 1u : 0u;

@@ -136,8 +136,7 @@ void Shuffler::ReShuffle() {
   }
   cur_step_ = 0;
   if (cur_epoch_ >= num_epoch_) return;
-  SAM_CHECK(prep_.joinable());
-  prep_.join();  // normally long done
+  if (prep_.joinable()) prep_.join();  // normally long done (already joined after Quiesce)
   data_.swap(next_);
   uint32_t *oldest = d_prev_;
   d_prev_ = d_data_;  // its last batches may still be in flight

@@ -33,6 +33,9 @@ class Shuffler {
   // steps per epoch over all workers of the aligned split (known before any worker exists)
   static size_t AlignedNumStep(size_t num_data, size_t batch_size, size_t num_worker);
   ~Shuffler();
+  // waits for the helper thread that prepares the next epoch (it touches the tracked streams); GetBatch after this
+  // still works, the join in ReShuffle is then a no-op
+  void Quiesce() { if (prep_.joinable()) prep_.join(); }
   // next batch of this sampler: device pointer into the epoch's slice + size; false when all epochs are done
   bool GetBatch(const uint32_t **d_batch, size_t *size);
   uint64_t Epoch() const { return cur_epoch_; }

@@ -33,6 +33,10 @@ void fgnn_host_wire_sizes(size_t batch_size, const size_t *fanout, size_t num_la
  * intact.  Returns 0 on success. */
 int fgnn_host_queue_selftest(size_t slots, size_t slot_bytes, size_t messages, int producers, int consumers);
 
+/* A receiver blocked on an empty ring and a sender blocked on a full one after MemoryQueue::Abort (the parent saw a
+ * child die, samgraph_wait_one_child): returns how many of the two ended by SIGABRT (2 = both; the reference's
+ * semaphore waits, memory_queue.cc:104-138, hang forever in that situation). */
+int fgnn_host_queue_abort_selftest(void);
 /* The same, with consumers that behave like the engine's extraction thread (eng_engine.cc: StartExtract): each holds up
  * to `depth` received messages unreleased and takes a further one only when it is already published (TryRecv); with
  * nothing held it blocks.  Must terminate for any slots >= 2 (a ring of 2-3 slots is what large fan-outs leave under

@@ -185,6 +185,13 @@ sys.exit(eng.fgnn_host_queue_named_role(C.c_size_t(slots), C.c_size_t(4096), C.c
 """
 
 
+def test_queue_waiters_give_up_when_the_queue_is_aborted(hooks):
+    """A dead peer must not hang the job: samgraph_wait_one_child marks the queue aborted, and processes blocked in
+    GetPtr (ring full) or Recv (ring empty) then abort like a failed CHECK instead of waiting forever (the
+    reference's sem_wait pairs, memory_queue.cc:104-138, never return in that case)."""
+    assert hooks.fgnn_host_queue_abort_selftest() == 2
+
+
 @pytest.mark.parametrize("producers,consumers,slots", [(1, 1, 2), (2, 3, 5)])
 def test_queue_named_regions_between_unrelated_processes(hooks, producers, consumers, slots):
     """The torchrun launch style: processes that share no forking parent meet in named shared-memory regions
