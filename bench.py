@@ -1299,6 +1299,7 @@ def run_pipeline_rank(args, rank, world):
             dist.barrier()  # every batch of the region has been consumed
             return time.perf_counter() - t0, busy
 
+        links = link_selftest(dist, rank, world, dev_id, n_dev, args.rehearse)
         region(W, False)
         del keys[:]
         elapsed, busy = region(K, False)
@@ -1380,7 +1381,7 @@ def run_pipeline_rank(args, rank, world):
                     "sampler_busy_s": s_busy, "trainer_busy_s": t_busy,
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
-                    "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff,
+                    "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff, "links": links,
                     "numa": {"gpu_node_of_rank": gnodes, "nodes_with_memory": numa_nodes_with_memory(),
                              "host_feat_policy": os.environ.get("SAMGRAPH_HOST_FEAT_NUMA",
                                                                 "interleave over the nodes with memory (default)"),
@@ -1419,6 +1420,53 @@ def run_pipeline_rank(args, rank, world):
                         except OSError:
                             pass
     dist.destroy_process_group()
+
+
+def link_selftest(dist, rank, world, dev_id, n_dev, rehearse):
+    """First-contact proof for N >= 2, run once in the untimed warm-up: ONE RCCL all-reduce over ALL ranks (samplers
+    included: `rccl_world` == world says RCCL saw every rank; the data path itself has no collective), its bus
+    bandwidth on a 64 MiB payload, and the peer-access matrix between the ranks' GPUs (what the trainers' peer reads of
+    the samplers' HBM rings rest on).  With fewer GPUs than ranks RCCL refuses (two ranks on one device): recorded as
+    such, nothing is faked.  Every rank takes part (new_group is a collective call); rank 0 gets the record."""
+    import datetime
+    if rehearse:
+        return {"rccl_world": None, "why": "control-plane rehearsal: no GPU work"}
+    if n_dev < world:
+        grp = None
+        rec = {"rccl_world": None, "why": "%d ranks share %d GPU(s): RCCL needs a device per rank" % (world, n_dev)}
+    else:
+        grp = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=300))
+        dev = torch.device("cuda", dev_id)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one, group=grp)
+        torch.cuda.synchronize(dev)
+        buf = torch.ones(16 << 20, dtype=torch.float32, device=dev)  # 64 MiB
+        dist.all_reduce(buf, group=grp)  # first use of the size
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf, group=grp)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 5
+        nbytes = buf.numel() * 4
+        rec = {"rccl_world": int(round(float(one.item()))), "allreduce_64MiB_ms": dt * 1e3,
+               "allreduce_busbw_GBps": 2 * (world - 1) / world * nbytes / dt / 1e9,
+               "note": "one all-reduce over all ranks in the warm-up (samplers too); busbw = 2(n-1)/n x bytes / time"}
+        del buf, one
+    # row of the peer matrix for this rank's GPU: which other ranks' GPUs it can map
+    row = []
+    for r in range(world):
+        other = r % max(n_dev, 1)
+        try:
+            row.append(True if other == dev_id else bool(torch.cuda.can_device_access_peer(dev_id, other)))
+        except Exception:
+            row.append(None)
+    rows = [None] * world
+    dist.all_gather_object(rows, row)
+    rec["peer_access"] = {"matrix": rows, "note": "matrix[i][j]: rank i's GPU can map rank j's GPU memory "
+                                                  "(hipDeviceCanAccessPeer); ranks sharing a GPU read True"}
+    return rec if rank == 0 else None
 
 
 def launch_ranks(args):

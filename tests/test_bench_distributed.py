@@ -60,6 +60,8 @@ def test_plain_launch_spawns_ranks(gpus, samplers):
     assert out["input_nodes_per_step"] == 1.0  # every one of the 20 batches reached exactly one trainer
     assert out["scaling"] == "strong" and out["ms_per_step"] > 0
     assert out["pipeline"]["handoff"]["transport"] == "none (rehearsal)" and len(out["pipeline"]["handoff"]["rings"]) == S
+    # the link self-test's record is part of every N >= 2 line; a rehearsal has no GPU and says so instead of a number
+    assert out["pipeline"]["links"]["rccl_world"] is None and "rehearsal" in out["pipeline"]["links"]["why"]
     assert not [f for f in set(os.listdir("/dev/shm")) - before if f.startswith("fgnn_bench_")]  # rank 0 cleaned up
 
 

@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner.py")
@@ -247,6 +248,13 @@ def test_bench_pipeline_two_processes(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["pipeline"]["samplers"] == 1
     assert out["value"] > 0 and out["edges_per_step"] > 1000 and 0 < out["pipeline"]["hit_rate"] <= 1
     assert out["epoch_time_s"]["with_training"] > 0
+    # the link self-test: with a GPU per rank RCCL must have seen both ranks; on a one-GPU box the line says why not
+    links = out["pipeline"]["links"]
+    if torch.cuda.device_count() >= 2:
+        assert links["rccl_world"] == 2 and links["allreduce_busbw_GBps"] > 0
+    else:
+        assert links["rccl_world"] is None and "share" in links["why"]
+    assert len(links["peer_access"]["matrix"]) == 2 and all(len(r) == 2 for r in links["peer_access"]["matrix"])
 
 
 def test_bench_pipeline_two_samplers_three_trainers(tmp_path):
