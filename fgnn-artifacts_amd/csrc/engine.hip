@@ -58,6 +58,8 @@ struct fgnn_sampler {
   // batch found its slot (its predecessor) on ANOTHER stream; that first time is served by recording the event late,
   // on the other stream (it then covers more than needed: correct, once).
   std::atomic<bool> cross_slot{false}, cross_csr{false};
+  // weighted_khop_prefix: 16-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
+  fgnn::PrefixTreeHost *ptree = nullptr;
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 = 0 (profiling build): fused last layer
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED = 1 (profiling build): wrong results under overlap
 };
@@ -186,12 +188,22 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
       return fail(err != FGNN_OK ? err : FGNN_EHIP);
     }
   }
+  // (FGNN_PREFIX_TREE=0, profiling build: every row searched like the reference, for A/Bs)
+  if (cfg->sample_type == FGNN_WEIGHTED_KHOP_PREFIX && cfg->num_node && fgnn::tune_int("FGNN_PREFIX_TREE", 1) != 0)
+    s->ptree = fgnn::prefix_tree_build(cfg->indptr, cfg->prob_prefix, cfg->num_node);  // null: no long rows / no memory
   if (h_err) *h_err = FGNN_OK;
   return s;
 }
 
+extern "C" int fgnn_sampler_prefix_tree_stats(const fgnn_sampler *s, size_t out[3]) {
+  if (!s || !out) return FGNN_EINVAL;
+  fgnn::prefix_tree_stats(s->ptree, out);
+  return FGNN_OK;
+}
+
 extern "C" void fgnn_sampler_destroy(fgnn_sampler *s) {
   if (!s) return;
+  fgnn::prefix_tree_destroy(s->ptree);
   for (auto &sl : s->slot) {
     if (sl.ht) fgnn_hashtable_destroy(sl.ht);
     sl.scan_sample.destroy();
@@ -425,7 +437,8 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
           s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
           s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX ? s->cfg.prob_prefix : s->cfg.prob_table, s->cfg.alias_table,
           cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key,
-          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, rank.bitmap ? &rank : nullptr);
+          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, rank.bitmap ? &rank : nullptr,
+          fgnn::prefix_tree_view(s->ptree));
     }
     else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
       rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,

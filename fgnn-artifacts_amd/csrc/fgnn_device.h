@@ -715,6 +715,19 @@ int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const flo
                       size_t num_input_cap, size_t fanout, uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out,
                       int src_mode, uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
                       void *stream, ScanWsHost *scan_host);
+// 5-ary search trees over the long rows of a prefix-sum table (prefix_tree.hip): tree_off[row] = node index of the
+// row's root in `pool` (4 floats per node), FGNN_EMPTY_KEY for rows without a tree (short, or not non-decreasing)
+constexpr uint32_t kPrefixTreeMinLen = 64;
+struct PrefixTreeView {
+  const uint32_t *tree_off;  // null: no trees
+  const float *pool;
+};
+struct PrefixTreeHost;
+PrefixTreeHost *prefix_tree_build(const uint32_t *indptr, const float *prefix, size_t num_node);  // synchronous
+void prefix_tree_destroy(PrefixTreeHost *t);
+PrefixTreeView prefix_tree_view(const PrefixTreeHost *t);
+void prefix_tree_stats(const PrefixTreeHost *t, size_t out[3]);  // long rows, rows refused (not monotone), pool bytes
+
 // What the FIRST sampler launch of a batch does on top of sampling, so that no separate start-of-batch kernel is
 // needed: FillWithUnique(seeds) (seed i -> local id i), copy of the seeds (the batch's output_nodes), item counts and
 // the batch summary's header.  n2o == null: not the first launch.
@@ -740,7 +753,7 @@ int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const ui
                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                                uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                                uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node,
-                               const RankWs *rank);
+                               const RankWs *rank, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr});
 // fgnn_sample_random_walk with look-back descriptors: the edge offsets and the compacted output come from one launch
 // (scan == null: per-workgroup sums -> scan -> emit, as the C entry point)
 int sample_random_walk_ex(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,

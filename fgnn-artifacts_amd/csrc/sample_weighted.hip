@@ -28,13 +28,33 @@ __device__ __forceinline__ float uniform_float(uint32_t x) {
   return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);  // (0,1], 24 bits, as the oracle
 }
 
+// Position of the first entry >= x in a non-decreasing row with a 5-ary tree (prefix_tree.hip): what the reference's
+// binary search (weighted_khop_prefix.cu:66-86) returns on such a row, in ceil(log5 len) 16-byte look-ups.
+// x <= the row's last entry.
+__device__ __forceinline__ uint32_t tree_search(uint32_t len, const float *pool, uint32_t root, float x) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 *nodes = reinterpret_cast<const f4 *>(pool);
+  uint32_t T = 0;
+  for (uint32_t m = len; m > 1; m = (m + 4u) / 5u) ++T;  // smallest T with 5^T >= len
+  uint32_t idx = 0, base = root;
+  for (uint32_t l = T; l >= 1; --l) {
+    const f4 nd = nodes[base + idx];  // +inf marks an empty child: never below x
+    idx = idx * 5u + (uint32_t)(nd.x < x) + (uint32_t)(nd.y < x) + (uint32_t)(nd.z < x) + (uint32_t)(nd.w < x);
+    uint32_t n = len;  // nodes of level l = ceil(len / 5^l)
+    for (uint32_t k = 0; k < l; ++k) n = (n + 4u) / 5u;
+    base += n;
+  }
+  return idx;  // level 1's separators are the row's own entries: the descent ends at the position
+}
+
 // the draw of (seed i, slot j).  MODE 0: per-row prefix sums + binary search (weighted_khop_prefix.cu:41-92),
 // 1: uniform with replacement (khop1.cu:42-72), 2: alias method, alias table = node ids (weighted_khop.cu:41-76)
 template <int MODE>
 __device__ __forceinline__ uint32_t weighted_pick(const uint32_t *__restrict__ indices, const float *__restrict__ prefix,
                                                   const uint32_t *__restrict__ alias, uint32_t off, uint32_t len,
                                                   uint32_t i, uint32_t j, uint64_t seed, uint64_t batch_key,
-                                                  uint32_t tag) {
+                                                  uint32_t tag, const float *tree_pool = nullptr,
+                                                  uint32_t tree_root = FGNN_EMPTY_KEY) {
   if (len == 0) return FGNN_EMPTY_KEY;
   if (MODE == 1) return indices[off + philox_u32(seed, batch_key, tag, i, j) % len];
   if (MODE == 2) {
@@ -46,6 +66,7 @@ __device__ __forceinline__ uint32_t weighted_pick(const uint32_t *__restrict__ i
   }
   const float up = prefix[off + len - 1];
   const float x = uniform_float(philox_u32(seed, batch_key, tag, i, j)) * up;
+  if (tree_root != FGNN_EMPTY_KEY) return indices[off + tree_search(len, tree_pool, tree_root, x)];
   if (x <= prefix[off]) return indices[off];
   size_t lo = off, hi = (size_t)off + len - 1;
   while (hi - lo >= 2) {
@@ -64,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *_
                                                                const uint32_t *__restrict__ input, size_t n_host,
                                                                const uint32_t *d_n, size_t cap, uint32_t F,
                                                                uint32_t *__restrict__ tmp_dst, uint64_t seed,
-                                                               uint64_t batch_key, uint32_t tag) {
+                                                               uint64_t batch_key, uint32_t tag, PrefixTreeView tree) {
   const size_t n = resolve_count(n_host, d_n, cap);
   const size_t total = n * F;
   const size_t stride = (size_t)gridDim.x * kBlock;
@@ -74,7 +95,9 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_kernel(const uint32_t *_
     const uint32_t rid = input[i];
     const uint32_t off = indptr[rid];
     const uint32_t len = indptr[rid + 1] - off;
-    tmp_dst[t] = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag);
+    const uint32_t root = (MODE == 0 && tree.tree_off && len > kPrefixTreeMinLen) ? tree.tree_off[rid] : FGNN_EMPTY_KEY;
+    tmp_dst[t] = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag, tree.pool,
+                                     root);
   }
 }
 
@@ -88,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
     const uint32_t *__restrict__ alias, const uint32_t *__restrict__ input, size_t n_host, const uint32_t *d_n,
     size_t cap, uint32_t F, uint32_t *__restrict__ tmp_dst, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ cnt, uint32_t *bitmap, uint32_t *__restrict__ order, uint64_t seed, uint64_t batch_key,
-    uint32_t tag) {
+    uint32_t tag, PrefixTreeView tree) {
   const size_t n = resolve_count(n_host, d_n, cap);
   const uint32_t G = (uint32_t)kWave / F;               // seeds per wave (F <= 64)
   const uint32_t lane = (uint32_t)lane_id();
@@ -99,15 +122,18 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
   for (size_t w = (size_t)blockIdx.x * kWavesPerBlock + wave_id(); w * G < cap; w += waves) {
     const size_t i = w * G + g;
     const bool seed_here = lane_used && i < cap;
-    uint32_t rid = FGNN_EMPTY_KEY, off = 0, len = 0;
+    uint32_t rid = FGNN_EMPTY_KEY, off = 0, len = 0, root = FGNN_EMPTY_KEY;
     if (seed_here && i < n) {
       rid = input[i];
       off = indptr[rid];
       len = indptr[rid + 1] - off;
+      // (the root's index is fetched with the row bounds: no extra round trip; the F lanes of a seed share the address)
+      if (MODE == 0 && tree.tree_off) root = tree.tree_off[rid];
+      if (len <= kPrefixTreeMinLen) root = FGNN_EMPTY_KEY;
     }
     uint32_t pick = FGNN_EMPTY_KEY;
     if (seed_here && i < n) {
-      pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag);
+      pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag, tree.pool, root);
       tmp_dst[i * F + j] = pick;
     }
     // a draw is dropped when it equals the seed's NEXT draw; the last one is always kept (count_edge, prefix.cu:94-112)
@@ -443,7 +469,7 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
                             const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                             uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                             uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node = 0,
-                            const RankWs *rank = nullptr) {
+                            const RankWs *rank = nullptr, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr}) {
   // rank != null: the caller guarantees unique seeds below num_node (the batch driver's frontier) and owns an all-zero
   // bitmap over the id space: the seeds are ordered by counting bits, nothing is sorted and no library is called
   auto st = static_cast<hipStream_t>(stream);
@@ -479,7 +505,7 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
 #define FGNN_DRAWC(M)                                                                                            \
   hipLaunchKernelGGL((weighted_draw_count_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, \
                      alias, input, num_input, d_num_input, cap, F, tmp_dst, keys, vals, cnt, bitmap, order, seed,    \
-                     batch_key, tag)
+                     batch_key, tag, tree)
     if (mode == 1) FGNN_DRAWC(1);
     else if (mode == 2) FGNN_DRAWC(2);
     else FGNN_DRAWC(0);
@@ -489,7 +515,7 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
     if (blocks > 256 * 32) blocks = 256 * 32;
 #define FGNN_DRAW(M)                                                                                              \
   hipLaunchKernelGGL((weighted_draw_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, indptr, indices, table_f, alias, \
-                     input, num_input, d_num_input, cap, F, tmp_dst, seed, batch_key, tag)
+                     input, num_input, d_num_input, cap, F, tmp_dst, seed, batch_key, tag, tree)
     if (mode == 1) FGNN_DRAW(1);
     else if (mode == 2) FGNN_DRAW(2);
     else FGNN_DRAW(0);
@@ -549,11 +575,11 @@ int fgnn::sample_with_replacement_ex(int sample_type, const uint32_t *indptr, co
                                      size_t num_input, const uint32_t *d_num_input, size_t num_input_cap, size_t fanout,
                                      uint32_t *out_src, uint32_t *out_dst, size_t *d_num_out, int src_mode,
                                      uint64_t seed, uint64_t batch_key, uint32_t layer, void *ws, size_t ws_bytes,
-                                     void *stream, size_t num_node, const RankWs *rank) {
+                                     void *stream, size_t num_node, const RankWs *rank, PrefixTreeView tree) {
   const int mode = sample_type == FGNN_KHOP1 ? 1 : sample_type == FGNN_WEIGHTED_KHOP ? 2 : 0;
   return launch_with_replacement(mode, sample_type, indptr, indices, table_f, alias, input, num_input, d_num_input,
                                  num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed, batch_key, layer,
-                                 ws, ws_bytes, stream, num_node, rank);
+                                 ws, ws_bytes, stream, num_node, rank, mode == 0 ? tree : PrefixTreeView{nullptr, nullptr});
 }
 
 extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,

@@ -431,7 +431,7 @@ EXPORTS += [
     "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta", "fgnn_batch_host_meta", "fgnn_batch_meta_copied",
-    "fgnn_sampler_run_range",
+    "fgnn_sampler_run_range", "fgnn_sampler_prefix_tree_stats",
 ]
 
 
@@ -505,6 +505,8 @@ class Sampler:
         cfg.walk_len, cfg.num_walks, cfg.restart_prob = walk_len, num_walks, restart_prob
         cfg.prob_table = prob_table.data_ptr() if prob_table is not None else 0
         cfg.alias_table = alias_table.data_ptr() if alias_table is not None else 0
+        if prob_prefix is not None:
+            torch.cuda.synchronize(self.device)  # the sampler reads the table while it is created (search trees)
         err = C.c_int(0)
         self.h = C.c_void_p(L.fgnn_sampler_create(C.byref(cfg), C.byref(err)))
         if not self.h:
@@ -517,6 +519,12 @@ class Sampler:
         if getattr(self, "h", None) and _lib is not None:
             _lib.fgnn_sampler_destroy(self.h)
             self.h = None
+
+    def prefix_tree_stats(self):
+        """(rows with a search tree, long rows refused as not non-decreasing, bytes) -- weighted_khop_prefix only"""
+        out = (C.c_size_t * 3)()
+        _check(load().fgnn_sampler_prefix_tree_stats(self.h, out), "fgnn_sampler_prefix_tree_stats")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def max_edges(self, layer):
         return load().fgnn_sampler_max_edges(self.h, C.c_int(layer))

@@ -315,6 +315,11 @@ typedef struct fgnn_batch_meta_s {
 
 fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);
 void fgnn_sampler_destroy(fgnn_sampler *s);
+/* weighted_khop_prefix samplers build, at creation, a 5-ary search tree over every prefix-table row longer than 64
+ * entries (a draw then costs ceil(log5 deg) 16-byte look-ups instead of the binary search's ceil(log2 deg),
+ * cuda_sampling_weighted_khop_prefix.cu:66-86; same result on every non-decreasing row, rows that are not keep the
+ * reference's search): out[0] = rows with a tree, out[1] = long rows refused (not non-decreasing), out[2] = bytes. */
+int fgnn_sampler_prefix_tree_stats(const fgnn_sampler *s, size_t out[3]);
 size_t fgnn_sampler_max_nodes(const fgnn_sampler *s);            /* PredictNumNodes(batch, fanout, L) */
 size_t fgnn_sampler_max_edges(const fgnn_sampler *s, int layer); /* worst-case edges of graphs[layer] */
 

@@ -435,6 +435,65 @@ def test_batch_driver_other_samplers(hip, oracle, mode):
         np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
 
 
+def test_weighted_prefix_search_trees_on_long_rows(hip, oracle):
+    """Rows of the prefix table longer than 64 entries are searched through a 5-ary tree built when the sampler is
+    created (prefix_tree.hip) instead of the reference's binary search (cuda_sampling_weighted_khop_prefix.cu:66-86):
+    row lengths around the level boundaries (65, 125 / 126, 625 / 626, 3 125 / 3 126, 78 125 / 78 126, ...), rows of equal weights
+    (long runs of ties would expose a wrong '<' / '<='), and ONE long row whose prefix sums are not non-decreasing -- it
+    must be refused a tree (the answer of a binary search on such a row depends on the probe order) and still match.
+    Bit-exact against the oracle's binary search, two layers so that hub rows are also reached as sampled neighbours."""
+    lens = [257, 300, 4096, 4097, 65536, 65537, 300000, 256, 17, 1, 0, 1000, 5000, 70000, 64, 65, 125, 126, 625, 626,
+            3125, 3126, 15625, 15626, 78125, 78126]
+    rng = np.random.default_rng(77)
+    num_node = 4000
+    deg = np.concatenate([np.array(lens), rng.integers(0, 40, size=num_node - len(lens))]).astype(np.int64)
+    indptr = np.zeros(num_node + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    E = int(indptr[-1])
+    # neighbours: mostly the special rows, so that layer 0's frontier is full of them
+    indices = np.where(rng.random(E) < 0.5, rng.integers(0, len(lens), size=E), rng.integers(0, num_node, size=E))
+    indices = indices.astype(np.uint32)
+    w = np.where(rng.random(E) < 0.3, 100.0, 1.0).astype(np.float32)
+    w[indptr[5]:indptr[6]] = 1.0  # a row of equal weights
+    # a row whose sums stall: beyond 1e8 a float moves in steps of 8, so most of these weights change nothing and
+    # neighbouring prefix values are EQUAL over long stretches (first-position-of-a-tie semantics)
+    w[indptr[13]:indptr[14]] = rng.choice(np.array([1.0, 4.0, 8.0, 16.0], dtype=np.float32), size=lens[13])
+    w[indptr[13]] = 1e8
+    prefix = np.empty(E, dtype=np.float32)
+    for r in range(num_node):
+        a, b = indptr[r], indptr[r + 1]
+        if b > a:
+            prefix[a:b] = np.cumsum(w[a:b], dtype=np.float32)  # sequential f32 accumulation like the tool
+    k = indptr[12] + 2500  # row 12 (5 000 entries): two neighbouring sums swapped -> not non-decreasing
+    assert prefix[k] < prefix[k + 1]
+    prefix[k], prefix[k + 1] = prefix[k + 1], prefix[k]
+    indptr = indptr.astype(np.uint32)
+    fanouts, batch = [6, 15], 96
+    sampler = hip.Sampler(dev(indptr), dev(indices), fanouts, batch, sample_type=hip.WEIGHTED_KHOP_PREFIX, seed=SEED,
+                          prob_prefix=dev(prefix))
+    long_rows, refused, nbytes = sampler.prefix_tree_stats()
+    assert long_rows == sum(1 for x in lens if x > 64) and refused == 1 and nbytes > 0
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng_o = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    for b in range(3):
+        seeds = np.concatenate([np.arange(len(lens)), 100 + rng.permutation(1000)[:batch - len(lens)]]).astype(np.uint32)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, oracle.WEIGHTED_KHOP_PREFIX, rng_o, b, oht,
+                                prob_prefix=prefix)
+        assert m.overflow == 0
+        for li in range(2):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        np.testing.assert_array_equal(host_u32(bt.input_nodes()), want["input_nodes"])
+
+
 @pytest.mark.parametrize("batch", [12000, 44000])
 def test_batch_driver_random_walk_large_capacities(hip, oracle, batch):
     """PinSAGE walks through the batch driver at worst-case frontier capacities of 432 K and 1.58 M seeds: the one-launch
