@@ -482,7 +482,8 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
     rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
-                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed);
+                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed,
+                                      /*table_free=*/!khop_fused);  // those samplers never look the table up
     if (rc != FGNN_OK) return rc;
     owed = mine;
     in_cap += ecap;

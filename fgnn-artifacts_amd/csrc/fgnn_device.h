@@ -662,7 +662,11 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                  ScanWsHost *scan, bool final_fill = false, bool resolved = false,
-                                 FixTail *owed_fix = nullptr, const FixTail *carry_fix = nullptr);
+                                 FixTail *owed_fix = nullptr, const FixTail *carry_fix = nullptr,
+                                 bool table_free = false);
+// table_free: nothing after this fill reads the global table (no fused sampler insert, no fgnn_hashtable_map, and every
+// later fill of the batch is table_free or final too) -- the fill may then go through the partitioned path although it
+// is not the batch's last (the batch driver's samplers that do not insert themselves: every layer)
 // owed_fix (non-null: the caller takes the remap fix-up of THIS fill over; filled in, mapped == null if none is owed):
 // the fix-up only rewrites `mapped` entries from other `mapped` entries -- nothing of the next layer's sampling reads
 // it, so the batch driver lets it ride on a later launch (FixTail) instead of giving it a launch of its own.

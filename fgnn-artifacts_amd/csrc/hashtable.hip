@@ -546,7 +546,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                        ScanWsHost *scan, bool final_fill, bool resolved, FixTail *owed_fix,
-                                       const FixTail *carry_fix) {
+                                       const FixTail *carry_fix, bool table_free) {
   if (!ht) return FGNN_EINVAL;
   if (owed_fix) *owed_fix = no_fix_tail();  // mapped != null on return: the caller owes this fill's fix-up
   FixTail carry = carry_fix && carry_fix->mapped ? *carry_fix : no_fix_tail();
@@ -573,9 +573,10 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
   bool exact = false;
-  if (!already_inserted && final_fill && mapped && scan == ht->scan && partition_fits(ht->part, ht, cap) &&
-      count_assign_grid(cap, scan) > 0) {
-    // the batch's last fill: partitioned by hash, deduplicated in LDS, the global table untouched
+  if (!already_inserted && (final_fill || table_free) && mapped && scan == ht->scan &&
+      partition_fits(ht->part, ht, cap) && count_assign_grid(cap, scan) > 0) {
+    // the batch's last fill (or any fill of a batch that never reads the table): partitioned by hash, deduplicated in
+    // LDS, the global table untouched
     const int rc = partition_fill(ht->part, ht, items, num_items, d_num_items, cap, pos, s, carry);
     if (rc != FGNN_OK) return rc;
     exact = true;
@@ -600,7 +601,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
     if (grid > 0) {
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
-                         scan->next(1, grid), final_fill && mapped != nullptr,
+                         scan->next(1, grid), (final_fill || exact) && mapped != nullptr,
                          resolved && !exact ? ht->disp : nullptr, exact);
       if (mapped) {
         const FixTail fix{mapped, d_num_items, num_items, cap, tv.pend, fix_tail_blocks(cap)};

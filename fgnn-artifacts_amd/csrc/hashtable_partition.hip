@@ -25,6 +25,10 @@
 // Streaming traffic: items read twice (2 x 1.5 MB), pairs written and read (2 x 3 MB), outcomes scattered into a
 // 1.5 MB array -- against 371 K random probes + 290 K memory-side CAS.
 //
+// The same holds for EVERY fill of a batch whose samplers do not insert into the table themselves (weighted, random
+// walk, khop1, ...: `table_free`, hashtable_fill_duplicates_ex): all their fills are partitioned, the table is never
+// read.
+//
 // Bins whose distinct keys do not fit the LDS table (a graph whose ids collide in the hash's top bits; never seen on
 // the R-MAT or power-law shapes) fall back, per bin, to the global table with the ordinary probes: a key's items all
 // sit in one bin, i.e. in one workgroup, so a workgroup barrier orders "all inserted" before "read back".
@@ -363,10 +367,12 @@ __global__ __launch_bounds__(kPartDedupThreads) void part_dedup_kernel(PartView 
         }
       }
     } else {
-      // this bin's keys through the global table (generation-tagged, ht_insert_min): the known nodes are in it already
+      // this bin's keys through the global table (generation-tagged, ht_insert_min), the known nodes with their local
+      // ids too: a batch whose fills are all partitioned has never put them there (and what an earlier fill's
+      // fall-back left pending in the table loses against the local id: min)
       for (uint32_t q = threadIdx.x; q < cnt; q += kPartDedupThreads) {
         const uint2 x = p.pairs[beg + q];
-        if (x.y & t.pend) (void)ht_insert_min(t, x.x, x.y);
+        (void)ht_insert_min(t, x.x, x.y);
       }
       __threadfence();
       __syncthreads();  // every item of these keys is this workgroup's: all inserted before any is read back
