@@ -961,12 +961,21 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
     from models import MODELS
     from samgraph.torch.adapter import CooBlock
     L = len(w["fanout"])
+    from graphed_step import GraphedSageStep
     model = MODELS["graphsage"](w["feat_dim"], 256, w["num_class"], L, 0.5).to(dev)
     loss_fcn = torch.nn.CrossEntropyLoss()
-    opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True)
+    graphed = not args.eager_train
+    opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True, capturable=graphed)
     model.train()
+    # the step replayed as a captured HIP graph (examples/graphed_step.py); --eager-train: op by op like the reference's
+    # loop.  Eager, the step is bound by the ~40 ops Python launches (0.83 ms of host time for ~0.5 ms of kernels); a
+    # replayed graph costs the host 0.12 ms and the GPU 0.58 ms.  (Every graph node costs the GPU 15-20 us on this
+    # runtime: with the 45 nodes of the op-by-op SAGEConv layers the replay took 0.93 ms and lost to eager; the fused
+    # layer of examples/models.py is what made the graph worth it -- profiles/r04_c_train_graph_vs_eager.txt.)
+    stepper = GraphedSageStep(model, opt, loss_fcn, w["batch_size"]) if graphed else None
     mode[0] = "full"
     warm, timed = train_region_batches(args.steps, args.train_steps, 1)
+    warm = max(warm, 8)  # the graphs of the usual size buckets are captured in the untimed region
     st = streams[0]
     bufs = batches[:2]
 
@@ -974,27 +983,41 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
         step, seeds = seeds_of(i)
         sampler.run_batch(i, seeds, step, bufs[i % 2], table, feat, label, stream=st)
 
+    phases = {"wait_for_batch": 0.0, "enqueue_next_batch": 0.0, "launch_step": 0.0, "wait_for_step": 0.0}
+
     def region(first, n):
         torch.cuda.synchronize()
+        for k in phases:
+            phases[k] = 0.0
         t0 = time.perf_counter()
         enqueue(first)
         for j in range(n):
             bt = bufs[(first + j) % 2]
+            ta = time.perf_counter()
             m = bt.wait()
             assert not m.overflow
-            blocks = []
-            for l in range(L):
-                row, col, nsrc, ndst = bt.graph(l)
-                blocks.append(CooBlock(row, col, nsrc, ndst))
-            x, y = bt.feat(), bt.label()
+            tb = time.perf_counter()
             # the batch's tensors are read by the step below; the next batch goes to the OTHER buffer
             if j + 1 < n:
                 enqueue(first + j + 1)
-            loss = loss_fcn(model(blocks, x), y)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            tc = time.perf_counter()
+            phases["wait_for_batch"] += tb - ta
+            phases["enqueue_next_batch"] += tc - tb
+            if stepper is not None:
+                stepper.step(bt, CooBlock)
+            else:
+                blocks = []
+                for l in range(L):
+                    row, col, nsrc, ndst = bt.graph(l)
+                    blocks.append(CooBlock(row, col, nsrc, ndst))
+                loss = loss_fcn(model(blocks, bt.feat()), bt.label())
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            td = time.perf_counter()
             torch.cuda.current_stream().synchronize()
+            phases["launch_step"] += td - tc
+            phases["wait_for_step"] += time.perf_counter() - td
         return time.perf_counter() - t0
 
     region(next_seq, warm)  # untimed: GEMM kernel selection, optimizer state, lazily loaded code objects
@@ -1002,8 +1025,12 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
     dt = region(next_seq, timed)
     next_seq += timed
     return {"ms_per_step": dt / timed * 1e3, "steps": timed,
+            "host_ms_per_step": {k: v / timed * 1e3 for k, v in phases.items()},
+            "step": ("captured HIP graph per (batch buffer, size bucket): %d graphs, %d replays, %d eager steps"
+                     % (len(stepper.graphs), stepper.replays, stepper.eager_steps)) if stepper else "eager (op by op)",
             "what": "sample + extract of batch k+1 on a side stream under the GraphSAGE step of batch k (examples/models.py: "
-                    f"{L} SAGEConv layers, hidden 256, fused Adam; aggregation by fgnn_block_aggregate), one GPU"}, next_seq
+                    f"{L} fused SAGEConv layers, hidden 256, fp32, fused Adam; aggregation by fgnn_block_aggregate), one "
+                    "GPU"}, next_seq
 
 
 def default_samplers(n_gpus):
@@ -1528,6 +1555,8 @@ def parse_args(argv=None):
                     help="N=1 extract leg: where the host feature table lives: auto / gpu = the GPU's NUMA node, node:<n>, "
                          "runtime = torch pin_memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-train", action="store_true",
+                    help="train leg: op-by-op training step instead of the captured HIP graph (examples/graphed_step.py)")
     ap.add_argument("--no-extract-leg", action="store_true", help="N=1: skip the cache-0.2 / host-miss extract leg")
     ap.add_argument("--no-overlap", action="store_true", help="one host thread, one stream, batches back to back")
     ap.add_argument("--timed-only", action="store_true",

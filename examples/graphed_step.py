@@ -1,0 +1,91 @@
+"""A GraphSAGE training step replayed as a captured HIP graph.
+
+One step on a papers100M-shaped batch is ~45 small kernels (0.5 ms of GPU time) that Python needs 0.6-1.2 ms to launch:
+the step is bound by the host (the reference trains through DGL + PyTorch eager the same way,
+example/samgraph/multi_gpu/train_graphsage.py:300-330).  A captured graph replays the whole step -- forward, loss,
+backward, fused Adam -- with one launch.  Graphs want static shapes and a batch's sizes differ from batch to batch, so:
+
+  * the step runs on the batch buffers' FULL-capacity tensors (they never move: fgnn_hip.lib.Batch.graph_buffers),
+    sliced to the batch's sizes rounded UP to a few coarse buckets -- one graph per (buffer, bucket combination), a
+    handful in practice;
+  * the edges between the real count and the bucket are pointed at an extra, discarded destination row (source row 0)
+    right before the replay, so they contribute to nothing that is kept; destination rows between the real count and
+    the bucket are computed from whatever the buffer holds and are never referenced by the next layer's real edges;
+    the loss reads the first `batch_size` output rows only.
+Arithmetic on the real rows is the eager step's (same kernels, same order; the weight-gradient GEMMs see a few padded
+all-but-irrelevant rows: they multiply rows of the upstream gradient that are exactly zero).  Batches that do not fit
+the pattern (a short last batch of an epoch, sizes beyond a buffer) run eagerly.
+"""
+import torch as th
+
+
+def _round_up(n, g):
+    return (n + g - 1) // g * g
+
+
+class GraphedSageStep:
+    def __init__(self, model, opt, loss_fcn, batch_size, edge_bucket=65536, node_bucket=32768, inner_bucket=4096):
+        """opt must be capturable (torch.optim.Adam(..., fused=True, capturable=True))."""
+        self.model, self.opt, self.loss_fcn, self.batch_size = model, opt, loss_fcn, batch_size
+        self.gE, self.gS, self.gI = edge_bucket, node_bucket, inner_bucket
+        self.graphs = {}
+        self.eager_steps = self.replays = 0
+        self._primed = False
+
+    def _eager(self, blocks, x, y):
+        loss = self.loss_fcn(self.model(blocks, x), y)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.eager_steps += 1
+        # (detached: an autograd graph of an eager step that stays alive keeps its AccumulateGrad nodes bound to the
+        # eager stream, and a later capture's backward would then run them outside the capture)
+        return loss.detach()
+
+    def step(self, bt, make_block):
+        """bt: a waited-for fgnn_hip.lib.Batch with features and labels; make_block(row, col, num_src, num_dst) builds
+        the block object the model's layers take.  Returns the loss tensor (valid until the next step)."""
+        m = bt.meta
+        L = int(m.num_layers)
+        ne = [int(m.num_edge[l]) for l in range(L)]
+        nsrc = [int(m.num_src[l]) for l in range(L)]
+        ndst = [int(m.num_dst[l]) for l in range(L)]
+        # samgraph layer numbering: layer 0 is the OUTER one (input features -> first hidden), layer L-1 ends at the seeds
+        bufs = [bt.graph_buffers(l) for l in range(L)]
+        x_full, y = bt.feat_buffer(), bt.label()
+        eb = [_round_up(max(ne[l], 1), self.gE if l == 0 else self.gI) for l in range(L)]
+        db = [_round_up(ndst[l], self.gI) if l < L - 1 else ndst[l] for l in range(L)]  # padded dst rows (+1 dummy each)
+        sb0 = _round_up(nsrc[0], self.gS)
+        fits = (self._primed and ndst[L - 1] == self.batch_size and sb0 <= x_full.shape[0]
+                and all(eb[l] <= bufs[l][0].numel() for l in range(L))
+                # padded destination rows of the outer layer must be rows the batch really has (their features enter a
+                # GEMM: no uninitialised memory there), and every layer's padded destinations must exist as its sources
+                and db[0] + 1 <= nsrc[0] and all(db[l] + 1 <= db[l - 1] + 1 for l in range(1, L)))
+        if not fits:
+            # the very first step is always eager: lazy initialisation (GEMM workspaces, the weight-gradient choice of
+            # examples/models.py, optimizer state) must not happen inside a capture
+            self._primed = True
+            blocks = [make_block(bufs[l][0][:ne[l]], bufs[l][1][:ne[l]], nsrc[l], ndst[l]) for l in range(L)]
+            return self._eager(blocks, x_full[:nsrc[0]], y)
+        # padded edges: source row 0 -> the discarded destination row db[l]
+        for l in range(L):
+            if eb[l] > ne[l]:
+                bufs[l][0][ne[l]:eb[l]].zero_()
+                bufs[l][1][ne[l]:eb[l]].fill_(db[l])
+        key = (id(bt), tuple(eb), sb0, tuple(db))
+        entry = self.graphs.get(key)
+        if entry is None:
+            blocks = [make_block(bufs[l][0][:eb[l]], bufs[l][1][:eb[l]], sb0 if l == 0 else db[l - 1] + 1, db[l] + 1)
+                      for l in range(L)]
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g):
+                out = self.model(blocks, x_full[:sb0])
+                loss = self.loss_fcn(out[:self.batch_size], y)
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self.opt.step()
+            entry = self.graphs[key] = (g, loss.detach())
+            del out, loss, blocks
+        entry[0].replay()
+        self.replays += 1
+        return entry[1]

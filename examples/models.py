@@ -17,10 +17,47 @@ if os.environ.get("FGNN_TORCH_AGGREGATE"):
     _fused_aggregate = None
 
 
+# The weight gradient of a layer, gw = gy^T z, reduces over the rows (tens of thousands of nodes) into a small matrix:
+# a handful of output tiles, so the library GEMM runs at a fraction of the chip unless the reduction is split -- a
+# batched GEMM over s row slices followed by a sum.  Which s wins is erratic (MI355X, fp32, tools/gw_microbench.py:
+# 22 500 x 256 x 256: library 111 us, s = 8 55 us, s = 32 181 us; 8 000 x 256 x 256: library 49 us, s = 8 231 us), so
+# the first call of a shape times the candidates once and the choice is kept per (rows / 2048, widths).
+_GW_CHOICE = {}
+
+
+def _gw_slices(gy, z, s):
+    m = gy.shape[0]
+    mp = (m // s) * s
+    gw = th.bmm(gy[:mp].view(s, mp // s, -1).transpose(1, 2), z[:mp].view(s, mp // s, -1)).sum(0)
+    return gw + gy[mp:].t().mm(z[mp:]) if mp < m else gw
+
+
+def _weight_grad(gy, z):
+    m = gy.shape[0]
+    if not gy.is_cuda or m < 4096 or not (gy.is_contiguous() and z.is_contiguous()):
+        return gy.t().mm(z)
+    key = (m >> 11, gy.shape[1], z.shape[1], gy.dtype)
+    s = _GW_CHOICE.get(key)
+    if s is None and th.cuda.is_current_stream_capturing():
+        s = 0  # no timing inside a capture: the library GEMM (eager steps before the capture have usually chosen already)
+    if s is None:
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        best = (float("inf"), 0)
+        for cand in (0, 8, 16, 64):
+            fn = (lambda: gy.t().mm(z)) if cand == 0 else (lambda: _gw_slices(gy, z, cand))
+            fn()
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, (e0.elapsed_time(e1), cand))
+        s = _GW_CHOICE[key] = best[1]
+    return _gw_slices(gy, z, s) if s else gy.t().mm(z)
+
+
 class _TallLinearFn(th.autograd.Function):
-    """y = x W^T + b for x with very many rows (10^5 nodes x 10^2 features).  The weight gradient gy^T x reduces over
-    the rows; the library GEMM picked for that shape is slow (0.26 ms for 88 K x 128 x 256 on MI355X), a batched GEMM
-    over 32 row slices followed by a sum takes 0.06 ms."""
+    """y = x W^T + b for x with very many rows (10^5 nodes x 10^2 features); the weight gradient through _weight_grad."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -33,14 +70,7 @@ class _TallLinearFn(th.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy.mm(weight) if ctx.needs_input_grad[0] else None
-        m, s = x.shape[0], 32
-        mp = (m // s) * s
-        if mp >= 8192 and x.is_contiguous():
-            gw = th.bmm(gy[:mp].view(s, mp // s, -1).transpose(1, 2), x[:mp].view(s, mp // s, -1)).sum(0)
-            if mp < m:
-                gw = gw + gy[mp:].t().mm(x[mp:])
-        else:
-            gw = gy.t().mm(x)
+        gw = _weight_grad(gy, x.contiguous())
         gb = gy.sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
@@ -83,6 +113,76 @@ class SAGEConvMean(nn.Module):
         return self.fc_self(h[:num_dst]) + self.fc_neigh(agg)
 
 
+class _FusedSageFn(th.autograd.Function):
+    """SAGEConv('mean') as ONE autograd node: z = [h_dst | mean_{(u->v)} h_u], out = z W^T + b with W = [W_self |
+    W_neigh].  One GEMM forward instead of two, two backward instead of four; the neighbour sums land straight in the
+    right half of z, the in-degrees are counted by the same launch (once per block), and there is no autograd
+    bookkeeping for the dozen small ops in between -- a training step is bound by the number of ops Python launches,
+    not by their GPU time (profiles/r04_c_train_*).  Same arithmetic as SAGEConvMean (fp32; the float additions of the
+    GEMM are grouped differently: rtol 1e-4)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, block, num_dst):
+        from fgnn_hip.nn import aggregate_into
+        h = h.contiguous()
+        din = h.shape[1]
+        z = th.zeros((num_dst, 2 * din), dtype=h.dtype, device=h.device)
+        inv = getattr(block, "_inv_in_degree", None)
+        deg = th.zeros(num_dst, dtype=h.dtype, device=h.device) if inv is None else None
+        aggregate_into(z[:, din:], h, block.row, block.col, in_degree=deg)
+        if inv is None:
+            inv = deg.clamp_(min=1).reciprocal_()
+            try:
+                block._inv_in_degree = inv  # a block is seen by one layer per step, forward and backward
+            except AttributeError:
+                pass
+        z[:, din:] *= inv.unsqueeze(1)
+        z[:, :din] = h[:num_dst]
+        ctx.save_for_backward(z, weight, block.row, block.col, inv)
+        ctx.num_src = h.shape[0]
+        return th.addmm(bias, z, weight.t())
+
+    @staticmethod
+    def backward(ctx, gout):
+        from fgnn_hip.nn import aggregate_into
+        z, weight, row, col, inv_deg = ctx.saved_tensors
+        gout = gout.contiguous()
+        din = z.shape[1] // 2
+        gw = _weight_grad(gout, z) if ctx.needs_input_grad[1] else None
+        gb = gout.sum(0) if ctx.needs_input_grad[2] else None
+        gh = None
+        if ctx.needs_input_grad[0]:
+            gz = gout.mm(weight)
+            gagg = gz[:, din:] * inv_deg.unsqueeze(1)  # (contiguous: a new tensor)
+            gh = aggregate_into(th.zeros((ctx.num_src, din), dtype=gz.dtype, device=gz.device), gagg, col, row)
+            gh[:z.shape[0]] += gz[:, :din]
+        return gh, gw, gb, None, None
+
+
+class FusedSAGEConv(nn.Module):
+    """SAGEConvMean with the layer's two linear maps as one weight [out, 2 in] = [W_self | W_neigh] and the whole layer
+    as one autograd node (_FusedSageFn); falls back to the op-by-op formulation off the GPU / without the HIP
+    library."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.in_feats = in_feats
+        self.weight = nn.Parameter(th.empty(out_feats, 2 * in_feats))
+        self.bias = nn.Parameter(th.zeros(out_feats))
+        for half in (self.weight[:, :in_feats], self.weight[:, in_feats:]):  # each map initialised like nn.Linear's
+            nn.init.kaiming_uniform_(half, a=5 ** 0.5)
+        bound = 1 / in_feats ** 0.5
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, block, h):
+        num_dst = block.number_of_dst_nodes()
+        if (_fused_aggregate is not None and h.is_cuda and h.dtype == th.float32
+                and getattr(block.row, "dtype", None) == th.int32 and block.col.dtype == th.int32):
+            return _FusedSageFn.apply(h, self.weight, self.bias, block, num_dst)
+        agg = _sum_to_dst(block, h) / _in_degree(block, h.dtype).clamp(min=1).unsqueeze(1)
+        return th.cat([h[:num_dst], agg], 1).mm(self.weight.t()) + self.bias
+
+
 class GraphConv(nn.Module):
     """dgl.nn.GraphConv(norm='both', allow_zero_in_degree=True) as the reference's GCN uses it
     (example/samgraph/multi_gpu/train_gcn.py:24-47): D_out^-1/2 on the sources, D_in^-1/2 on the destinations."""
@@ -123,10 +223,12 @@ class WeightedSAGEConv(nn.Module):
 
 
 class SAGE(nn.Module):
-    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout, fused=True):
         super().__init__()
         dims = [in_feats] + [n_hidden] * (n_layers - 1) + [n_classes]
-        self.layers = nn.ModuleList(SAGEConvMean(dims[i], dims[i + 1]) for i in range(n_layers))
+        # fused=False: the op-by-op layer (two nn.Linear-like maps per layer, the layout a DGL SAGEConv checkpoint has)
+        conv = FusedSAGEConv if fused else SAGEConvMean
+        self.layers = nn.ModuleList(conv(dims[i], dims[i + 1]) for i in range(n_layers))
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, blocks, x):

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(kBlock) void block_aggregate_kernel(const uint32_t 
                                                                  const uint32_t *__restrict__ dst_idx,
                                                                  const float *__restrict__ w,
                                                                  const float *__restrict__ h, float *out,
-                                                                 size_t num_edge, uint32_t dim) {
+                                                                 size_t num_edge, uint32_t dim, uint32_t out_ld,
+                                                                 float *deg) {
   const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + wave_id();
   const size_t e0 = wave * kEdgesPerWave;
   if (e0 >= num_edge) return;  // wave-uniform
@@ -37,6 +38,18 @@ __global__ __launch_bounds__(kBlock) void block_aggregate_kernel(const uint32_t 
     my_src = src_idx[e0 + lane];
     my_dst = dst_idx[e0 + lane];
     if (w) my_w = w[e0 + lane];
+  }
+  // in-degrees on the way (deg != null): the first lane of every run of equal destinations adds the run's length --
+  // one float atomic per (wave, destination) instead of an index_add_ pass of its own over the edges
+  if (deg) {
+    const uint32_t prev = __shfl_up(my_dst, 1, kWave);
+    const bool head = lane < cnt && (lane == 0 || prev != my_dst);
+    const unsigned long long heads = __ballot(head);
+    if (head) {
+      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+      const uint32_t next = later ? (uint32_t)__builtin_ctzll(later) : cnt;
+      unsafeAtomicAdd(&deg[my_dst], (float)(next - lane));
+    }
   }
   for (uint32_t dbase = 0; dbase < dim; dbase += kWave * P) {  // one trip for dim <= 64 P
     bool act[P];
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void block_aggregate_kernel(const uint32_t 
       for (uint32_t u = 0; u < UN; ++u) {
         if (i0 + u >= cnt) break;  // wave-uniform
         if (c[u] != cur) {         // wave-uniform: segment boundary, flush
-          float *op = out + (size_t)cur * dim + dbase + lane;
+          float *op = out + (size_t)cur * out_ld + dbase + lane;
 #pragma unroll
           for (int q = 0; q < P; ++q) {
             if (act[q]) unsafeAtomicAdd(op + kWave * q, acc[q]);
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void block_aggregate_kernel(const uint32_t 
         for (int q = 0; q < P; ++q) acc[q] += we[u] * v[u][q];
       }
     }
-    float *op = out + (size_t)cur * dim + dbase + lane;
+    float *op = out + (size_t)cur * out_ld + dbase + lane;
 #pragma unroll
     for (int q = 0; q < P; ++q)
       if (act[q]) unsafeAtomicAdd(op + kWave * q, acc[q]);
@@ -88,20 +101,27 @@ __global__ __launch_bounds__(kBlock) void block_aggregate_kernel(const uint32_t 
 }  // namespace
 }  // namespace fgnn
 
-extern "C" int fgnn_block_aggregate(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
-                                    size_t num_edge, const float *h, size_t dim, float *out, void *stream) {
+extern "C" int fgnn_block_aggregate_ex(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
+                                       size_t num_edge, const float *h, size_t dim, float *out, size_t out_ld,
+                                       float *in_degree, void *stream) {
   using namespace fgnn;
   if (num_edge == 0) return FGNN_OK;
-  if (!src_index || !dst_index || !h || !out || dim == 0 || dim > 0xffffffffull) return FGNN_EINVAL;
+  if (!src_index || !dst_index || !h || !out || dim == 0 || dim > 0xffffffffull || out_ld < dim || out_ld > 0xffffffffull)
+    return FGNN_EINVAL;
   auto st = static_cast<hipStream_t>(stream);
   const size_t waves = div_up(num_edge, (size_t)kEdgesPerWave);
   const size_t blocks = div_up(waves, (size_t)kWavesPerBlock);
 #define FGNN_AGG(PP)                                                                                               \
   hipLaunchKernelGGL((block_aggregate_kernel<PP>), dim3(blocks), dim3(kBlock), 0, st, src_index, dst_index,        \
-                     edge_weight, h, out, num_edge, (uint32_t)dim)
+                     edge_weight, h, out, num_edge, (uint32_t)dim, (uint32_t)out_ld, in_degree)
   if (dim <= 64) FGNN_AGG(1);
   else if (dim <= 128) FGNN_AGG(2);
   else FGNN_AGG(4);
 #undef FGNN_AGG
   return launch_status(__func__);
+}
+
+extern "C" int fgnn_block_aggregate(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
+                                    size_t num_edge, const float *h, size_t dim, float *out, void *stream) {
+  return fgnn_block_aggregate_ex(src_index, dst_index, edge_weight, num_edge, h, dim, out, dim, nullptr, stream);
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
     "fgnn_presample_count", "fgnn_presample_rank_scratch_bytes", "fgnn_presample_rank", "fgnn_cache_table_build",
-    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_batch_set_feat_row_mask",
+    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
 ]
 
 _lib = None
@@ -609,6 +609,7 @@ class Batch:
         self.feat_dim, self.feat_dtype, self.label_dtype = feat_dim, feat_dtype, label_dtype
         self.feat_rows_cap = min(feat_rows_cap, sampler.max_nodes) if feat_rows_cap else sampler.max_nodes
         self.meta = None
+        self._views = {}
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:
@@ -659,39 +660,60 @@ class Batch:
                             "cross-workgroup wait timed out")
         return m
 
-    # views of the device buffers, sized by the (waited-for) summary
+    # views of the device buffers, sized by the (waited-for) summary.  A buffer of the batch never moves: it is wrapped
+    # ONCE at its full capacity (torch.as_tensor on a __cuda_array_interface__ object costs ~25 us, eight of them per
+    # batch were a fifth of a training step's host time) and every call returns a slice of that tensor.
+    def _whole(self, key, ptr_fn, shape, dtype_code):
+        t = self._views.get(key)
+        if t is None:
+            t = self._views[key] = _wrap_device(ptr_fn(), shape, dtype_code, self.sampler.device)
+        return t
+
     def graph(self, layer):
-        m, L, dev = self.meta, load(), self.sampler.device
-        ne = int(m.num_edge[layer])
-        row = _wrap_device(L.fgnn_batch_row(self.h, layer), (ne,), I32, dev)
-        col = _wrap_device(L.fgnn_batch_col(self.h, layer), (ne,), I32, dev)
+        m, L = self.meta, load()
+        ne, cap = int(m.num_edge[layer]), self.sampler.max_edges(layer)
+        row = self._whole(("row", layer), lambda: L.fgnn_batch_row(self.h, layer), (cap,), I32)[:ne]
+        col = self._whole(("col", layer), lambda: L.fgnn_batch_col(self.h, layer), (cap,), I32)[:ne]
         return row, col, int(m.num_src[layer]), int(m.num_dst[layer])
 
+    def graph_buffers(self, layer):
+        """(row, col) of a layer at their full capacity (the buffers never move): for callers that need stable addresses
+        and sizes, e.g. a captured graph (examples/graphed_step.py); valid entries = meta.num_edge[layer]"""
+        L, cap = load(), self.sampler.max_edges(layer)
+        return (self._whole(("row", layer), lambda: L.fgnn_batch_row(self.h, layer), (cap,), I32),
+                self._whole(("col", layer), lambda: L.fgnn_batch_col(self.h, layer), (cap,), I32))
+
+    def feat_buffer(self):
+        """the feature buffer at its full capacity [feat_rows_cap, feat_dim]; valid rows = meta.num_input"""
+        return self._whole("feat", lambda: load().fgnn_batch_feat(self.h), (self.feat_rows_cap, self.feat_dim),
+                           self.feat_dtype)
+
     def graph_data(self, layer):
-        p = load().fgnn_batch_data(self.h, layer)
-        if not p:
+        L = load()
+        if not L.fgnn_batch_data(self.h, layer):
             return None
-        return _wrap_device(p, (int(self.meta.num_edge[layer]),), I32, self.sampler.device)
+        return self._whole(("data", layer), lambda: L.fgnn_batch_data(self.h, layer), (self.sampler.max_edges(layer),),
+                           I32)[:int(self.meta.num_edge[layer])]
 
     def input_nodes(self):
-        return _wrap_device(load().fgnn_batch_input_nodes(self.h), (int(self.meta.num_input),), I32,
-                            self.sampler.device)
+        return self._whole("input", lambda: load().fgnn_batch_input_nodes(self.h), (self.sampler.max_nodes,),
+                           I32)[:int(self.meta.num_input)]
 
     def output_nodes(self):
-        return _wrap_device(load().fgnn_batch_output_nodes(self.h), (int(self.meta.num_output),), I32,
-                            self.sampler.device)
+        return self._whole("output", lambda: load().fgnn_batch_output_nodes(self.h), (self.sampler.max_batch_size,),
+                           I32)[:int(self.meta.num_output)]
 
     def feat(self):
         # a batch larger than a caller-chosen feat_rows_cap carries meta.overflow and only the first cap rows
-        return _wrap_device(load().fgnn_batch_feat(self.h),
-                            (min(int(self.meta.num_input), self.feat_rows_cap), self.feat_dim),
-                            self.feat_dtype, self.sampler.device)
+        return self._whole("feat", lambda: load().fgnn_batch_feat(self.h), (self.feat_rows_cap, self.feat_dim),
+                           self.feat_dtype)[:min(int(self.meta.num_input), self.feat_rows_cap)]
 
     def label(self):
-        return _wrap_device(load().fgnn_batch_label(self.h), (int(self.meta.num_output),), self.label_dtype,
-                            self.sampler.device)
+        return self._whole("label", lambda: load().fgnn_batch_label(self.h), (self.sampler.max_batch_size,),
+                           self.label_dtype)[:int(self.meta.num_output)]
 
     def cache_index_arrays(self):
-        m, L, dev = self.meta, load(), self.sampler.device
+        m, L = self.meta, load()
         n = [int(m.num_miss), int(m.num_miss), int(m.num_cache), int(m.num_cache)]
-        return [_wrap_device(L.fgnn_batch_cache_index_ptr(self.h, k), (n[k],), I32, dev) for k in range(4)]
+        return [self._whole(("cidx", k), lambda k=k: L.fgnn_batch_cache_index_ptr(self.h, k), (self.sampler.max_nodes,),
+                            I32)[:n[k]] for k in range(4)]

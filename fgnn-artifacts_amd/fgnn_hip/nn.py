@@ -46,3 +46,21 @@ def block_aggregate(h, row, col, num_dst, edge_weight=None):
     if edge_weight is not None:
         edge_weight = edge_weight.to(torch.float32).contiguous()
     return _BlockAggregate.apply(h, row, col, edge_weight, num_dst)
+
+
+def aggregate_into(out, h, src_idx, dst_idx, edge_weight=None, in_degree=None):
+    """out[dst_idx[e]] += edge_weight[e] * h[src_idx[e]] into a caller-initialised fp32 tensor: no autograd, for layers
+    that write their own backward (examples/models.py: FusedSAGEConv).  `out` may be a column block of a wider
+    row-major matrix (unit stride inside a row); in_degree (fp32 [num_dst], caller-zeroed) receives the edge count of
+    every destination on the way."""
+    assert h.dtype == torch.float32 and out.dtype == torch.float32 and h.is_contiguous()
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[1] == h.shape[1]
+    assert src_idx.dtype == torch.int32 and dst_idx.dtype == torch.int32
+    L = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+    _lib._check(L.fgnn_block_aggregate_ex(
+        C.c_void_p(src_idx.data_ptr()), C.c_void_p(dst_idx.data_ptr()),
+        C.c_void_p(edge_weight.data_ptr()) if edge_weight is not None else None, C.c_size_t(src_idx.numel()),
+        C.c_void_p(h.data_ptr()), C.c_size_t(h.shape[1]), C.c_void_p(out.data_ptr()), C.c_size_t(out.stride(0)),
+        C.c_void_p(in_degree.data_ptr()) if in_degree is not None else None, st), "fgnn_block_aggregate_ex")
+    return out

@@ -250,6 +250,12 @@ int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_inde
  * h = grad_out.  Fastest when equal dst_index values are contiguous (the samplers' seed-major edge order). */
 int fgnn_block_aggregate(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
                          size_t num_edge, const float *h, size_t dim, float *out, void *stream);
+/* Same with a row stride for `out` (out_ld >= dim elements: the sums land in a column block of a wider matrix, e.g. the
+ * right half of [h_dst | mean h_u]) and, if in_degree != NULL, in_degree[dst_index[e]] += 1 for every edge on the way
+ * (float counts into a caller-zeroed array: the mean's denominators without a pass of their own). */
+int fgnn_block_aggregate_ex(const uint32_t *src_index, const uint32_t *dst_index, const float *edge_weight,
+                            size_t num_edge, const float *h, size_t dim, float *out, size_t out_ld, float *in_degree,
+                            void *stream);
 
 /* ---- pre-sampling cache policy (init-time) --------------------------------------------------
  * PreSampler (dist/pre_sampler.cc:75-162): freq[node] += 1 for every input node of every presample batch, then

@@ -825,6 +825,103 @@ def test_example_layers_same_with_fused_and_torch_aggregation(hip, layer):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("din,dout,first_layer", [(128, 256, True), (256, 172, False), (100, 47, False)])
+def test_fused_sage_layer_matches_the_op_by_op_layer(hip, din, dout, first_layer):
+    """examples/models.py FusedSAGEConv (one autograd node, one GEMM over [h_dst | mean h_u]) against SAGEConvMean
+    with the same weights and against the plain torch formulation without the HIP aggregation kernel: output,
+    gradients of both weight halves, the bias and (where the input needs one) the input, fp32, rtol 1e-4 (the GEMMs
+    group their additions differently).  Reference: dgl.nn.SAGEConv('mean') as train_graphsage.py:24-51 uses it."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    models = importlib.import_module("models")
+    from samgraph.torch.adapter import CooBlock
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    E, nsrc, ndst = 50003, 30000, 2500
+    row = torch.randint(0, nsrc, (E,), device="cuda", generator=g, dtype=torch.int32)
+    col = torch.sort(torch.randint(0, ndst - 7, (E,), device="cuda", generator=g, dtype=torch.int32))[0]  # 7 dst without edges
+    fused, plain = models.FusedSAGEConv(din, dout).cuda(), models.SAGEConvMean(din, dout).cuda()
+    with torch.no_grad():
+        plain.fc_self.weight.copy_(fused.weight[:, :din])
+        plain.fc_neigh.weight.copy_(fused.weight[:, din:])
+        plain.fc_neigh.bias.copy_(fused.bias)
+    x = torch.randn(nsrc, din, device="cuda", generator=g)
+    gy = torch.randn(ndst, dout, device="cuda", generator=g)
+    outs = []
+    for layer in (fused, plain):
+        h = x.clone().requires_grad_(not first_layer)
+        y = layer(CooBlock(row, col, nsrc, ndst), h)
+        y.backward(gy)
+        outs.append((y.detach(), None if first_layer else h.grad))
+    tol = dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(outs[0][0], outs[1][0], **tol)
+    if not first_layer:
+        torch.testing.assert_close(outs[0][1], outs[1][1], **tol)
+    torch.testing.assert_close(fused.weight.grad[:, :din], plain.fc_self.weight.grad, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(fused.weight.grad[:, din:], plain.fc_neigh.weight.grad, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(fused.bias.grad, plain.fc_neigh.bias.grad, rtol=1e-4, atol=2e-3)
+    # and against plain torch without any kernel of this repo
+    h2 = x.clone()
+    msg = torch.zeros((ndst, din), device="cuda").index_add_(0, col.long(), h2[row.long()])
+    deg = torch.zeros(ndst, device="cuda").index_add_(0, col.long(), torch.ones(E, device="cuda")).clamp(min=1)
+    ref = h2[:ndst] @ fused.weight[:, :din].t() + (msg / deg[:, None]) @ fused.weight[:, din:].t() + fused.bias
+    torch.testing.assert_close(outs[0][0], ref.detach(), **tol)
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_equals_the_eager_step(hip):
+    """examples/graphed_step.py: the GraphSAGE training step replayed as a captured HIP graph on the batch buffers'
+    full-capacity tensors, sizes rounded up to buckets, padded edges pointed at a discarded row -- against the same
+    steps taken op by op (the reference's loop, train_graphsage.py:300-330) from the same initial weights on the same
+    batches, dropout 0: every parameter after three steps within rtol 1e-4 (fp32; the padded rows add exact zeros to
+    the weight gradients but change how the GEMMs group their sums)."""
+    import copy
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    from graphed_step import GraphedSageStep
+    from models import SAGE
+    from samgraph.torch.adapter import CooBlock
+    from fgnn_hip import synth
+    num_node, dim, ncls, batch, fanouts = 60000, 64, 13, 512, [8, 5]
+    indptr, indices = synth.powerlaw_csr(num_node, 900000, seed=8)
+    feat = np.random.default_rng(3).standard_normal((num_node, dim)).astype(np.float32)
+    label = np.random.default_rng(4).integers(0, ncls, size=num_node).astype(np.int64)
+    d_feat, d_label = dev(feat), dev(label)
+    sampler = hip.Sampler(dev(indptr), dev(indices.copy()), fanouts, batch, sample_type=hip.KHOP2, seed=SEED)
+    bufs = [sampler.new_batch(dim, hip.F32, hip.I64) for _ in range(2)]
+    torch.manual_seed(0)
+    model_e = SAGE(dim, 32, ncls, 2, 0.0).cuda()
+    model_g = copy.deepcopy(model_e)
+    loss_fcn = torch.nn.CrossEntropyLoss()
+    opt_e = torch.optim.Adam(model_e.parameters(), lr=0.01, fused=True, capturable=True)
+    opt_g = torch.optim.Adam(model_g.parameters(), lr=0.01, fused=True, capturable=True)
+    stepper = GraphedSageStep(model_g, opt_g, loss_fcn, batch, edge_bucket=2048, node_bucket=1024, inner_bucket=256)
+    losses = []
+    for b in range(4):
+        bt = bufs[b % 2]
+        sampler.run_batch(b, dev(_seeds(batch, num_node, seed=500 + b)), b, bt, None, d_feat, d_label)
+        m = bt.wait()
+        blocks = [CooBlock(*bt.graph(l)) for l in range(2)]
+        loss_e = loss_fcn(model_e(blocks, bt.feat()), bt.label())
+        opt_e.zero_grad()
+        loss_e.backward()
+        opt_e.step()
+        loss_g = stepper.step(bt, CooBlock)
+        losses.append((float(loss_e), float(loss_g)))
+        assert int(m.num_output) == batch
+    assert stepper.eager_steps == 1 and stepper.replays == 3 and 1 <= len(stepper.graphs) <= 3
+    for le, lg in losses:
+        assert abs(le - lg) <= 1e-4 * max(1.0, abs(le)), losses
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        torch.testing.assert_close(pg, pe, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_tall_linear_matches_nn_linear():
     """examples/models.py TallLinear (weight gradient as a batched GEMM over row slices) against nn.Linear, fp32,
     rtol 1e-4."""

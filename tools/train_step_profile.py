@@ -26,12 +26,14 @@ class Block:
 dev = "cuda:0"
 g = torch.Generator(device=dev)
 g.manual_seed(0)
-# layer 0 (outer): 528 K src -> 88 K dst, 490 K edges ; layer 1: 88 K src -> 8000 dst, 80 K edges
-b0 = Block(torch.randint(0, 528000, (490000,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, 88000, (490000,), device=dev, generator=g, dtype=torch.int32))[0], 528000, 88000)
-b1 = Block(torch.randint(0, 88000, (80000,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, 8000, (80000,), device=dev, generator=g, dtype=torch.int32))[0], 88000, 8000)
-x = torch.randn(528000, 128, device=dev)
+# the papers100M-shaped R-MAT batch of bench.py: layer 0 (outer) 302 K src -> 22.5 K dst, 371 K edges; layer 1: 22.5 K src
+# -> 8000 dst, 15 K edges
+S0, D0, E0, E1 = 302000, 22500, 371000, 15000
+b0 = Block(torch.randint(0, S0, (E0,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, D0, (E0,), device=dev, generator=g, dtype=torch.int32))[0], S0, D0)
+b1 = Block(torch.randint(0, D0, (E1,), device=dev, generator=g, dtype=torch.int32), torch.sort(torch.randint(0, 8000, (E1,), device=dev, generator=g, dtype=torch.int32))[0], D0, 8000)
+x = torch.randn(S0, 128, device=dev)
 y = torch.randint(0, 172, (8000,), device=dev)
-model = SAGE(128, 256, 172, 2, 0.5).to(dev)
+model = SAGE(128, 256, 172, 2, 0.5, fused=os.environ.get('SAGE_FUSED', '1') == '1').to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=os.environ.get('ADAM_FUSED', '1') == '1')
 lossf = nn.CrossEntropyLoss()
 
@@ -52,7 +54,26 @@ for _ in range(20):
     step()
 e1.record()
 torch.cuda.synchronize()
-print("step %.3f ms" % (e0.elapsed_time(e1) / 20))
+print("step %.3f ms (SAGE_FUSED=%s)" % (e0.elapsed_time(e1) / 20, os.environ.get('SAGE_FUSED', '1')))
+# weight-gradient GEMM gy^T x at the row counts a batch's layers have: library GEMM against the 32-slice batched GEMM
+for m in (8000, 22500, 88000, 302000):
+    for (k, n) in ((128, 256), (256, 172)):
+        xx, gy = torch.randn(m, k, device=dev), torch.randn(m, n, device=dev)
+        mp = m // 32 * 32
+
+        def t(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 10 * 1e3
+        a = t(lambda: gy.t().mm(xx))
+        b = t(lambda: torch.bmm(gy[:mp].view(32, mp // 32, -1).transpose(1, 2), xx[:mp].view(32, mp // 32, -1)).sum(0))
+        print("gw %6d x %3d x %3d: mm %.1f us, 32-slice bmm + sum %.1f us" % (m, k, n, a, b))
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for _ in range(5):
         step()
