@@ -940,6 +940,33 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
         "checked": "one batch compared row by row with the direct gather",
         "numa": numa_info,
     }
+    # How good is the pre-sampler's ranking?  One more epoch of sampling, counted: the hit rate of the pre-sampler's
+    # cache on THAT epoch next to the cache that knows the epoch in advance (the reference's cache-by-fake-optimal tool,
+    # utility/data-process/toolkit/cache/cache_by_fake_optimal.cc:66-185: rank by the frequencies of the measured
+    # epochs themselves) and next to the static in-degree ranking (cache_by_degree), all at the same ratio
+    try:
+        freq2 = torch.zeros(num_node, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(streams[0]):
+            for step in range(steps_per_epoch):
+                seeds = train[step * bs:min(train.numel(), (step + 1) * bs)]
+                sampler.sample(seeds, (1 << 62) | step, bt, seq=next_seq)
+                next_seq += 1
+                lib.presample_count(freq2, bt.input_nodes_buffer(), d_num_nodes=bt.d_num_input())
+            bt.finish()
+            bt.wait()
+            total = float(freq2.sum(dtype=torch.int64))
+            f64 = freq2.to(torch.int64)
+            hit_pre = float(f64[(rank[:n_cached].to(torch.int64) & 0xFFFFFFFF)].sum()) / total
+            rank2 = lib.presample_rank(freq2)
+            hit_opt = float(f64[(rank2[:n_cached].to(torch.int64) & 0xFFFFFFFF)].sum()) / total
+            streams[0].synchronize()
+        res["hit_rate_by_policy"] = {
+            "pre_sample (1 epoch, what the leg above used)": hit_pre, "fake_optimal (hindsight on the same epoch)": hit_opt,
+            "note": "row-weighted hit rates of one further sampled epoch at cache ratio %.2f; fake_optimal ranks by that "
+                    "epoch's own frequencies (cache_by_fake_optimal.cc), an upper bound for any static cache" % args.cache_ratio}
+        del freq2, f64, rank2
+    except Exception as e:  # a secondary figure must not cost the leg
+        res["hit_rate_by_policy"] = {"error": "%s: %s" % (type(e).__name__, e)}
     for b in batches:
         lib.load().fgnn_batch_set_feat_row_mask(b.h, 0xFFFFFFFF)
     mode[0] = "full"

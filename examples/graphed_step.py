@@ -19,15 +19,22 @@ the pattern (a short last batch of an epoch, sizes beyond a buffer) run eagerly.
 import torch as th
 
 
-def _round_up(n, g):
+def _bucket(n, floor):
+    """n rounded up to eight steps per octave (at most 12.5 % padding), never finer than `floor`: batches of very
+    different sizes still fall into a handful of buckets"""
+    n = max(int(n), 1)
+    g = max(1 << max(n.bit_length() - 4, 0), floor)
     return (n + g - 1) // g * g
 
 
 class GraphedSageStep:
-    def __init__(self, model, opt, loss_fcn, batch_size, edge_bucket=65536, node_bucket=32768, inner_bucket=4096):
-        """opt must be capturable (torch.optim.Adam(..., fused=True, capturable=True))."""
+    def __init__(self, model, opt, loss_fcn, batch_size, edge_bucket=32768, node_bucket=32768, inner_bucket=4096,
+                 max_graphs=16):
+        """opt must be capturable (torch.optim.Adam(..., fused=True, capturable=True)).  *_bucket: the finest rounding
+        of edge counts / input rows / inner-layer rows; max_graphs: batches of further shapes run eagerly (a capture
+        costs ~0.1 s: a workload whose shapes never repeat must not capture per batch)."""
         self.model, self.opt, self.loss_fcn, self.batch_size = model, opt, loss_fcn, batch_size
-        self.gE, self.gS, self.gI = edge_bucket, node_bucket, inner_bucket
+        self.gE, self.gS, self.gI, self.max_graphs = edge_bucket, node_bucket, inner_bucket, max_graphs
         self.graphs = {}
         self.eager_steps = self.replays = 0
         self._primed = False
@@ -53,9 +60,9 @@ class GraphedSageStep:
         # samgraph layer numbering: layer 0 is the OUTER one (input features -> first hidden), layer L-1 ends at the seeds
         bufs = [bt.graph_buffers(l) for l in range(L)]
         x_full, y = bt.feat_buffer(), bt.label()
-        eb = [_round_up(max(ne[l], 1), self.gE if l == 0 else self.gI) for l in range(L)]
-        db = [_round_up(ndst[l], self.gI) if l < L - 1 else ndst[l] for l in range(L)]  # padded dst rows (+1 dummy each)
-        sb0 = _round_up(nsrc[0], self.gS)
+        eb = [_bucket(ne[l], self.gE if l == 0 else self.gI) for l in range(L)]
+        db = [_bucket(ndst[l], self.gI) if l < L - 1 else ndst[l] for l in range(L)]  # padded dst rows (+1 dummy each)
+        sb0 = _bucket(nsrc[0], self.gS)
         fits = (self._primed and ndst[L - 1] == self.batch_size and sb0 <= x_full.shape[0]
                 and all(eb[l] <= bufs[l][0].numel() for l in range(L))
                 # padded destination rows of the outer layer must be rows the batch really has (their features enter a
@@ -74,6 +81,9 @@ class GraphedSageStep:
                 bufs[l][1][ne[l]:eb[l]].fill_(db[l])
         key = (id(bt), tuple(eb), sb0, tuple(db))
         entry = self.graphs.get(key)
+        if entry is None and len(self.graphs) >= self.max_graphs:
+            blocks = [make_block(bufs[l][0][:ne[l]], bufs[l][1][:ne[l]], nsrc[l], ndst[l]) for l in range(L)]
+            return self._eager(blocks, x_full[:nsrc[0]], y)
         if entry is None:
             blocks = [make_block(bufs[l][0][:eb[l]], bufs[l][1][:eb[l]], sb0 if l == 0 else db[l - 1] + 1, db[l] + 1)
                       for l in range(L)]

@@ -532,6 +532,23 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
   return fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
 }
 
+// DoGPUSample + DoGetCacheMissIndex (dist_loops_arch5.cc:86-105: what an arch5 sampler does per batch) in one call, with
+// the internal sequence counter of fgnn_sampler_sample: the last layer's remap fix-up rides on the split launch
+extern "C" int fgnn_sampler_sample_indexed(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds,
+                                           uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
+                                           void *stream) {
+  if (!s) return FGNN_EINVAL;
+  uint64_t seq;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    seq = s->next_seq++;
+  }
+  fgnn::FixTail owed = fgnn::no_fix_tail();
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr);
+  if (rc == FGNN_OK && cache_table) rc = batch_cache_index(out, cache_table, stream, &owed);
+  return rc;
+}
+
 // whole batch in one call: sample -> [cache index] -> extract -> summary copy (saves host round trips per step)
 extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                                       uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,

@@ -610,9 +610,8 @@ void Engine::SampleOnceArch5() {
   s.started = Timer();
   s.started_us = RC().option_dump_trace ? Timer::NowMicro() : 0;
   s.key = key;
-  SAM_FGNN(fgnn_sampler_sample(sampler_, d_batch, bsize, key, s.fb, s.st));
   const bool use_cache = RC().UseGPUCache();
-  if (use_cache) SAM_FGNN(fgnn_batch_cache_index(s.fb, d_cache_table_, s.st));
+  SAM_FGNN(fgnn_sampler_sample_indexed(sampler_, d_batch, bsize, key, s.fb, use_cache ? d_cache_table_ : nullptr, s.st));
   // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
   void *slot = mq_->GetPtr(&s.mq_key);
   PackArgs a;

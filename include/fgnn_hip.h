@@ -340,6 +340,10 @@ void fgnn_batch_destroy(fgnn_batch *b);
  * the seed, data = random-walk visit count.  input_nodes = final unique list. */
 int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
                         fgnn_batch *out, void *stream);
+/* fgnn_sampler_sample followed by fgnn_batch_cache_index (cache_table may be NULL: sample only) as one call -- what an
+ * arch5 sampler process does per batch (dist_loops_arch5.cc:86-105); one launch fewer than the two calls. */
+int fgnn_sampler_sample_indexed(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                                fgnn_batch *out, const uint32_t *cache_table, void *stream);
 /* Thread-safe, explicitly ordered variant for overlapping batches: `seq` = 0,1,2,... is the batch's position
  * in the run; calls may come from several host threads (one per stream) in any timing, the library makes
  * khop2's in-place CSR swaps happen in `seq` order and keeps at most 6 batches in flight.  fgnn_sampler_sample
