@@ -1353,7 +1353,10 @@ def run_pipeline_rank(args, rank, world):
             dist.barrier()  # every batch of the region has been consumed
             return time.perf_counter() - t0, busy
 
-        links = link_selftest(dist, rank, world, dev_id, n_dev, args.rehearse)
+        try:
+            links = link_selftest(dist, rank, world, dev_id, n_dev, args.rehearse)
+        except Exception as e:  # a diagnostic must not cost the line (every rank raises or none: the calls are collective)
+            links = {"rccl_world": None, "error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
         region(W, False)
         del keys[:]
         elapsed, busy = region(K, False)
