@@ -75,7 +75,7 @@ def t_loop(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-if os.environ.get("FGNN_PROBE_SPLIT_UNUSED"):
+if os.environ.get("FGNN_PROBE_SPLIT"):
     n_in = int(m["num_input"]) if isinstance(m, dict) else int(m.num_input)
     print("standalone cache split, %d real input nodes: %.1f us/call" % (n_in, t_loop(lambda: bt.cache_index(table))))
     for ab in (1, 2, 4, 8, 3, 7, 15):
