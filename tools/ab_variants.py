@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--modes", default="full,sample")
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--graph", default="rmat")
+    ap.add_argument("--sample-type", default=None, help="override the workload's sample type (e.g. khop0)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--timing-variant", action="store_true",
                     help="adds a copy of the first variant whose batches record HIP events around the gather (what "
@@ -44,6 +45,8 @@ def main():
     torch.cuda.set_device(0)
     lib.load()
     w = bench.WORKLOADS[a.workload]
+    if a.sample_type:
+        w = dict(w, sample_type=a.sample_type)
     args = argparse.Namespace(graph=a.graph, workload=a.workload, seed=0x5A4D47)
     indptr, indices, num_edge, desc = bench.gen_graph(args, w, dev)
     feat = bench.gen_features_on_gpu(w["num_node"], w["feat_dim"], dev)
