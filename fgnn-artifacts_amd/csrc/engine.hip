@@ -32,11 +32,12 @@ struct fgnn_sampler {
     uint32_t *tmp_dst = nullptr;          // [max_edge_cap] sampled neighbours (global ids)
     void *ws = nullptr;                   // kernel scratch
     // `done`: the slot's last batch has finished its sampling stage; `csr`: it has enqueued its last sampler kernel
-    // (khop2 only).  Both are recorded only once somebody has needed them (see `cross_slot` / `cross_csr`).
+    // (khop2 only).  Both are recorded only where the last hand-over crossed streams (see `csr_cross` below).
     hipEvent_t done = nullptr, csr = nullptr;
     hipStream_t last_st = nullptr;        // stream of the slot's last batch
     bool was_used = false;
     bool done_recorded = false, csr_recorded = false;  // the event covers the slot's last batch
+    bool expect_cross = false;            // the slot's last reuse came from another stream: record `done` for the next
     fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
     uint32_t *rank_bitmap = nullptr;      // with-replacement samplers: seed ranking bitmap over the node ids (all zero
                                           // between batches), fgnn::RankWs
@@ -54,10 +55,11 @@ struct fgnn_sampler {
   bool csr_flag[kSlots] = {};
   // Events cost host time per batch (a record and a wait each), and most callers never need them: a single-stream
   // caller orders everything by the stream, a caller rotating over 2, 3 or 6 streams meets every slot on its own
-  // stream again.  So a slot's `done` (and the CSR hand-over `csr`) is recorded per batch only after the first time a
-  // batch found its slot (its predecessor) on ANOTHER stream; that first time is served by recording the event late,
-  // on the other stream (it then covers more than needed: correct, once).
-  std::atomic<bool> cross_slot{false}, cross_csr{false};
+  // stream again.  So a slot's `done` is recorded only if the slot's LAST reuse came from another stream, the CSR
+  // hand-over `csr` only if the last batch followed its predecessor on another stream (what happened last is the guess
+  // for what happens next); a reuse that finds no recorded event records it late, on the other stream -- it then covers
+  // more than needed: correct, and only at a change of pattern (e.g. the pre-sampling epoch's stream -> batch streams).
+  std::atomic<bool> csr_cross{false};
   // weighted_khop_prefix: 16-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
   fgnn::PrefixTreeHost *ptree = nullptr;
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 = 0 (profiling build): fused last layer
@@ -308,7 +310,7 @@ struct SeqGuard {
   // end of the slot's use by this batch: remember the stream, record `done` if slots have been seen to change streams
   void close_slot() {
     fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
-    sl.done_recorded = s->cross_slot.load(std::memory_order_relaxed) && hipEventRecord(sl.done, st) == hipSuccess;
+    sl.done_recorded = sl.expect_cross && hipEventRecord(sl.done, st) == hipSuccess;
     sl.last_st = st;
     sl.was_used = true;
   }
@@ -317,7 +319,7 @@ struct SeqGuard {
   void pass_csr(bool record_allowed) {
     if (csr_marked) return;
     fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
-    sl.csr_recorded = record_allowed && s->cross_csr.load(std::memory_order_relaxed) &&
+    sl.csr_recorded = record_allowed && s->csr_cross.load(std::memory_order_relaxed) &&
                       hipEventRecord(sl.csr, st) == hipSuccess;
     sl.last_st = st;  // read by the next call (under the mutex released in mark_csr)
     mark_csr();
@@ -382,9 +384,9 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
   out->meta_copied = false;
   // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
   // stream, by the slot's event otherwise
-  if (sl.was_used && sl.last_st != st) {
-    if (!sl.done_recorded) FGNN_HIP_CHECK(hipEventRecord(sl.done, sl.last_st));  // late: covers more than needed, once
-    s->cross_slot.store(true, std::memory_order_relaxed);
+  sl.expect_cross = sl.was_used && sl.last_st != st;
+  if (sl.expect_cross) {
+    if (!sl.done_recorded) FGNN_HIP_CHECK(hipEventRecord(sl.done, sl.last_st));  // late: covers more than needed
     FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
   }
   if (ordered && seq > 0) {
@@ -394,9 +396,10 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
       if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
     }
     fgnn_sampler::Slot &prev = s->slot[(seq - 1) % kSlots];
-    if (prev.last_st != st) {
-      if (!prev.csr_recorded) FGNN_HIP_CHECK(hipEventRecord(prev.csr, prev.last_st));  // late, once (see cross_csr)
-      s->cross_csr.store(true, std::memory_order_relaxed);
+    const bool cross = prev.last_st != st;
+    s->csr_cross.store(cross, std::memory_order_relaxed);  // this batch records its own hand-over if it needed one
+    if (cross) {
+      if (!prev.csr_recorded) FGNN_HIP_CHECK(hipEventRecord(prev.csr, prev.last_st));  // late (see csr_cross)
       FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
     }
   }

@@ -153,7 +153,7 @@ def _run_range(hip, indptr, indices, table, train, fanouts, bs, n_streams, num_b
 def test_any_number_of_streams_gives_the_serial_result(n_streams):
     """khop2's cross-batch order (in-place CSR swaps, cuda_sampling_khop2.cu:74-83) and the reuse of the sampler's six
     slots are ordered by the stream where a slot (a predecessor) comes back on the stream it ran on, by events where it
-    does not -- events that are only recorded once a batch has needed one (engine.hip, cross_slot / cross_csr).  1, 2, 3
+    does not -- events that are only recorded where the last hand-over needed one (engine.hip, expect_cross / csr_cross).  1, 2, 3
     and 6 streams never need a slot event, 4 and 5 do; every count above 1 needs the CSR event.  400 overlapping batches
     must equal the same batches on one stream, digest by digest, and leave the same CSR -- through the per-batch call
     from Python and through the native batch loop (fgnn_sampler_run_range) in ranges of 1, 7 and 64 batches."""
