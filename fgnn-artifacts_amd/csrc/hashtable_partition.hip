@@ -22,8 +22,11 @@
 // The nodes the table already knows (seeds and earlier layers' nodes: n2o[0 .. num_items)) go through the same
 // partition with value = their local id, so "already known" needs no global lookup either.  The table's `Reset` is a
 // generation bump anyway; this fill leaves the global table untouched.
-// Streaming traffic: items read twice (2 x 1.5 MB), pairs written and read (2 x 3 MB), outcomes scattered into a
-// 1.5 MB array -- against 371 K random probes + 290 K memory-side CAS.
+// Traffic: items read twice (2 x 1.5 MB), pairs written and read (2 x 3 MB), every item marked "first occurrence" in
+// item order by the scatter pass (1.5 MB, coalesced) and an outcome scattered only to the quarter of the items that are
+// not -- against 371 K random probes + 290 K memory-side CAS.  PMC per papers100M batch: 1.0 + 6.8 + 4.1 MB for the three
+// launches against 46.7 MB for the insert (profiles/r04_e_pmc_traffic.json); interleaved A/B: sampler-side stage 0.0899 ->
+// 0.0690 ms per batch (profiles/r04_a_ab_partition_vs_global.txt).
 //
 // The same holds for EVERY fill of a batch whose samplers do not insert into the table themselves (weighted, random
 // walk, khop1, ...: `table_free`, hashtable_fill_duplicates_ex): all their fills are partitioned, the table is never
