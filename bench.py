@@ -502,9 +502,12 @@ def run_single(args):
             # C++ thread too, cuda_loops_arch1.cc:38-84) -- no Python, ctypes or GIL work between two batches
             sts = streams[:stage_streams[0]] if SPT > 1 else streams[:1]
             if mode[0] == "cached":
-                ms, tm, busy = sampler.run_range(first, last - first, train, bs, batches, sts, cache_table=leg["table"],
-                                                 label=label, cache_rows=leg["cache_rows"], full_feat=leg["host_feat"],
-                                                 cached=True)
+                # four batches in flight: a batch's chain here is sampling + split + miss gather (host link, ~0.36 ms) +
+                # hit gather, and with three the link idles between miss gathers (0.309 ms per batch, 0.73 of the link;
+                # four: 0.294 / 0.77; six: 0.360 -- profiles/r04_f_extract_streams_sweep.txt)
+                ms, tm, busy = sampler.run_range(first, last - first, train, bs, leg["batches"], leg["streams"],
+                                                 cache_table=leg["table"], label=label, cache_rows=leg["cache_rows"],
+                                                 full_feat=leg["host_feat"], cached=True)
             else:
                 ms, tm, busy = sampler.run_range(first, last - first, train, bs, batches, sts, cache_table=table,
                                                  feat=feat if mode[0] == "full" else None,
@@ -880,10 +883,16 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     # the cache holds the rows the trainer would read for the cached nodes: feat[rank[i] & mask]
     cache_rows = torch.empty((n_cached, dim), dtype=torch.float32, device=dev)
     lib.gather_rows(cache_rows, feat, src_index=rank[:n_cached], src_row_mask=mask)
-    for b in batches:
+    n_leg_streams = 4 if len(streams) == 3 else len(streams)
+    leg_streams = list(streams) + [torch.cuda.Stream(device=dev) for _ in range(n_leg_streams - len(streams))]
+    leg_batches = list(batches) + [sampler.new_batch(dim, lib.F32, lib.I64)
+                                   for _ in range(max(0, 2 * n_leg_streams - len(batches)))]
+    for k, b in enumerate(leg_batches[len(batches):]):
+        b.enable_timing(k == 0)
+    for b in leg_batches:
         lib.load().fgnn_batch_set_feat_row_mask(b.h, mask)
     # what the kernels get: the device-visible address of the table (== the host address for hipHostMalloc memory)
-    leg.update(table=ptable, cache_rows=cache_rows,
+    leg.update(table=ptable, cache_rows=cache_rows, streams=leg_streams, batches=leg_batches,
                host_feat=lib.DevicePointer(table_obj.device_ptr, host_feat) if table_obj else host_feat)
     torch.cuda.synchronize()
     mode[0] = "cached"
@@ -921,8 +930,9 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     miss_bytes, hit_bytes = miss * (row_b + 8), hit * (2 * row_b + 8)
     res = {
         "workload": f"features in host memory ({1 << bits} rows, ids masked), HBM cache of {n_cached} rows "
-                    f"(ratio {args.cache_ratio}) ranked by the pre-sampler over one epoch, same batches and overlap as "
-                    "the headline",
+                    f"(ratio {args.cache_ratio}) ranked by the pre-sampler over one epoch, same batches as the headline, "
+                    f"{n_leg_streams} batches in flight",
+        "streams": n_leg_streams,
         "steps": n, "ms_per_step": dt / n * 1e3, "edges_per_s": edges / dt, "rows_per_s": rows / dt,
         "hit_rate": hit / max(rows, 1), "miss_rows_per_step": miss / n, "hit_rows_per_step": hit / n,
         "miss": {"bound": "host link", "bytes_per_step": miss * row_b / n,
