@@ -108,9 +108,10 @@ def main():
     def region_(v, n, mode):
         # the native batch loop (fgnn_sampler_run_range), like bench.py; the sampler-side stage on two streams
         first = v["seq"]
-        full = mode == "full"
-        sts = streams if full or len(streams) < 3 else streams[:2]
-        metas, _, _ = v["sampler"].run_range(first, n, train, bs, v["batches"], sts, cache_table=table,
+        full = mode in ("full", "nosplit")  # nosplit: the whole path without the cache-index split (what would merging
+        sts = streams if full or len(streams) < 3 else streams[:2]  # the split into another launch buy at most?)
+        metas, _, _ = v["sampler"].run_range(first, n, train, bs, v["batches"], sts,
+                                             cache_table=None if mode == "nosplit" else table,
                                              feat=feat if full else None, label=label if full else None)
         v["seq"] = first + n
         return sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
