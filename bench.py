@@ -744,6 +744,14 @@ def run_single(args):
                 out["cpu_baseline_products"] = cpu_baseline_products(dev)
             except Exception as e:
                 out["cpu_baseline_products"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the line is long and a log tail shows its END: the figures a reader looks for first, once more, last
+    out["summary"] = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"],
+                      "windows_ms_per_step": [round(x, 5) for x in window_ms], "steps": args.steps, "warmup": args.warmup,
+                      "host_enqueue_ms_per_step": host_enqueue_ms, "gather_frac_of_hbm_peak": out["roofline"]["frac"],
+                      "sample_stage_ms_per_step": sample_stage["ms_per_step"] if sample_stage else None,
+                      "extract_leg_ms_per_step": extract_leg.get("ms_per_step") if extract_leg else None,
+                      "train_leg_ms_per_step": train_leg.get("ms_per_step") if train_leg else None,
+                      "cpu_baseline_edges_per_s": (out.get("cpu_baseline") or {}).get("value")}
     print(json.dumps(out), flush=True)
 
 
