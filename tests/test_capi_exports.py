@@ -122,3 +122,13 @@ int main(int argc, char **argv) {
     subprocess.check_call(["gcc", "-O0", "-o", str(exe), str(src), "-ldl"])
     p = subprocess.run([str(exe), ENGINE_LIB], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr
+
+
+def test_shipped_kernel_library_reads_no_switch_from_the_environment():
+    """A stray FGNN_* variable must not change -- let alone corrupt -- a run: the shipped libfgnn_hip.so holds no such
+    name at all (A/B switches and ablation masks exist only in the profiling build, csrc/Makefile `prof`,
+    -DFGNN_PROFILING: fgnn_device.h tune_int).  (getenv itself stays imported: rocPRIM's headers, used at init time by
+    presample.hip / prefix_tree.hip / the stateless weighted entry points, read their own variables.)"""
+    from fgnn_hip import lib
+    data = open(lib.LIB_PATH, "rb").read()
+    assert b"FGNN_" not in data, "an FGNN_* name is compiled into the shipped library"
