@@ -94,7 +94,8 @@ class GraphedSageStep:
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()
                 self.opt.step()
-            entry = self.graphs[key] = (g, loss.detach())
+            # (the entry keeps the batch object alive: its graphs replay on its buffers' addresses)
+            entry = self.graphs[key] = (g, loss.detach(), bt)
             del out, loss, blocks
         entry[0].replay()
         self.replays += 1
