@@ -11,7 +11,7 @@
 // (profiles/r03_c_pmc_traffic.json), at the chip's random-request rate.  Duplicates are global (hub nodes reached from
 // everywhere: only 0.26 % of a layer's edges repeat inside the tile a sampler workgroup emits,
 // profiles/r02_b_dup_locality.txt), so a per-workgroup LDS table in front of the global one merges nothing.  What
-// works is making the table itself local: keys are split by the top bits of their hash into bins of ~1.5 K items, a
+// works is making the table itself local: keys are split by the top bits of their hash into bins of 1-2 K items, a
 // bin's items are brought together by one streaming pass, and ONE workgroup dedups a bin in a 64 KiB LDS table -- the
 // per-block hash buckets are the whole table, the global one is not touched at all:
 //   part_hist_kernel     items -> counts[workgroup][bin]      (LDS histogram per workgroup; plain stores of its row)
@@ -45,10 +45,13 @@ constexpr int kPartIPT = 4;
 constexpr int kPartTile = kPartThreads * kPartIPT;  // 4096 items per tile
 constexpr int kPartMaxBlocks = 128;               // hist / scatter workgroups (rows of the count matrix)
 constexpr int kPartDedupThreads = 512;
-constexpr int kPartRegPairs = 4;                  // pairs a dedup lane keeps in registers: bins up to 2048 items
+constexpr int kPartRegPairs = 8;                  // pairs a dedup lane keeps in registers: bins up to 4096 items
 constexpr uint32_t kPartLdsSlots = 8192;          // 64 KiB of 8-byte buckets: two workgroups per CU
 constexpr size_t kPartLdsBytes = kPartLdsSlots * sizeof(unsigned long long) + 16;  // + two counters
-constexpr uint32_t kPartPerBin = 1536;            // items per bin aimed at (distinct keys ~0.8 of that: load < 0.2)
+// items per bin aimed at (the bin count is the next power of two: bins hold 1024 .. 2048 items, ~0.8 of them distinct:
+// LDS load <= 0.2).  2048 rather than 1536: a papers100M batch (~393 K items) then always gets 256 bins; at 1536 the
+// batches straddled the 256 / 512 boundary and the 512-bin ones cost the whole path 1 % (two builds alternating)
+constexpr uint32_t kPartPerBin = 2048;
 constexpr uint32_t kPartMinLog2 = 5, kPartMaxLog2 = 11;
 constexpr uint32_t kPartHash = 0x9E3779B1u;
 
