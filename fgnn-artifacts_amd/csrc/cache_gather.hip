@@ -418,7 +418,7 @@ static bool pointer_is_host(const void *p) {
 
 int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                          const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
-                         void *stream, const GatherTail *tail_in, size_t host_grid) {
+                         void *stream, const GatherTail *tail_in, size_t host_grid, size_t wg_per_cu_in) {
   auto s = static_cast<hipStream_t>(stream);
   const GatherTail tail = tail_in ? *tail_in : GatherTail{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   if (tail_in && !gather_takes_tail(out, src, d_n ? n_cap : n, dim, dtype)) return FGNN_EINVAL;
@@ -460,7 +460,8 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
     const size_t host_wgs = (size_t)tune_int("FGNN_GATHER_HOST_WGS", (int)host_grid);  // 0: no special case
     const bool host_src = host_wgs != 0 && pointer_is_host(src);
     const int unroll = tune_int("FGNN_GATHER_UNROLL", 4);
-    const size_t wg_per_cu = (size_t)tune_int("FGNN_GATHER_WG_PER_CU", 4), cus = (size_t)device_cu_count();
+    const size_t wg_per_cu = (size_t)tune_int("FGNN_GATHER_WG_PER_CU", wg_per_cu_in ? (int)wg_per_cu_in : 4),
+                 cus = (size_t)device_cu_count();
     // non-temporal loads: gathered rows are touched once; measured 6.4 TB/s vs 4.9 TB/s with default-policy
     // loads (profiles/r01_gather_sweep.csv)
     const bool nt = tune_int("FGNN_GATHER_NT", 1) != 0;

@@ -634,7 +634,8 @@ extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *l
     tailed = make_tail(b, feat, label, &tail);
     if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
     rc = fgnn::gather_rows_ex(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
-                              b->feat_dim, b->feat_dtype, b->feat_row_mask, stream, tailed ? &tail : nullptr);
+                              b->feat_dim, b->feat_dtype, b->feat_row_mask, stream, tailed ? &tail : nullptr, 0,
+                              fgnn::kSharedGpuGatherWgPerCu);
     if (b->timing) {
       FGNN_HIP_CHECK(hipEventRecord(b->t1, st));
       b->timed = true;

@@ -703,9 +703,15 @@ struct GatherTail {
 bool gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype);
 int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                    const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask, void *stream,
-                   const GatherTail *tail, size_t host_grid = 0);
+                   const GatherTail *tail, size_t host_grid = 0, size_t wg_per_cu = 0);
 // workgroups of a host-source gather on a GPU that also runs the sampling chain (see gather_rows_ex)
 constexpr size_t kSharedGpuHostGrid = 64;
+// persistent workgroups per CU of the batch driver's HBM feature gather (the stateless entry points keep 4, which is
+// what the kernel alone likes best: 59 us against 61.5 for a papers100M batch).  With other batches' sampling chains
+// beside it, 3 leaves them the wave slots and memory requests they need: whole path 0.1067 -> 0.1027 ms per batch at a
+// gather that takes 85.6 instead of 82.4 us (twitter / uk shapes -1 % / -2 %; 2 per CU: 0.1055 and a 113 us gather) --
+// profiles/r04_h_gather_wg_per_cu.txt
+constexpr size_t kSharedGpuGatherWgPerCu = 3;
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
 // carry_fix: an owed remap fix-up; rides on the one-launch split, launched on its own on the three-launch path
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
