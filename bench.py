@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 HOST_LINK_GBS = 64.0    # PCIe Gen5 x16 per direction (secondary bound of the miss rows)
 XGMI_LINK_GBS = 153.0   # one xGMI link (sampler -> trainer peer reads)
+QUEUE_SLOTS = 170       # messages the shared queue holds at most (mq_size, memory_queue.h:46 = eng_queue.h kMaxSlots)
 
 import torch
 
@@ -1099,6 +1100,38 @@ def train_region_batches(steps, train_steps, trainers):
     return warm, timed
 
 
+def span_margins(warmup, trainers, decoupled=False):
+    """(lead, tail) batches around the timed windows of a pipeline span: consumed, stamped, not counted.  The lead is the
+    warm-up AND the queue's transient: the span starts on an empty queue, and where the trainers are the slower side
+    (every default role split at cache 0.2) the steady state is a FULL queue -- reached after about
+    slots x t_sample / (t_extract - t_sample) consumed batches, ~70 at 1S+1T and ~320 at 2S+6T; twice the queue's slots
+    covers both (340 batches of 0.05-0.45 ms each).  On separate GPUs the fill level does not change the trainers' rate;
+    where sampler and trainer SHARE one GPU (the development box) it does: 0.34 ms per batch while the queue fills,
+    0.44 once it is full (profiles/r05_b_windows_transient.txt).  tail: two batches per trainer cover the spread of the
+    trainers' finishing times."""
+    if decoupled:
+        return 1, 0
+    return max(warmup, 2 * trainers, 2 * QUEUE_SLOTS), max(warmup, 2 * trainers)
+
+
+def span_total(lead, windows, steps, tail, trainers, train):
+    """batches of one span; with a training step per batch every trainer must take the same number (all-reduce)"""
+    total = lead + windows * steps + tail
+    return (total + trainers - 1) // trainers * trainers if train else total
+
+
+def read_windows(stamps, lead, windows, steps):
+    """stamps: [(t, key)] of every consumed batch of a span, any order.  Returns (merged, [(t_begin, t_end, keys)] per
+    window): window j = the batches lead + j*steps .. lead + (j+1)*steps - 1 in consumption order, its clock runs from
+    the stamp of the batch consumed just before it to the stamp of its last batch."""
+    merged = sorted(stamps)
+    out = []
+    for j in range(windows):
+        a = lead + j * steps
+        out.append((merged[a - 1][0], merged[a + steps - 1][0], [k for _, k in merged[a:a + steps]]))
+    return merged, out
+
+
 def pipeline_roles(world, samplers=None):
     s = samplers if samplers else default_samplers(world)
     if not (0 < s < world):
@@ -1257,6 +1290,16 @@ def run_pipeline_rank(args, rank, world):
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     dev_id = local_rank % max(n_dev, 1)  # more ranks than GPUs (a functional check on one GPU): they share
+    n1_child = None
+    if rank == 0 and not (args.rehearse or args.no_n1_point or args.decoupled):
+        # started now, before this process touches the GPU; it sleeps on its stdin until the spans are done
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                            "TORCHELASTIC_RUN_ID", "FGNN_BENCH_CHILD")}
+        # FGNN_BENCH_N1_WRAP (tools): a profiler in front of the child, e.g. "rocprofv3 --kernel-trace --stats -d DIR --"
+        wrap = os.environ.get("FGNN_BENCH_N1_WRAP", "").split()
+        n1_child = subprocess.Popen(wrap + [sys.executable, os.path.abspath(__file__), "--n1-point-child"], env=env,
+                                    stdin=subprocess.PIPE, stdout=subprocess.PIPE)
     w = WORKLOADS[args.workload]
     if args.num_walks and "num_walks" in w:
         w = dict(w, num_walks=args.num_walks)
@@ -1264,7 +1307,18 @@ def run_pipeline_rank(args, rank, world):
         args.sample_type = w["sample_type"]
     bs = w["batch_size"]
     W, K = args.warmup, args.steps
-    K2W, K2 = (0, 0) if (args.no_train_leg or args.rehearse) else train_region_batches(K, args.train_steps, T)
+    # Steady-state timing (no barrier inside the measured span): one SPAN of lead + R x K + tail batches goes through the
+    # pipeline with the samplers free-running (bounded by the ring) and every trainer stamping CLOCK_MONOTONIC -- one
+    # node, one clock for all ranks -- when a batch has been consumed; rank 0 merges the stamps and reads R back-to-back
+    # windows of K consecutively consumed batches out of the middle.  `lead` covers the pipeline's fill (first message =
+    # one sample chain + one extract) and the warm-up, `tail` the drain (trainers finishing their shares at slightly
+    # different times).  The reference times the same loop per epoch (multi_gpu/train_graphsage.py:286-330).
+    R = 1 if args.decoupled else max(1, args.windows)
+    T_ = pipeline_roles(world, args.samplers)[1]
+    lead, tail = span_margins(W, T_, args.decoupled)
+    K2 = 0 if (args.no_train_leg or args.rehearse) else train_region_batches(K, args.train_steps, T_)[1]
+    total1 = span_total(lead, R, K, tail, T_, False)
+    total2 = span_total(lead, R, K2, tail, T_, True) if K2 else 0
     # ---- job-wide names from rank 0: shared-memory prefix (the processes have no common forking parent) and the
     # dataset directory
     obj = [None]
@@ -1292,12 +1346,13 @@ def run_pipeline_rank(args, rank, world):
     try:
         steps_per_epoch = (w["num_train"] + bs - 1) // bs
         min_local = steps_per_epoch // S
-        per_sampler = max(sum(split_count(n, S, 0) for n in (W, K, K2W, K2)), 1)
+        per_sampler = max(sum(split_count(n, S, 0) for n in (total1, total2)), 1)
         num_epoch = (per_sampler + min_local - 1) // min_local + 1
-        # hand-off self-check in the untimed warm-up region: every sampler checksums its first W // S messages, the
+        # hand-off self-check at the start of the span's lead: every sampler checksums its first W // S messages, the
         # trainer that receives one recomputes the sum through the address it reads the payload from (the sampler's
         # HBM slot mapped over xGMI, or the pinned host slot) and the job dies on a mismatch (eng_engine.cc)
-        check_n = W // S
+        check_n = max(W, 1) // S if W // S else 1  # a few: the receiver verifies synchronously (a long checked lead
+        # would hold the trainers back and delay the steady state the windows are read from)
         os.environ["SAMGRAPH_HANDOFF_CHECK"] = str(check_n)
         be = (RehearsalBackend if args.rehearse else EngineBackend)(args, w, job, S, T, is_sampler, idx, dev_id, num_epoch)
         dist.barrier()  # every process has attached to every shared region
@@ -1316,6 +1371,9 @@ def run_pipeline_rank(args, rank, world):
         sampled = [0]  # batches this sampler has produced
         keys = []
 
+        links, rccl_ok = link_selftest(dist, rank, world, dev_id, n_dev, args.rehearse)
+        if not rccl_ok:  # every rank has the same verdict: no region that needs RCCL
+            K2, total2 = 0, 0
         model = opt = loss_fcn = None
         if K2 and T > 1:
             # gradient all-reduce between the trainers: RCCL ("nccl") when each has its own GPU, gloo when ranks
@@ -1334,26 +1392,30 @@ def run_pipeline_rank(args, rank, world):
             opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True)
             model.train()
 
-        def region(total, train):
-            """`total` batches through the pipeline: this rank's share as a sampler (sample_once) or as a trainer
-            (get_next_batch [+ training step]); returns (wall time between the two barriers, this rank's busy time)"""
+        now = lambda: time.clock_gettime(time.CLOCK_MONOTONIC)  # noqa: E731  (one node: every rank reads the same clock)
+
+        def span(total, train):
+            """`total` batches through the pipeline with NO barrier between the first and the last: this rank's share as
+            a sampler (sample_once, free-running against the ring) or as a trainer (get_next_batch [+ training step],
+            one CLOCK_MONOTONIC stamp per consumed batch).  Returns (stamps [(t, key)], seconds in this rank's loop)."""
             mine = split_count(total, S, idx) if is_sampler else split_count(total, T, idx)
+            stamps = []
             dist.barrier()
-            t0 = time.perf_counter()
+            t0 = now()
             if is_sampler:
                 for _ in range(mine):
                     be.sample_once()
                     j = sampled[0]
                     sampled[0] += 1
                     keys.append((j // local_steps, first_step + j % local_steps))
+                loop_s = now() - t0
                 if args.decoupled:
-                    busy = time.perf_counter() - t0
                     time.sleep(0.02)  # the publisher thread publishes the last batches as their GPU work completes
                     dist.barrier()
             else:
                 if args.decoupled:
                     dist.barrier()  # diagnostic: the samplers have filled the queue, the trainers run alone
-                    t0 = time.perf_counter()
+                    t0 = now()
                 if mine:
                     be.extract_start(mine)
                 for _ in range(mine):
@@ -1365,41 +1427,48 @@ def run_pipeline_rank(args, rank, world):
                         loss.backward()
                         opt.step()
                         torch.cuda.current_stream().synchronize()
+                    stamps.append((now(), key))
                     keys.append((key // steps_per_epoch, key % steps_per_epoch))
-            if not (args.decoupled and is_sampler):
-                busy = time.perf_counter() - t0
-            dist.barrier()  # every batch of the region has been consumed
-            return time.perf_counter() - t0, busy
+                loop_s = now() - t0
+            dist.barrier()  # every batch of the span has been consumed
+            return stamps, loop_s
 
-        try:
-            links = link_selftest(dist, rank, world, dev_id, n_dev, args.rehearse)
-        except Exception as e:  # a diagnostic must not cost the line (every rank raises or none: the calls are collective)
-            links = {"rccl_world": None, "error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
-        region(W, False)
-        del keys[:]
-        elapsed, busy = region(K, False)
+        def collect(stamps, per_key):
+            """every rank's stamps and per-batch figures on rank 0 (after the span: nothing of this is timed)"""
+            got = [None] * world
+            dist.all_gather_object(got, (stamps, per_key))
+            all_stamps = [x for st, _ in got for x in st]
+            merged_pk = {}
+            for _, pk in got:
+                for k, v in pk.items():
+                    merged_pk.setdefault(k, {}).update(v)
+            return all_stamps, merged_pk
+
+        # ---- span 1: sample -> hand-off -> cached extraction
+        stamps, loop_s = span(total1, False)
         # a sampler's publisher thread logs a batch when it publishes it: all published by the barrier above
-        stats = dict(edges=0.0, rows=0.0, miss_rows=0.0, graph_bytes=0.0, ms_miss=0.0, ms_cache=0.0)
-        stats.update(be.sampler_stats(keys) if is_sampler else be.trainer_stats(keys))
-        n_batches = len(keys)
-        train_elapsed = None
+        per_key = {}
+        for e, st in keys:
+            g = e * steps_per_epoch + st
+            per_key[g] = ({"edges": be.sampler_stats([(e, st)])["edges"]} if is_sampler
+                          else be.trainer_stats([(e, st)]))
+        all_stamps, pk = collect(stamps, per_key)
+        n_produced = len(keys) if is_sampler else 0
+        del keys[:]
+        # ---- span 2: the same with a training step per consumed batch
+        train_stamps = []
         if K2:
-            region(K2W, True)  # untimed: GEMM kernel selection, optimizer state, lazily loaded code objects
+            stamps2, _ = span(total2, True)
+            train_stamps, _ = collect(stamps2, {})
             del keys[:]
-            train_elapsed, _ = region(K2, True)
 
-        # reductions: time = MAX over ranks, work = SUM over ranks; per-role busy time = MAX within the role
         def red(vals, op):
             t = torch.tensor(vals, dtype=torch.float64)
             dist.all_reduce(t, op=op)
             return [float(x) for x in t]
-        t_max, t_train, s_busy, t_busy, setup_max = red(
-            [elapsed, train_elapsed or 0.0, busy if is_sampler else 0.0, busy if not is_sampler else 0.0, t_setup],
-            dist.ReduceOp.MAX)
-        edges, rows, miss_rows, graph_bytes, ms_miss, ms_cache, nb_s, nb_t = red(
-            [stats["edges"], stats["rows"], stats["miss_rows"], stats["graph_bytes"], stats["ms_miss"],
-             stats["ms_cache"], n_batches if is_sampler else 0, n_batches if not is_sampler else 0],
-            dist.ReduceOp.SUM)
+        s_loop, t_loop, setup_max = red([loop_s if is_sampler else 0.0, loop_s if not is_sampler else 0.0, t_setup],
+                                        dist.ReduceOp.MAX)
+        nb_s, = red([n_produced], dist.ReduceOp.SUM)
         dist.barrier()  # every trainer has verified what it was going to verify
         rings = be.queue_stats(S) if rank == 0 else None  # shared counters: any process of the job can read them
         # where every rank's GPU hangs (NUMA node of its PCIe root) next to where the shared host feature table lives
@@ -1407,8 +1476,51 @@ def run_pipeline_rank(args, rank, world):
         dist.all_gather_object(gnodes, None if args.rehearse else gpu_numa_node(dev_id))
         be.shutdown()
         dist.barrier()
+        n1_point = None
         if rank == 0:
-            assert int(nb_s) == K and int(nb_t) == K, (nb_s, nb_t, K)
+            n1_point = {"value": None, "why": "control-plane rehearsal" if args.rehearse else "not requested"}
+            if n1_child is not None:
+                req = {"env": {"SAMGRAPH_SHM_PREFIX": job["prefix"] + "_n1", "SAMGRAPH_EMPTY_FEAT": str(args.empty_feat_bits),
+                               "SAMGRAPH_LOG_LEVEL": os.environ.get("SAMGRAPH_LOG_LEVEL", "warn")},
+                       "dev_id": dev_id, "dir": job["dir"], "lead": lead, "windows": R, "steps": K, "tail": tail,
+                       "steps_per_epoch": steps_per_epoch, "sample_type": args.sample_type, "batch_size": bs,
+                       "cache_ratio": args.cache_ratio, "fanout": w["fanout"], "seed": args.seed,
+                       "row_bytes": w["feat_dim"] * 4}
+                try:
+                    o, _ = n1_child.communicate((json.dumps(req) + "\n").encode(), timeout=float(
+                        os.environ.get("FGNN_BENCH_N1_TIMEOUT", "300")))
+                    lines = [ln for ln in o.decode(errors="replace").splitlines() if ln.startswith("{")]
+                    n1_point = json.loads(lines[-1]) if lines else {"value": None, "error": "rc %s" % n1_child.returncode}
+                except Exception as e:  # a secondary measurement must not cost the line
+                    n1_child.kill()
+                    n1_point = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+                n1_child = None
+        if rank == 0:
+            assert int(nb_s) == total1 and len(all_stamps) == total1, (nb_s, len(all_stamps), total1)
+            assert len({k for _, k in all_stamps}) == total1  # every batch reached exactly one trainer
+            merged, wins = read_windows(all_stamps, lead, R, K)
+            if os.environ.get("FGNN_BENCH_DUMP_STAMPS"):  # tools: every consumed batch's stamp (seconds from the first)
+                with open(os.environ["FGNN_BENCH_DUMP_STAMPS"], "w") as f:
+                    f.write("# first stamp at CLOCK_MONOTONIC %.6f\n" % merged[0][0])
+                    for t, k in merged:
+                        f.write("%.6f %d\n" % (t - merged[0][0], k))
+            win_ms = [(t1 - t0_) / K * 1e3 for t0_, t1, _ in wins]
+            order = sorted(range(R), key=lambda r: win_ms[r])
+            med = order[(R - 1) // 2]  # the median window (the slower of the middle two for an even R)
+            t_max = wins[med][1] - wins[med][0]
+            mkeys = wins[med][2]
+            edges = sum(pk[k]["edges"] for k in mkeys)
+            rows, miss_rows, graph_bytes = (sum(pk[k][n] for k in mkeys) for n in ("rows", "miss_rows", "graph_bytes"))
+            # launch averages (roofline): over the launches of ALL R windows (R x K of each kind)
+            wkeys = [k for _, _, ks in wins for k in ks]
+            rows_a, miss_rows_a, ms_miss, ms_cache = (sum(pk[k][n] for k in wkeys)
+                                                      for n in ("rows", "miss_rows", "ms_miss", "ms_cache"))
+            n_launch = len(wkeys)
+            t_train = train_win_ms = None
+            if K2:
+                _, twins = read_windows(train_stamps, lead, R, K2)
+                train_win_ms = [(t1 - t0_) / K2 * 1e3 for t0_, t1, _ in twins]
+                t_train = sorted(train_win_ms)[(R - 1) // 2] * K2 * 1e-3
             live = [r for r in rings if r]
             handoff = {"rings": rings, "check_messages_per_sampler": check_n,
                        "verified": sum(r["verified"] for r in live), "check_failed": sum(r["check_failed"] for r in live),
@@ -1426,15 +1538,24 @@ def run_pipeline_rank(args, rank, world):
             row_b = w["feat_dim"] * 4
             hit_rows = rows - miss_rows
             handoff_bytes = graph_bytes + 8 * rows + 4 * bs * K  # COO arrays + (miss|cache) index pairs + output ids
-            cache_launch_bytes = hit_rows * (2 * row_b + 8)
+            cache_launch_bytes = (rows_a - miss_rows_a) * (2 * row_b + 8)  # of all R windows' launches, like ms_cache
             out = {
                 "metric": f"sampled-edges/sec ({args.sample_type} fanout {'/'.join(map(str, w['fanout']))}, batch {bs}, "
                           "factored pipeline: sampler GPUs (sample + dedup + remap + cache-index split) -> HBM message "
-                          "ring -> trainer GPUs (cached feature extraction)); edges of the batches the trainers "
-                          "consumed / wall time",
+                          "ring -> trainer GPUs (cached feature extraction)); edges of K consecutively consumed batches "
+                          f"/ the time the trainers took to consume them, median of {R} back-to-back windows of a "
+                          "continuously full pipeline",
                 "value": edges / t_max, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
                 "ms_per_step": t_max / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "u32", "data": "synthetic" if not args.rehearse else "none (control-plane rehearsal)",
+                "windows": {"count": R, "ms_per_step": win_ms, "min": min(win_ms), "max": max(win_ms), "median_index": med,
+                            "lead_batches": lead, "tail_batches": total1 - lead - R * K, "span_batches": total1,
+                            "span_ms_per_step": (wins[-1][1] - wins[0][0]) / (R * K) * 1e3,
+                            "median_window_keys": mkeys,
+                            "clock": "CLOCK_MONOTONIC stamped by the consuming trainer after every batch; window j = "
+                                     "batches lead + jK .. lead + (j+1)K - 1 in consumption order over all trainers, from "
+                                     "the stamp of the batch before it to the stamp of its last; no barrier inside the "
+                                     "span; value / ms_per_step come from the median window"},
                 "config": {"workload": f"{args.workload}-shaped synthetic graph: {info[0]['graph']}; N={w['num_node']}, "
                                        f"E={info[0]['num_edge']}, train set {w['num_train']} uniform random ids (seed 1), "
                                        f"{args.sample_type} fanout {w['fanout']}, batch {bs}; features in host memory "
@@ -1446,14 +1567,18 @@ def run_pipeline_rank(args, rank, world):
                              "achieved": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 if ms_cache else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cache else None,
-                             "traffic": None, "avg_launch_ms": ms_cache / K,
-                             "algorithmic_bytes_per_launch": cache_launch_bytes / K,
+                             "traffic": None, "avg_launch_ms": ms_cache / n_launch, "timed_launches": n_launch,
+                             "algorithmic_bytes_per_launch": cache_launch_bytes / n_launch,
                              "note": "hit rows x (row read + row write + 2 index words) / HIP-event time of the launch, "
                                      "summed over the trainers' batches"},
                 "pipeline": {
                     "samplers": S, "trainers": T, "devices": min(n_dev, world),
-                    "sampler_side_edges_per_s": edges / s_busy if s_busy else None,
-                    "sampler_busy_s": s_busy, "trainer_busy_s": t_busy,
+                    "sampler_loop_ms_per_batch": s_loop / max(split_count(total1, S, 0), 1) * 1e3,
+                    "trainer_loop_ms_per_batch": t_loop / max(split_count(total1, T, 0), 1) * 1e3,
+                    "loop_note": "wall time of a rank's whole span loop / its batches (MAX within the role): a sampler's "
+                                 "includes its waits on a full ring, a trainer's its waits on an empty one -- each "
+                                 "stage ALONE only with --decoupled",
+                    "sampler_busy_s": s_loop, "trainer_busy_s": t_loop,
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
                     "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff, "links": links,
@@ -1461,26 +1586,28 @@ def run_pipeline_rank(args, rank, world):
                              "host_feat_policy": os.environ.get("SAMGRAPH_HOST_FEAT_NUMA",
                                                                 "interleave over the nodes with memory (default)"),
                              "note": "every trainer pulls its miss rows out of ONE shared host table (DESIGN 6)"},
-                    "n1_point_of_this_curve": "N = 1 runs config 2's shape (features HBM-resident, no hand-off); the "
-                                              "like-for-like N = 1 point of THIS pipeline (host-memory features behind a "
-                                              f"{args.cache_ratio} cache, one GPU doing both halves) is the N = 1 line's "
-                                              "`pipeline_n1_point.value` (= edges_per_step / roofline_extract.ms_per_step)",
+                    "n1_point_of_this_curve": n1_point,
                     "miss": {"bound": "host link", "bytes_per_step": miss_rows * row_b / K,
                              "achieved": miss_rows * row_b / t_max / 1e9 / T, "peak": HOST_LINK_GBS,
                              "unit": "GB/s per trainer GPU", "frac": miss_rows * row_b / t_max / 1e9 / T / HOST_LINK_GBS,
-                             "avg_launch_ms": ms_miss / K,
-                             "launch_GBps": miss_rows * row_b / (ms_miss * 1e-3) / 1e9 if ms_miss else None},
+                             "avg_launch_ms": ms_miss / n_launch,
+                             "launch_GBps": miss_rows_a * row_b / (ms_miss * 1e-3) / 1e9 if ms_miss else None},
                 },
                 "epoch_time_s": {"sample_plus_extract": steps_per_epoch * t_max / K,
                                  "with_training": steps_per_epoch * t_train / K2 if K2 else None,
-                                 "training_steps_timed": K2,
-                                 "note": f"{steps_per_epoch} steps/epoch x seconds per step of the region; with_training "
+                                 "training_steps_timed": K2, "training_windows_ms_per_step": train_win_ms,
+                                 "note": f"{steps_per_epoch} steps/epoch x seconds per step of the median window; with_training "
                                          "= the same pipeline with a GraphSAGE step (examples/models.py, hidden 256, "
                                          "Adam) on every batch, gradients all-reduced over RCCL between trainers"},
                 "edges_per_step": edges / K, "input_nodes_per_step": rows / K, "setup_s": setup_max,
             }
             print(json.dumps(out), flush=True)
     finally:
+        if n1_child is not None:  # never asked (an error above): an empty line ends it
+            try:
+                n1_child.communicate(b"\n", timeout=30)
+            except Exception:
+                n1_child.kill()
         try:
             dist.barrier()
         except Exception:
@@ -1497,38 +1624,82 @@ def run_pipeline_rank(args, rank, world):
     dist.destroy_process_group()
 
 
-def link_selftest(dist, rank, world, dev_id, n_dev, rehearse):
-    """First-contact proof for N >= 2, run once in the untimed warm-up: ONE RCCL all-reduce over ALL ranks (samplers
+def limited_collective(dist, world, body, limit_s):
+    """`body` (collective calls that may never return when a peer has failed) on a helper thread; this rank waits for
+    ITS OWN thread for at most limit_s seconds, then every rank learns over the job's gloo group who finished.
+    Returns (body's result | None, {rank: reason} of the ranks that did not finish -- the same dict on every rank)."""
+    import threading
+    res = {}
+
+    def run():
+        try:
+            res["rec"] = body()
+        except Exception as e:
+            res["err"] = "%s: %s" % (type(e).__name__, e)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(limit_s)
+    mine = None if "rec" in res else res.get("err", "no answer within %.0f s" % limit_s)
+    status = [None] * world
+    dist.all_gather_object(status, mine)  # gloo: works whatever the helper thread is stuck in
+    return res.get("rec"), {r: e for r, e in enumerate(status) if e is not None}
+
+
+def link_selftest(dist, rank, world, dev_id, n_dev, rehearse, limit_s=None):
+    """First-contact proof for N >= 2, run once before the timed span: ONE RCCL all-reduce over ALL ranks (samplers
     included: `rccl_world` == world says RCCL saw every rank; the data path itself has no collective), its bus
     bandwidth on a 64 MiB payload, and the peer-access matrix between the ranks' GPUs (what the trainers' peer reads of
     the samplers' HBM rings rest on).  With fewer GPUs than ranks RCCL refuses (two ranks on one device): recorded as
-    such, nothing is faked.  Every rank takes part (new_group is a collective call); rank 0 gets the record."""
+    such, nothing is faked.  Every rank takes part; rank 0 gets the record.
+
+    A rank whose RCCL initialisation fails ALONE must not leave the others inside a collective: the RCCL calls run on a
+    helper thread, every rank waits for ITS OWN thread for at most `limit_s` seconds, then all ranks agree over gloo on
+    who finished; on any failure every rank aborts its communicator (ncclCommAbort ends a kernel that waits for a peer)
+    and the record says which ranks failed and why.  Returns (record on rank 0 | None, rccl_ok on every rank)."""
     import datetime
+    if limit_s is None:
+        limit_s = float(os.environ.get("FGNN_BENCH_LINK_TIMEOUT", "90"))
     if rehearse:
-        return {"rccl_world": None, "why": "control-plane rehearsal: no GPU work"}
+        return {"rccl_world": None, "why": "control-plane rehearsal: no GPU work"}, True
+    ok = True
     if n_dev < world:
-        grp = None
         rec = {"rccl_world": None, "why": "%d ranks share %d GPU(s): RCCL needs a device per rank" % (world, n_dev)}
     else:
-        grp = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=300))
+        grp = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=limit_s + 30))
         dev = torch.device("cuda", dev_id)
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one, group=grp)
-        torch.cuda.synchronize(dev)
-        buf = torch.ones(16 << 20, dtype=torch.float32, device=dev)  # 64 MiB
-        dist.all_reduce(buf, group=grp)  # first use of the size
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            dist.all_reduce(buf, group=grp)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / 5
-        nbytes = buf.numel() * 4
-        rec = {"rccl_world": int(round(float(one.item()))), "allreduce_64MiB_ms": dt * 1e3,
-               "allreduce_busbw_GBps": 2 * (world - 1) / world * nbytes / dt / 1e9,
-               "note": "one all-reduce over all ranks in the warm-up (samplers too); busbw = 2(n-1)/n x bytes / time"}
-        del buf, one
+
+        def body():
+            torch.cuda.set_device(dev)
+            if os.environ.get("FGNN_BENCH_LINK_FAIL_RANK") == str(rank):  # tests: this rank fails alone
+                raise RuntimeError("injected failure (FGNN_BENCH_LINK_FAIL_RANK)")
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one, group=grp)
+            torch.cuda.synchronize(dev)
+            buf = torch.ones(16 << 20, dtype=torch.float32, device=dev)  # 64 MiB
+            dist.all_reduce(buf, group=grp)  # first use of the size
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(buf, group=grp)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / 5
+            nbytes = buf.numel() * 4
+            return {"rccl_world": int(round(float(one.item()))), "allreduce_64MiB_ms": dt * 1e3,
+                    "allreduce_busbw_GBps": 2 * (world - 1) / world * nbytes / dt / 1e9,
+                    "note": "one all-reduce over all ranks before the span (samplers too); busbw = 2(n-1)/n x "
+                            "bytes / time (ranks enter the timed loop unsynchronised: a lower bound)"}
+        res, bad = limited_collective(dist, world, body, limit_s)
+        if bad:
+            ok = False
+            try:  # end whatever this rank's thread still has in flight
+                grp._get_backend(dev).abort()
+            except Exception:
+                pass
+            rec = {"rccl_world": None, "error": "RCCL self-test failed", "failed_ranks": {str(r): e for r, e in bad.items()},
+                   "limit_s": limit_s, "consequence": "the training region (gradient all-reduce over RCCL) is skipped; the "
+                                                      "data path has no collective and is measured as usual"}
+        else:
+            rec = res
     # row of the peer matrix for this rank's GPU: which other ranks' GPUs it can map
     row = []
     for r in range(world):
@@ -1541,7 +1712,60 @@ def link_selftest(dist, rank, world, dev_id, n_dev, rehearse):
     dist.all_gather_object(rows, row)
     rec["peer_access"] = {"matrix": rows, "note": "matrix[i][j]: rank i's GPU can map rank j's GPU memory "
                                                   "(hipDeviceCanAccessPeer); ranks sharing a GPU read True"}
-    return rec if rank == 0 else None
+    return (rec if rank == 0 else None), ok
+
+
+# ---- the like-for-like N = 1 point of the N >= 2 pipeline, measured inside the same job ------------------------------
+def run_n1_point_child():
+    """Child of rank 0 of an N >= 2 job, started BEFORE rank 0 touched the GPU (a process that has initialised the GPU
+    never starts another program); waits for one JSON request on stdin -- sent after the job's spans, when the ranks have
+    shut their engines down -- then runs the SAME pipeline on ONE GPU: the engine's arch3 (sampler and extractor halves
+    of arch5 in one process, background threads, in-process ring; the reference's default single-GPU mode,
+    cuda_loops_arch3.cc) on the job's dataset, features in host memory behind the same pre-sample cache, timed by the
+    same stamps-and-windows rule.  Prints one JSON line."""
+    line = sys.stdin.readline()
+    if not line.strip():
+        return
+    if os.environ.get("FGNN_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FGNN_BENCH_WATCHDOG"]), exit=True)
+    req = json.loads(line)
+    for k, v in req["env"].items():
+        os.environ[k] = v
+    import samgraph.torch as sam
+    torch.cuda.set_device(req["dev_id"])
+    ctx = "cuda:%d" % req["dev_id"]
+    lead, R, K, tail = req["lead"], req["windows"], req["steps"], req["tail"]
+    total = lead + R * K + tail
+    spe = req["steps_per_epoch"]
+    cfg = dict(dataset_path=req["dir"], _arch=sam.kArch3, _sample_type=sam.sample_types[req["sample_type"]],
+               batch_size=req["batch_size"], num_epoch=(total + spe - 1) // spe + 1,
+               _cache_policy=sam.cache_policies["pre_sample"], presample_epoch=1, cache_percentage=req["cache_ratio"],
+               max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8, sampler_ctx=ctx, trainer_ctx=ctx,
+               num_fanout=len(req["fanout"]), fanout=req["fanout"], seed=req["seed"])
+    sam.config(cfg)
+    t0 = time.time()
+    sam.init()
+    setup = time.time() - t0
+    sam.start()
+    stamps = []
+    for _ in range(total):
+        key = sam.get_next_batch()
+        stamps.append((time.clock_gettime(time.CLOCK_MONOTONIC), key))
+    _, wins = read_windows(stamps, lead, R, K)
+    win_ms = [(b - a) / K * 1e3 for a, b, _ in wins]
+    med = sorted(range(R), key=lambda r: win_ms[r])[(R - 1) // 2]
+    edges = sum(sam.get_log_step_value(k // spe, k % spe, sam.kLogL1NumSample) for k in wins[med][2])
+    rows = sum(sam.get_log_step_value(k // spe, k % spe, sam.kLogL1FeatureBytes) for k in wins[med][2]) / req["row_bytes"]
+    miss = sum(sam.get_log_step_value(k // spe, k % spe, sam.kLogL1MissBytes) for k in wins[med][2]) / req["row_bytes"]
+    out = {"value": edges / (wins[med][1] - wins[med][0]), "unit": "edges/s", "n_gpus": 1, "ms_per_step": win_ms[med],
+           "windows_ms_per_step": win_ms, "steps": K, "hit_rate": (rows - miss) / max(rows, 1.0), "setup_s": setup,
+           "what": "the same pipeline on ONE GPU of this job: arch3 through samgraph.torch / c_lib.so (sampler + extractor "
+                   "threads in one process, in-process ring), same dataset, features in host memory behind the same "
+                   "pre-sample cache, same windows rule -- the like-for-like N = 1 point of this line (the N = 1 "
+                   "bench line itself is config 2's shape: features HBM-resident)"}
+    print(json.dumps(out), flush=True)
+    sam.shutdown()
 
 
 def launch_ranks(args):
@@ -1592,7 +1816,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=151)   # one papers100M epoch at batch 8000
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--windows", type=int, default=5,
-                    help="N=1: timed windows of --steps steps each, back to back; `value` is the median window's")
+                    help="timed windows of --steps steps each, back to back; `value` is the median window's")
     ap.add_argument("--workload", default=os.environ.get("FGNN_BENCH_WORKLOAD", "papers100M"), choices=list(WORKLOADS))
     ap.add_argument("--graph", default=os.environ.get("FGNN_BENCH_GRAPH", "rmat"), choices=["rmat", "powerlaw"],
                     help="rmat: SURVEY.md 8(d)'s generator (default); powerlaw: round 1's locality-free generator")
@@ -1622,6 +1846,10 @@ def parse_args(argv=None):
                          "samplers fill the queue first, then the trainers drain it -- sampler_busy_s and trainer_busy_s "
                          "are then each stage's time ALONE; needs steps <= queue slots (set "
                          "SAMGRAPH_DEVICE_RING_SLOTS >= steps to keep the payloads in HBM)")
+    ap.add_argument("--no-n1-point", action="store_true",
+                    help="N>=2: skip the like-for-like N = 1 point (the same pipeline on one GPU, run by a child of rank "
+                         "0 after the spans)")
+    ap.add_argument("--n1-point-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rehearse", action="store_true",
                     help="N>=2 without a GPU: launcher, rendezvous, roles, step ranges, the real shared ring and the "
                          "reductions with empty batches (tests); measures nothing")
@@ -1643,6 +1871,8 @@ def main():
     # (samgraph_config sets the same default; here it also covers the torch side of a trainer rank)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args = parse_args()
+    if args.n1_point_child:
+        return run_n1_point_child()
     if args.cpu_only:
         dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
         r = cpu_baseline_products(dev, budget_s=10.0)

@@ -400,6 +400,13 @@ extern "C" int fgnn_gather_rows_masked(void *out, const void *src, const uint32_
   return fgnn::gather_rows_ex(out, src, src_index, dst_index, n, d_n, n_cap, dim, dtype, src_row_mask, stream, nullptr);
 }
 
+extern "C" int fgnn_gather_rows_shared(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index,
+                                       size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype,
+                                       uint32_t src_row_mask, int shared_gpu, void *stream) {
+  return fgnn::gather_rows_ex(out, src, src_index, dst_index, n, d_n, n_cap, dim, dtype, src_row_mask, stream, nullptr,
+                              shared_gpu ? fgnn::kSharedGpuHostGrid : 0);
+}
+
 bool fgnn::gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype) {
   const size_t row_bytes = dim * dtype_bytes(dtype);
   return row_bytes && row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&

@@ -40,8 +40,9 @@ struct RunConfig {
   bool option_dump_trace = false, option_sanity_check = false;
   size_t option_empty_feat = 0;
   size_t mq_budget_bytes = 8ull << 30;  // SAMGRAPH_MQ_BYTES: total size of the shared queue
-  // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h).  Unset: 4 where sampler and
-  // extractor share a process (arch2-4, arch6: a plain device pointer); for arch5 as many as the host ring has slots
+  // SAMGRAPH_DEVICE_RING_SLOTS: message slots per sampler in its HBM (eng_queue.h).  Unset: as many as the queue has
+  // slots -- max(max_sampling_jobs, 8) where sampler and extractor share a process (arch2-4, arch6: a plain device
+  // pointer; CreateDeviceRing clamps to the queue's size), for arch5 as many as the host ring has slots
   // (170 x ~46 MB = 7.8 GB of the 288 at [25,10] x 8000; mapped by the trainers with hipIpc, a trainer that cannot map
   // it makes the whole job fall back to the host ring): whenever the trainers are the slower side the queue fills up,
   // and with fewer device slots than queue slots the surplus messages would travel through pinned host memory -- over
@@ -49,7 +50,7 @@ struct RunConfig {
   long device_ring_slots = -1;
   size_t DeviceRingSlots() const {
     if (device_ring_slots >= 0) return (size_t)device_ring_slots;
-    return run_arch == kArch5 ? 170 : 4;
+    return 170;  // clamped to the queue's slots (MemoryQueue::CreateDeviceRing)
   }
 
   bool UseGPUCache() const { return cache_percentage > 0 && run_arch != kArch1; }  // run_config.h:84-86

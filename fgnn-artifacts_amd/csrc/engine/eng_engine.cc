@@ -63,7 +63,7 @@ std::shared_ptr<GraphBatch> GraphPool::Get() {
 
 void GraphPool::Submit(std::shared_ptr<GraphBatch> b) {
   std::lock_guard<std::mutex> lk(mu_);
-  SAM_CHECK(!stop_);
+  if (stop_) return;  // shutdown while the extractor still had a batch in its hands: nobody will ask for it
   q_.push(std::move(b));
 }
 
@@ -127,8 +127,39 @@ void Engine::CreateQueue() {
   size_t slot = MaxMessageBytes(RC().batch_size, RC().fanout.data(), RC().fanout.size(), have_data);
   size_t slots = RC().mq_budget_bytes / slot;
   if (slots > kMaxSlots) slots = kMaxSlots;
+  // sampler and extractor in ONE process (arch2-4, arch6): the reference joins them by a TaskQueue of max_sampling_jobs
+  // tasks (cuda_engine.cc:142), not by the 170-slot shared-memory queue of arch5 -- and a sampler that may run 170
+  // batches ahead parks their payloads in pinned host memory once its few HBM slots are taken (RunConfig::
+  // DeviceRingSlots), over the link the extractor's miss rows need.  The extractor keeps kExtractDepth messages in
+  // flight and the sampler two: below that depth the two halves would wait for each other's slots
+  if (RC().run_arch != kArch5) slots = std::min(slots, std::max<size_t>(RC().max_sampling_jobs, kExtractDepth + 4));
   if (slots < 2) slots = 2;
   mq_ = new MemoryQueue(slot, slots);
+}
+
+// batch buffers of the message-producing sampler loop (arch5 sampler process, in-process archs): `slots` buffers rotating
+// over `streams` HIP streams -- the chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has
+// to stay ordered with events); one batch alone cannot fill the chip.  SAMGRAPH_SAMPLER_STREAMS / _SLOTS override.
+void Engine::CreateSamplerSlots(size_t streams, size_t slots) {
+  const char *e_slots = getenv("SAMGRAPH_SAMPLER_SLOTS"), *e_streams = getenv("SAMGRAPH_SAMPLER_STREAMS");
+  const size_t n_streams = e_streams && atoi(e_streams) > 0 ? (size_t)atoi(e_streams) : streams;
+  slots_.resize(e_slots && atoi(e_slots) > 0 ? (size_t)atoi(e_slots) : e_streams ? 3 * n_streams : slots);
+  for (size_t i = 0; i < slots_.size(); ++i) {
+    Slot &s = slots_[i];
+    int err = 0;
+    s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
+    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
+    if (i < n_streams) {
+      SAM_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    } else {
+      s.st = slots_[i % n_streams].st;
+      s.owns_st = false;
+    }
+    SAM_HIP(hipEventCreate(&s.e0));
+    SAM_HIP(hipEventCreate(&s.e1));
+    SAM_HIP(hipEventCreate(&s.e2));
+    if (s.owns_st) shuffler_->TrackStream(s.st);  // batches in flight read the epoch's seed array
+  }
 }
 
 void Engine::UploadTopology(int device) {
@@ -257,19 +288,8 @@ void Engine::InitInProcess() {
   shuffler_.reset(new Shuffler(static_cast<const uint32_t *>(ds_.train_set.ptr), ds_.num_train, RC().num_epoch,
                                RC().batch_size, 0, 1, stream_));
   if (RC().option_sanity_check) shuffler_->EnableSanityCheck(ds_.num_node);
-  slots_.resize(dynamic ? 0 : 2);  // the dynamic-cache loop (eng_dynamic.cc) hands batches over in process, no messages
-  for (auto &s : slots_) {
-    int err = 0;
-    s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
-    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
-    // a stream per slot: the chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to
-    // stay ordered with events); one batch alone cannot fill the chip
-    SAM_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-    SAM_HIP(hipEventCreate(&s.e0));
-    SAM_HIP(hipEventCreate(&s.e1));
-    SAM_HIP(hipEventCreate(&s.e2));
-    shuffler_->TrackStream(s.st);
-  }
+  // the dynamic-cache loop (eng_dynamic.cc) hands batches over in process, no messages
+  if (!dynamic) CreateSamplerSlots(kInProcessSamplerStreams, kInProcessSamplerSlots);
   if (RC().UseGPUCache()) {
     Timer tp;
     if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) PreSample();
@@ -413,25 +433,7 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   // side is bound by khop2's order chain, and a third batch in flight only slows the chain's kernels down
   // (profiles/r03_sampler_streams_sweep.txt: 81.2 us per batch with 2 streams / 6 buffers, 85.4 with 3 / 6, 88.6 with
   // 4 / 8, 121.7 with 1 / 2)
-  const char *e_slots = getenv("SAMGRAPH_SAMPLER_SLOTS"), *e_streams = getenv("SAMGRAPH_SAMPLER_STREAMS");
-  const size_t n_streams = e_streams && atoi(e_streams) > 0 ? (size_t)atoi(e_streams) : 2;
-  slots_.resize(e_slots && atoi(e_slots) > 0 ? (size_t)atoi(e_slots) : 3 * n_streams);
-  for (size_t i = 0; i < slots_.size(); ++i) {
-    Slot &s = slots_[i];
-    int err = 0;
-    s.fb = fgnn_batch_create(sampler_, 0, FGNN_F32, FGNN_I64, 0, &err);
-    SAM_CHECK(s.fb) << "fgnn_batch_create failed: " << err << " " << fgnn_last_error();
-    if (i < n_streams) {
-      SAM_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
-    } else {
-      s.st = slots_[i % n_streams].st;
-      s.owns_st = false;
-    }
-    SAM_HIP(hipEventCreate(&s.e0));
-    SAM_HIP(hipEventCreate(&s.e1));
-    SAM_HIP(hipEventCreate(&s.e2));
-    if (s.owns_st) shuffler_->TrackStream(s.st);  // batches in flight read the epoch's seed array
-  }
+  CreateSamplerSlots(2, 6);
   if (RC().UseGPUCache()) {
     Timer tp;
     if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) {
@@ -614,6 +616,7 @@ void Engine::SampleOnceArch5() {
   SAM_FGNN(fgnn_sampler_sample_indexed(sampler_, d_batch, bsize, key, s.fb, use_cache ? d_cache_table_ : nullptr, s.st));
   // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
   void *slot = mq_->GetPtr(&s.mq_key);
+  if (!slot) return;  // this process is shutting down (MemoryQueue::Close): the batch is dropped, Shutdown syncs its stream
   PackArgs a;
   memset(&a, 0, sizeof(a));
   a.d_meta = fgnn_batch_device_meta(s.fb);
@@ -729,9 +732,38 @@ void Engine::BuildTrainerCache() {
 // parsed and its ~10 copies are enqueued, and the GPU idles while the host waits.
 void Engine::TrainerOnce() {
   SAM_HIP(hipSetDevice(tdevice_));
-  while (pool_->Full()) std::this_thread::sleep_for(std::chrono::microseconds(1));
+  while (pool_->Full() && !shutdown_) std::this_thread::sleep_for(std::chrono::microseconds(1));
+  if (shutdown_) return;
   TrainerIssue(xctx_[0], nullptr, 0);
-  TrainerComplete(xctx_[0]);
+  if (xctx_[0].b) TrainerComplete(xctx_[0]);
+}
+
+// The extractor's loop (StartExtract's thread of an arch5 trainer, samgraph_start's copy thread of arch2 / arch3):
+// up to kExtractDepth batches in flight.  A further message is taken only when one is PUBLISHED (TryRecv never waits):
+// a trainer that blocked for a message while holding unreleased queue slots could wait for a sampler that is itself
+// waiting for one of those slots (few slots: large fan-outs under SAMGRAPH_MQ_BYTES, many trainers).  With nothing in
+// flight the thread holds no slot and may block like the reference's loop does.
+void Engine::ExtractLoop(size_t count) {
+  SAM_HIP(hipSetDevice(tdevice_));
+  size_t issued = 0;
+  int head = 0, inflight = 0;
+  while ((issued < count || inflight) && !shutdown_) {
+    if (issued < count && inflight < kExtractDepth) {
+      const void *msg = nullptr;
+      size_t key = 0;
+      if (inflight == 0 || mq_->TryRecv(&msg, &key)) {
+        ExtractCtx &x = xctx_[(head + inflight) % kExtractDepth];
+        TrainerIssue(x, msg, key);
+        if (!x.b) break;  // the queue was closed under a blocking receive: this process is shutting down
+        ++inflight;
+        ++issued;
+        continue;
+      }
+    }
+    TrainerComplete(xctx_[head]);
+    head = (head + 1) % kExtractDepth;
+    --inflight;
+  }
 }
 
 // `msg` null: block for the next message (the caller holds no queue slot); else the message TryRecv handed out
@@ -742,6 +774,10 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
   Timer t_recv;
   size_t mq_key = taken_key;
   const char *msg = static_cast<const char *>(taken ? taken : mq_->Recv(&mq_key));
+  if (!msg) {  // MemoryQueue::Close
+    x.b.reset();
+    return;
+  }
   const double recv_time = t_recv.Passed();
   Timer t_copy;
   TransData hdr;
@@ -870,8 +906,8 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
   size_t miss_rows = num_miss;
   bool timed_gathers = false;
   if (!use_cache) {
-    SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
-                                     ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
+    SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
+                                     ds_.feat_dim, FGNN_F32, FeatRowMask(), ExtractorSharesGpu(), tstream_));
     miss_rows = hdr.input_size;
   } else if (dist_type_ == DistType::Switch) {
     // own (smaller) cache: split on this GPU with device-side counts
@@ -884,15 +920,15 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
     SAM_FGNN(fgnn_get_miss_cache_index(d_cache_table_, d_input, n, nullptr, n, idx[0], idx[1], idx[2], idx[3], d_counts,
                                        ws, ws_bytes, tstream_));
-    SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32,
-                                     FeatRowMask(), tstream_));
+    SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32,
+                                     FeatRowMask(), ExtractorSharesGpu(), tstream_));
     SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
                               tstream_));
   } else {
     SAM_HIP(hipEventRecord(te_[0], tstream_));
     if (num_miss)   // CombineMissData with the host fetch fused in
-      SAM_FGNN(fgnn_gather_rows_masked(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss,
-                                       ds_.feat_dim, FGNN_F32, FeatRowMask(), tstream_));
+      SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss,
+                                       ds_.feat_dim, FGNN_F32, FeatRowMask(), ExtractorSharesGpu(), tstream_));
     SAM_HIP(hipEventRecord(te_[1], tstream_));
     if (num_cache)  // CombineCacheData
       SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, d_cidx[2], d_cidx[3], num_cache, nullptr, num_cache,
@@ -985,29 +1021,7 @@ void Engine::StartExtract(int count) {
   }
   SAM_CHECK(initialized_ && (dist_type_ == DistType::Extract || dist_type_ == DistType::Switch));
   if (extract_thread_.joinable()) extract_thread_.join();
-  extract_thread_ = std::thread([this, count]() {
-    SAM_HIP(hipSetDevice(tdevice_));
-    // Up to kExtractDepth batches in flight.  A further message is taken only when one is PUBLISHED (TryRecv never
-    // waits): a trainer that blocked for a message while holding unreleased queue slots could wait for a sampler that
-    // is itself waiting for one of those slots (few slots: large fan-outs under SAMGRAPH_MQ_BYTES, many trainers).
-    // With nothing in flight the thread holds no slot and may block like the reference's loop does.
-    int issued = 0, head = 0, inflight = 0;
-    while ((issued < count || inflight) && !shutdown_) {
-      if (issued < count && inflight < kExtractDepth) {
-        const void *msg = nullptr;
-        size_t key = 0;
-        if (inflight == 0 || mq_->TryRecv(&msg, &key)) {
-          TrainerIssue(xctx_[(head + inflight) % kExtractDepth], msg, key);
-          ++inflight;
-          ++issued;
-          continue;
-        }
-      }
-      TrainerComplete(xctx_[head]);
-      head = (head + 1) % kExtractDepth;
-      --inflight;
-    }
-  });
+  extract_thread_ = std::thread([this, count]() { ExtractLoop(count > 0 ? (size_t)count : 0); });
 }
 
 void Engine::RunSampleOnce() {
@@ -1062,14 +1076,18 @@ void Engine::Start() {
     for (size_t i = 0; i < total && !shutdown_; ++i) SampleOnceArch5();
     if (!shutdown_) PublishPending();
   });
-  extract_thread_ = std::thread([this, total]() {
-    for (size_t i = 0; i < total && !shutdown_; ++i) TrainerOnce();
-  });
+  // the copy thread keeps several batches in flight, like an arch5 trainer's (one at a time leaves the host link idle
+  // while the next message is parsed: 0.48 against 0.27 ms per batch on a 1 M-node graph)
+  extract_thread_ = std::thread([this, total]() { ExtractLoop(total); });
 }
 
 void Engine::Shutdown() {
   shutdown_ = true;
   if (pool_) pool_->Stop();
+  // threads of THIS process that are blocked on the queue (samgraph_start's loops stopped before their last batch: the
+  // sampler waits for a free slot, the extractor for a message) give up; an arch5 process has no such thread of its own
+  // -- its peers live in other processes and finish by themselves
+  if (mq_ && (sample_thread_.joinable() || extract_thread_.joinable())) mq_->Close();
   if (sample_thread_.joinable()) sample_thread_.join();
   if (extract_thread_.joinable()) extract_thread_.join();
   if (publish_thread_.joinable()) {  // publishes what is still in flight, then stops

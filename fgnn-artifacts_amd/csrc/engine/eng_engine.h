@@ -110,6 +110,14 @@ class Engine {
   void SyncPublished() { if (publish_thread_.joinable()) PublishPending(); }
   // SAMGRAPH_EMPTY_FEAT=k: the feature table holds 2^k rows, node ids are masked before indexing it (the reference's
   // mock extraction, cpu_extraction.cc:47-62)
+  // does the extractor's GPU also run this process's sampling chain (arch2-4 with both contexts on one device, arch6)?
+  // its host-source gathers then stay small (fgnn_gather_rows_shared); an arch5 trainer has its GPU to itself.
+  // SAMGRAPH_EXTRACT_SHARED_GPU=0/1 overrides (A/B runs; two arch5 ranks that share one development GPU)
+  int ExtractorSharesGpu() const {
+    static const int forced = [] { const char *e = getenv("SAMGRAPH_EXTRACT_SHARED_GPU"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    return sampler_ != nullptr && device_ == tdevice_;
+  }
   uint32_t FeatRowMask() const {
     return RC().option_empty_feat ? (uint32_t)((1ull << RC().option_empty_feat) - 1) : 0xFFFFFFFFu;
   }
@@ -128,6 +136,8 @@ class Engine {
   // joined by an in-process queue
   void InitInProcess();
   void CreateQueue();
+  void CreateSamplerSlots(size_t streams, size_t slots);
+  static constexpr size_t kInProcessSamplerStreams = 2, kInProcessSamplerSlots = 2;
   // arch5 sampler
   void PreSample();
   void PreSampleStatic();
@@ -141,6 +151,7 @@ class Engine {
   void SampleOnceDynamic();
   // arch5 trainer
   void TrainerOnce();
+  void ExtractLoop(size_t count);
   struct ExtractCtx;
   void TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key);
   void TrainerComplete(ExtractCtx &x);

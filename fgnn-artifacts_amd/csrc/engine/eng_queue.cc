@@ -226,25 +226,30 @@ void MemoryQueue::PinMemory() {
 namespace {
 // spin ~a few microseconds, then sleep in steps that grow from 1 us to 16 us: a hand-off that actually waits (small
 // queues, a slower peer) is picked up within a few microseconds of a 80-120 us batch, a long wait costs no core
+// false: this process is closing the queue (MemoryQueue::Close) and the condition has not come true
 template <typename Pred>
-void WaitFor(Pred ready, const int *aborted) {
+bool WaitFor(Pred ready, const int *aborted, const std::atomic<bool> &closing) {
   for (int i = 0; i < 4000; ++i) {
-    if (ready()) return;
+    if (ready()) return true;
     __builtin_ia32_pause();
   }
   int us = 1;
   while (!ready()) {
     if (__atomic_load_n(aborted, __ATOMIC_ACQUIRE)) SAM_FATAL << "message queue aborted: a process of the job has died";
+    if (closing.load(std::memory_order_acquire)) return false;
     std::this_thread::sleep_for(std::chrono::microseconds(us));
     if (us < 16) us *= 2;
   }
+  return true;
 }
 }  // namespace
 
 void *MemoryQueue::GetPtr(size_t *key) {
   const size_t k = __atomic_fetch_add(&meta_->send_cnt, 1, __ATOMIC_ACQ_REL);
   const size_t slot = k % meta_->max_size, gen = k / meta_->max_size;
-  WaitFor([&] { return __atomic_load_n(&meta_->rel_seq[slot], __ATOMIC_ACQUIRE) == gen; }, &meta_->aborted);
+  // (a closing process never publishes the slot it claimed: nobody of this process will wait for it either)
+  if (!WaitFor([&] { return __atomic_load_n(&meta_->rel_seq[slot], __ATOMIC_ACQUIRE) == gen; }, &meta_->aborted, closing_))
+    return nullptr;
   *key = k;
   return meta_->data + slot * meta_->mq_nbytes;
 }
@@ -254,12 +259,15 @@ void MemoryQueue::SimpleSend(size_t key) {
 }
 
 const void *MemoryQueue::Recv(size_t *key) {
-  WaitFor([&] {
-    return __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE) != __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE);
-  }, &meta_->aborted);
+  if (!WaitFor([&] {
+        return __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE) != __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE);
+      }, &meta_->aborted, closing_))
+    return nullptr;
   const size_t k = __atomic_fetch_add(&meta_->recv_cnt, 1, __ATOMIC_ACQ_REL);
   const size_t slot = k % meta_->max_size;
-  WaitFor([&] { return __atomic_load_n(&meta_->pub_seq[slot], __ATOMIC_ACQUIRE) == k + 1; }, &meta_->aborted);
+  if (!WaitFor([&] { return __atomic_load_n(&meta_->pub_seq[slot], __ATOMIC_ACQUIRE) == k + 1; }, &meta_->aborted,
+               closing_))
+    return nullptr;
   *key = k;
   return meta_->data + slot * meta_->mq_nbytes;
 }

@@ -84,6 +84,10 @@ class MemoryQueue {
   void *GetPtr(size_t *key);                         // claim a slot for writing (blocks while the ring is full)
   void SimpleSend(size_t key);                       // publish
   const void *Recv(size_t *key);                     // blocks until a message is available
+  // THIS process is shutting down while its own threads may still be blocked on the queue (an in-process engine stopped
+  // before its last batch): their GetPtr / Recv return nullptr instead of waiting on.  The reference's loops poll
+  // ShouldShutdown at 1 us (cuda_loops_arch3.cc:178-196); other processes of the job are not affected.
+  void Close() { closing_.store(true, std::memory_order_release); }
   bool TryRecv(const void **data, size_t *key);      // never blocks: takes the oldest message only if it is PUBLISHED
   void Release(size_t key);                          // SharedData::~SharedData
   // a process of the job has died: every blocked GetPtr / Recv of every process logs and aborts instead of waiting for
@@ -133,6 +137,7 @@ class MemoryQueue {
   bool owns_ring_[kMaxRings] = {};
   std::thread svc_;                    // answers spill requests for the ring this process owns
   std::atomic<bool> svc_stop_{false};
+  std::atomic<bool> closing_{false};   // Close(): process-local
 };
 
 // worst-case message size for a config (GetMaxMQSize, task_queue.cc:349-371)

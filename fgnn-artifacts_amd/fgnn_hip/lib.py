@@ -31,7 +31,7 @@ EXPORTS = [
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
     "fgnn_presample_count", "fgnn_presample_rank_scratch_bytes", "fgnn_presample_rank", "fgnn_cache_table_build",
-    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
+    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_gather_rows_shared", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
 ]
 
 _lib = None
@@ -398,8 +398,9 @@ def get_miss_cache_index(table, nodes, num_nodes=None, d_num_nodes=None, ws=None
     return outs[0], outs[1], outs[2], outs[3], d_counts
 
 
-def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_row_mask=None):
-    """out[dst_index[i] or i] = src[(src_index[i] or i) & src_row_mask]; rows are the trailing dims."""
+def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_row_mask=None, shared_gpu=None):
+    """out[dst_index[i] or i] = src[(src_index[i] or i) & src_row_mask]; rows are the trailing dims.
+    shared_gpu (not None): fgnn_gather_rows_shared -- a host-source launch stays small on a GPU that also samples."""
     _need_gpu(out)
     if n is None:
         n = (src_index if src_index is not None else dst_index if dst_index is not None else src).shape[0]
@@ -407,6 +408,13 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_
     for s in out.shape[1:]:
         dim *= s
     assert out.dtype == src.dtype and out.is_contiguous() and src.is_contiguous()
+    if shared_gpu is not None:
+        mask = 0xFFFFFFFF if src_row_mask is None else src_row_mask
+        _check(load().fgnn_gather_rows_shared(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), C.c_size_t(n),
+                                              _ptr(d_n), C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]),
+                                              C.c_uint32(mask), C.c_int(int(shared_gpu)), _stream()),
+               "fgnn_gather_rows_shared")
+        return out
     if src_row_mask is not None:
         _check(load().fgnn_gather_rows_masked(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), C.c_size_t(n),
                                               _ptr(d_n), C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]),

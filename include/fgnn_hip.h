@@ -242,6 +242,16 @@ int fgnn_gather_rows_masked(void *out, const void *src, const uint32_t *src_inde
                             size_t n, const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
                             void *stream);
 
+/* fgnn_gather_rows_masked for a caller whose GPU ALSO runs the sampling chain (one process sampling and extracting:
+ * the reference's arch2-4 / arch6 loops, cuda_loops_arch3.cc:178-196): rows read from HOST memory come over the host
+ * link at ~50 GB/s whatever the grid, and a launch sized like an HBM gather keeps ~1 M slow reads in the memory pipeline
+ * in front of every other kernel's misses -- the next batches' sampling chains then run 2-6x slower.  shared_gpu != 0
+ * limits a host-source launch to 64 workgroups (HBM sources are not affected); shared_gpu == 0 is
+ * fgnn_gather_rows_masked. */
+int fgnn_gather_rows_shared(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
+                            const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
+                            int shared_gpu, void *stream);
+
 /* ---- neighbourhood aggregation over a sampled block (consumer side of the path) ----------- */
 
 /* out[dst_index[e], :] += edge_weight[e] * h[src_index[e], :]  for e < num_edge (edge_weight NULL = 1), fp32.

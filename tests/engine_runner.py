@@ -10,6 +10,7 @@ import faulthandler
 import multiprocessing as mp
 import os
 import sys
+import time
 import traceback
 
 import numpy as np
@@ -270,6 +271,34 @@ def run_inproc(arch, sample_type, workdir, cache_pct, threaded):
                                                                 " static-presample" if STATIC_PRESAMPLE else
                                                                 " policy-%s" % FILE_POLICY if FILE_POLICY else "", n,
                                                                 miss_total))
+
+
+def run_inproc_early_stop(arch, sample_type, workdir, cache_pct, take):
+    """samgraph_start's threads stopped long before their last batch (the reference's loops poll ShouldShutdown,
+    cuda_loops_arch3.cc:178-196): by then the sampler thread is blocked on a full queue and the copy thread holds
+    batches nobody will ask for -- shutdown must come back, and the batches taken until then are still exact."""
+    path = dataset(workdir, sample_type)
+    import samgraph.torch as sam
+    cfg = base_config(path, {"arch2": sam.kArch2, "arch3": sam.kArch3, "arch4": sam.kArch4}[arch], sample_type)
+    cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0", cache_percentage=cache_pct, num_epoch=40)
+    sam.config(cfg)
+    sam.init()
+    rep = OracleReplay(path, sample_type, 0, 1, cache_pct > 0)
+    sam.start()
+    n = 0
+    for key, seeds, task in rep.epochs():
+        got = sam.get_next_batch()
+        assert got == key, (got, key)
+        check_batch(sam, key, seeds, task, rep, "%s key %d" % (arch, key))
+        n += 1
+        if n == take:
+            break
+    time.sleep(0.3)  # the threads run ahead until the queue and the graph pool are full
+    t0 = time.time()
+    sam.shutdown()
+    assert time.time() - t0 < 20.0
+    print("%s %s early stop ok: %d of %d batches taken, shutdown in %.2f s" % (arch, sample_type, n, 40 * rep.num_step,
+                                                                               time.time() - t0))
 
 
 def run_dynamic(sample_type, workdir, threaded):
@@ -627,6 +656,8 @@ if __name__ == "__main__":
         run_sgnn(mode, st, wd, int(sys.argv[4]), float(sys.argv[5]), len(sys.argv) > 6 and sys.argv[6] == "background")
     elif mode == "dynamic":
         run_dynamic(st, wd, len(sys.argv) > 4 and sys.argv[4] == "threads")
+    elif mode in ("arch2", "arch3", "arch4") and sys.argv[5] == "early_stop":
+        run_inproc_early_stop(mode, st, wd, float(sys.argv[4]), int(sys.argv[6]))
     elif mode in ("arch2", "arch3", "arch4"):
         run_inproc(mode, st, wd, float(sys.argv[4]), sys.argv[5] == "threads")
     else:

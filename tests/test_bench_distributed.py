@@ -21,18 +21,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _expected_edges(world, samplers, warmup, steps):
-    """edges the samplers report for the timed region: sampler i walks its own step range (dist_shuffler.cc:59-79)
-    from its first step, the warm-up share first"""
+def _check_windows(out, gpus, S, warmup, steps):
+    """the steady-state rule of the N >= 2 line: R back-to-back windows of `steps` consecutively consumed batches out of
+    ONE span with no barrier inside; value / ms_per_step / edges_per_step belong to the median window"""
     import bench
-    total = 0
-    for i in range(samplers):
-        first, local = bench.local_step_range(151, i, samplers)
-        skip = bench.split_count(warmup, samplers, i)
-        for j in range(skip, skip + bench.split_count(steps, samplers, i)):
-            key = (j // local) * 151 + first + j % local
-            total += bench.RehearsalBackend.edges_of(key)
-    return total
+    T = gpus - S
+    wd = out["windows"]
+    lead, tail = bench.span_margins(warmup, T)
+    assert wd["count"] == 5 and len(wd["ms_per_step"]) == 5 and all(x > 0 for x in wd["ms_per_step"])
+    assert wd["lead_batches"] == lead and wd["tail_batches"] == tail and wd["span_batches"] == lead + 5 * steps + tail
+    assert out["ms_per_step"] == sorted(wd["ms_per_step"])[2] == wd["ms_per_step"][wd["median_index"]]
+    assert wd["min"] <= out["ms_per_step"] <= wd["max"]
+    keys = wd["median_window_keys"]
+    assert len(keys) == len(set(keys)) == steps
+    # every key is a step some sampler owns (its range of the epoch, dist_shuffler.cc:59-79), taken once
+    owned = set()
+    for i in range(S):
+        first, local = bench.local_step_range(151, i, S)
+        n = bench.split_count(wd["span_batches"], S, i)
+        owned |= {(j // local) * 151 + first + j % local for j in range(n)}
+    assert set(keys) <= owned
+    assert round(out["edges_per_step"] * steps) == sum(bench.RehearsalBackend.edges_of(k) for k in keys)
+    assert abs(out["value"] - out["edges_per_step"] / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
 
 
 def _run(cmd, env=None):
@@ -56,7 +66,8 @@ def test_plain_launch_spawns_ranks(gpus, samplers):
     assert out["n_gpus"] == gpus and out["steps"] == 20 and out["warmup"] == 5
     assert out["pipeline"]["samplers"] == S and out["pipeline"]["trainers"] == gpus - S
     assert out["config"]["parallelism"].startswith("%dS+%dT" % (S, gpus - S))
-    assert round(out["edges_per_step"] * 20) == _expected_edges(gpus, S, 5, 20)
+    _check_windows(out, gpus, S, 5, 20)
+    assert out["pipeline"]["n1_point_of_this_curve"]["value"] is None  # a number on a GPU box, a reason here
     assert out["input_nodes_per_step"] == 1.0  # every one of the 20 batches reached exactly one trainer
     assert out["scaling"] == "strong" and out["ms_per_step"] > 0
     assert out["pipeline"]["handoff"]["transport"] == "none (rehearsal)" and len(out["pipeline"]["handoff"]["rings"]) == S
@@ -72,7 +83,7 @@ def test_torchrun_launch():
                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "12",
                 "--warmup", "3", "--rehearse"], env)
     assert out["n_gpus"] == 2 and out["steps"] == 12
-    assert round(out["edges_per_step"] * 12) == _expected_edges(2, 1, 3, 12)
+    _check_windows(out, 2, 1, 3, 12)
 
 
 def test_gpus_flag_must_match_the_launcher():
@@ -103,6 +114,67 @@ def test_training_region_gives_every_trainer_the_same_number_of_batches():
             assert warm % trainers == 0 and timed % trainers == 0 and warm >= trainers and timed >= trainers
             assert {bench.split_count(timed, trainers, i) for i in range(trainers)} == {timed // trainers}
             assert timed <= max(min(steps, train_steps), trainers)
+
+
+def test_span_arithmetic_and_window_reader():
+    import bench
+    assert bench.span_margins(5, 6) == (340, 12) and bench.span_margins(5, 1) == (340, 5) and bench.span_margins(0, 1) == (340, 2)
+    assert bench.span_margins(5, 6, decoupled=True) == (1, 0)
+    for T in (1, 2, 3, 6, 7):
+        lead, tail = bench.span_margins(5, T)
+        assert bench.span_total(lead, 5, 20, tail, T, False) == lead + 100 + tail
+        tot = bench.span_total(lead, 5, 18, tail, T, True)
+        assert tot % T == 0 and 0 <= tot - (lead + 90 + tail) < T
+    # stamps from three trainers, shuffled: batch b is consumed at time 10 + 2 b
+    import random
+    stamps = [(10.0 + 2.0 * b, 1000 + b) for b in range(3 + 4 * 5 + 2)]
+    random.Random(1).shuffle(stamps)
+    merged, wins = bench.read_windows(stamps, 3, 4, 5)
+    assert [k for _, k in merged] == list(range(1000, 1025))
+    for j, (t0, t1, keys) in enumerate(wins):
+        assert keys == list(range(1003 + 5 * j, 1008 + 5 * j)) and abs((t1 - t0) - 10.0) < 1e-9
+        assert t0 == 10.0 + 2.0 * (3 + 5 * j - 1)  # the clock of a window starts at the batch consumed before it
+
+
+def _limited_collective_rank(rank, port, q):
+    import datetime
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+    grp = dist.new_group(ranks=[0, 1], backend="gloo", timeout=datetime.timedelta(seconds=20))
+    import torch
+
+    def body():
+        if rank == 1:
+            raise RuntimeError("this rank fails alone")
+        t = torch.ones(1)
+        dist.all_reduce(t, group=grp)  # rank 1 never joins: stuck until the group's own timeout
+        return {"sum": float(t)}
+    import time
+    t0 = time.time()
+    res, bad = bench.limited_collective(dist, 2, body, 2.0)
+    q.put((rank, res, bad, time.time() - t0))
+    dist.barrier()  # the job's own group still works on both ranks
+    os._exit(0)  # rank 0's helper thread is still inside the abandoned collective
+
+
+def test_a_rank_failing_a_collective_alone_does_not_hang_the_others():
+    """bench.link_selftest's rule: the RCCL calls run on a helper thread with a per-rank limit and
+    the ranks agree over gloo on who finished -- checked here with a gloo sub-group standing in for RCCL"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_limited_collective_rank, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    for rank, res, bad, took in got:
+        assert res is None and took < 15.0
+        assert set(bad) == {0, 1} and "fails alone" in bad[1] and "no answer" in bad[0]
 
 
 def test_step_ranges_cover_epoch():

@@ -80,6 +80,13 @@ def test_single_process_two_role_archs(tmp_path, arch, sample_type, cache, mode)
     assert "ok" in _run(tmp_path, arch, sample_type, cache, mode)
 
 
+@pytest.mark.parametrize("take", [3, 12])
+def test_threads_stopped_before_their_last_batch(tmp_path, take):
+    """samgraph_shutdown with samgraph_start's loops still running (the sampler blocked on a full queue, the extractor
+    on a full graph pool or on an empty queue): no hang, no abort (bench.py's N = 1 point of the pipeline stops so)."""
+    assert "early stop ok" in _run(tmp_path, "arch3", "khop2", 0.25, "early_stop", take)
+
+
 @pytest.mark.parametrize("arch,sample_type,cache,mode", [("arch3", "khop2", 0.25, "inline"),
                                                          ("arch2", "random_walk", 0.1, "threads")])
 def test_static_presample_policy(tmp_path, arch, sample_type, cache, mode):

@@ -247,6 +247,23 @@ def test_gather_matches_oracle(hip, oracle, dtype, dim):
     assert out.cpu().numpy().tobytes() == src[nodes].tobytes()
 
 
+@pytest.mark.parametrize("shared", [0, 1])
+def test_gather_from_pinned_host_rows_with_the_shared_gpu_hint(hip, oracle, shared):
+    """fgnn_gather_rows_shared: miss rows read from pinned host memory by the kernel itself (ExtractMissData +
+    CombineMissData, cuda_cache_manager_host.cc:38-56); the hint only changes the launch shape of a host-source gather"""
+    rs = np.random.default_rng(5)
+    n_src, n, dim = 1 << 12, 30011, 128
+    src = rs.standard_normal((n_src, dim)).astype(np.float32)
+    idx = rs.integers(0, 1 << 20, size=n).astype(np.uint32)  # ids beyond the table: masked like SAMGRAPH_EMPTY_FEAT
+    dst = rs.permutation(n).astype(np.uint32)
+    want = np.zeros((n, dim), dtype=np.float32)
+    want[dst] = oracle.extract(src, idx & (n_src - 1))
+    for table in (torch.from_numpy(src).pin_memory(), dev(src)):  # host source, then an HBM source (hint ignored)
+        got = torch.zeros((n, dim), dtype=torch.float32, device="cuda")
+        hip.gather_rows(got, table, src_index=dev(idx), dst_index=dev(dst), src_row_mask=n_src - 1, shared_gpu=shared)
+        assert got.cpu().numpy().tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("kind,fanouts,batch", [("khop2", [25, 10], 2000), ("khop0", [5, 10, 15], 300),
                                                 ("khop2", [10, 5], 1)])
 def test_layered_pipeline_matches_oracle(hip, oracle, kind, fanouts, batch):
