@@ -1,4 +1,6 @@
 // capi.hip -- small entry points of libfgnn_hip.so that are not tied to one kernel file.
+#include <atomic>
+
 #include "fgnn_device.h"
 
 #include <cstdio>
@@ -27,11 +29,13 @@ unsigned long long *scan_help_counter() {
   }
   return g_helps[dev];
 }
-static int g_scan_help_after = -1;
-int scan_help_after_override() { return g_scan_help_after; }
+static std::atomic<int> g_scan_help_after{-1};
+int scan_help_after_override() { return g_scan_help_after.load(std::memory_order_relaxed); }
 }  // namespace fgnn
 
-extern "C" void fgnn_debug_set_scan_help_after(int polls) { fgnn::g_scan_help_after = polls; }
+extern "C" void fgnn_debug_set_scan_help_after(int polls) {
+  fgnn::g_scan_help_after.store(polls, std::memory_order_relaxed);
+}
 
 extern "C" size_t fgnn_debug_phase_log_bytes(void) {
   return (size_t)fgnn::kPhaseLogKinds * fgnn::kPhaseLogTiles * 8 * sizeof(unsigned long long);

@@ -60,7 +60,7 @@ struct fgnn_sampler {
   // for what happens next); a reuse that finds no recorded event records it late, on the other stream -- it then covers
   // more than needed: correct, and only at a change of pattern (e.g. the pre-sampling epoch's stream -> batch streams).
   std::atomic<bool> csr_cross{false};
-  // weighted_khop_prefix: 16-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
+  // weighted_khop_prefix: 5-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
   fgnn::PrefixTreeHost *ptree = nullptr;
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 = 0 (profiling build): fused last layer
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED = 1 (profiling build): wrong results under overlap
@@ -419,6 +419,16 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
   // a layer's remap fix-up is not launched by itself: the next fill's insert launch carries it (FixTail) -- nothing of
   // the next layer's sampling reads the remapped edges -- and the last layer's goes to the caller or runs at the end
   fgnn::FixTail owed = fgnn::no_fix_tail();
+  // Samplers that never look the dedup table up (all but the fused k-hop ones) may run EVERY fill through the
+  // partitioned, table-free path -- decided once per batch: if one layer's worst case is too large for it (beyond the
+  // one-launch count+assign, ~12.6 M items), a fill that fell back to the global insert would dedup against a table the
+  // earlier partitioned fills never wrote to.  Then every fill but the last takes the global path
+  bool table_free = !khop_fused;
+  for (size_t l = L, ic = num_seeds; table_free && l-- > 0;) {
+    const size_t ec = ic * s->cfg.fanout[l];
+    table_free = ec == 0 || fgnn::hashtable_can_partition(ht, ec);
+    ic += ec;
+  }
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
   size_t cur_n_host = num_seeds;
@@ -486,7 +496,7 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
                                       inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed,
-                                      /*table_free=*/!khop_fused);  // those samplers never look the table up
+                                      table_free && l != 0);  // (the last fill decides for itself: nothing follows it)
     if (rc != FGNN_OK) return rc;
     owed = mine;
     in_cap += ecap;

@@ -666,7 +666,10 @@ int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size
                                  bool table_free = false);
 // table_free: nothing after this fill reads the global table (no fused sampler insert, no fgnn_hashtable_map, and every
 // later fill of the batch is table_free or final too) -- the fill may then go through the partitioned path although it
-// is not the batch's last (the batch driver's samplers that do not insert themselves: every layer)
+// is not the batch's last (the batch driver's samplers that do not insert themselves: every layer).  The promise is
+// per BATCH: the caller checks hashtable_can_partition for every layer's capacity first (a non-final table_free fill
+// that cannot be partitioned is refused, FGNN_EINVAL)
+bool hashtable_can_partition(const fgnn_hashtable *ht, size_t cap);
 // owed_fix (non-null: the caller takes the remap fix-up of THIS fill over; filled in, mapped == null if none is owed):
 // the fix-up only rewrites `mapped` entries from other `mapped` entries -- nothing of the next layer's sampling reads
 // it, so the batch driver lets it ride on a later launch (FixTail) instead of giving it a launch of its own.

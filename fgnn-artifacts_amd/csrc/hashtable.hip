@@ -542,6 +542,14 @@ bool fgnn::hashtable_can_resolve(const fgnn_hashtable *ht, size_t cap) {
   return enabled && ht && ht->disp && ht->scan && cap > 0 && cap <= ht->max_fill_items && count_assign_grid(cap, ht->scan) > 0;
 }
 
+// can a fill of `cap` items take the partitioned, table-free path (hashtable_partition.hip)?  The batch driver asks for
+// EVERY layer of a batch before it promises `table_free` to any of them: a fill that fell back to the global insert
+// would dedup against a table the earlier, partitioned fills never wrote their new nodes to
+bool fgnn::hashtable_can_partition(const fgnn_hashtable *ht, size_t cap) {
+  return ht && ht->scan && cap > 0 && cap <= ht->max_fill_items && partition_fits(ht->part, ht, cap) &&
+         count_assign_grid(cap, ht->scan) > 0;
+}
+
 int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
@@ -573,6 +581,9 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
   } while (0)
   // already_inserted: the sampler kernel inserted each edge as it produced it and left the buckets in pos[]
   bool exact = false;
+  // table_free is the caller's promise for the WHOLE batch (hashtable_can_partition held for every fill): a table-free
+  // fill that cannot be partitioned here would silently dedup against an incomplete table
+  if (table_free && !final_fill && !(mapped && scan == ht->scan && hashtable_can_partition(ht, cap))) return FGNN_EINVAL;
   if (!already_inserted && (final_fill || table_free) && mapped && scan == ht->scan &&
       partition_fits(ht->part, ht, cap) && count_assign_grid(cap, scan) > 0) {
     // the batch's last fill (or any fill of a batch that never reads the table): partitioned by hash, deduplicated in

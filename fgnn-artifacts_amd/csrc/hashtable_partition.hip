@@ -35,6 +35,8 @@
 // Bins whose distinct keys do not fit the LDS table (a graph whose ids collide in the hash's top bits; never seen on
 // the R-MAT or power-law shapes) fall back, per bin, to the global table with the ordinary probes: a key's items all
 // sit in one bin, i.e. in one workgroup, so a workgroup barrier orders "all inserted" before "read back".
+#include <atomic>
+
 #include "fgnn_device.h"
 
 namespace fgnn {
@@ -296,6 +298,9 @@ __device__ __forceinline__ bool part_lds_insert(unsigned long long *tab, uint32_
       return false;
     }
     h = (h + 1) & (kPartLdsSlots - 1);
+    // somebody has found the table full: the bin goes through the global table whatever this item finds -- do not walk
+    // the other 8 K slots for every remaining item (a bin of 100 K items would cost ~10^9 LDS probes before it fell back)
+    if ((probes & 31u) == 31u && *(volatile uint32_t *)overflow) return false;
   }
   *overflow = 1u;  // table full (benign race: every writer stores 1)
   return false;
@@ -342,12 +347,17 @@ __global__ __launch_bounds__(kPartDedupThreads) void part_dedup_kernel(PartView 
     }
     __syncthreads();
     uint32_t newkeys = 0;
-    if (in_regs) {
+    // more items than four tables' worth: a bin that full (fills beyond 2048 bins x 2048 items, or a run of ids that
+    // collide in the hash's top bits) almost surely overflows -- straight to the global table, no LDS pass
+    const bool hopeless = cnt > 4u * kPartLdsSlots;
+    if (hopeless) {
+      if (threadIdx.x == 0) sh_overflow = 1u;
+    } else if (in_regs) {
 #pragma unroll
       for (int r = 0; r < kPartRegPairs; ++r)
         if (r * kPartDedupThreads + threadIdx.x < cnt) newkeys += part_lds_insert(tab, lg, kv[r], &sh_overflow) ? 1u : 0u;
     } else {
-      for (uint32_t q = threadIdx.x; q < cnt; q += kPartDedupThreads)
+      for (uint32_t q = threadIdx.x; q < cnt && !*(volatile uint32_t *)&sh_overflow; q += kPartDedupThreads)
         newkeys += part_lds_insert(tab, lg, p.pairs[beg + q], &sh_overflow) ? 1u : 0u;
     }
 #pragma unroll
@@ -402,7 +412,8 @@ __global__ __launch_bounds__(kPartDedupThreads) void part_dedup_kernel(PartView 
   }
 }
 
-int g_part_lds_limit = -1;
+std::atomic<int> g_part_lds_limit{-1};
+constexpr int kMaxAttrDevices = 64;
 
 }  // namespace
 
@@ -446,7 +457,8 @@ int partition_fill(PartWs *w, const fgnn_hashtable *ht, const uint32_t *items, s
                    const size_t *d_num_items, size_t cap, uint32_t *pos, hipStream_t s, const FixTail &carry) {
   const HtView tv = ht_view(ht);
   PartView p{w->pairs, w->bins, w->bins + (size_t)kPartMaxBlocks * w->max_bins, w->max_log2,
-             g_part_lds_limit >= 0 ? (uint32_t)g_part_lds_limit : kPartLdsSlots * 3u / 4u};
+             g_part_lds_limit.load(std::memory_order_relaxed) >= 0
+                 ? (uint32_t)g_part_lds_limit.load(std::memory_order_relaxed) : kPartLdsSlots * 3u / 4u};
   // tiles are walked with a stride: the count matrix has one row per workgroup
   const size_t tiles = div_up(cap + ht->max_items, (size_t)kPartTile);
   const size_t blocks = tiles < (size_t)kPartMaxBlocks ? tiles : (size_t)kPartMaxBlocks;
@@ -456,11 +468,15 @@ int partition_fill(PartWs *w, const fgnn_hashtable *ht, const uint32_t *items, s
                      num_items, d_num_items, cap, ht->n2o, ht->d_num_items, tv.pend, p, (uint32_t)blocks, carry);
   hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)blocks), dim3(kPartThreads), 0, s, items, num_items,
                      d_num_items, cap, ht->n2o, ht->d_num_items, tv.pend, p, pos);
-  static bool attr_done = false;  // more than the 64 KiB a kernel gets without asking (160 KiB per CU on gfx950)
-  if (!attr_done) {
+  // more than the 64 KiB a kernel gets without asking (160 KiB per CU on gfx950).  The attribute belongs to the
+  // function ON A DEVICE: asked once per device (a process that samples on a second GPU launches there too)
+  static std::atomic<bool> attr_done[kMaxAttrDevices];
+  int dev = 0;
+  FGNN_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxAttrDevices || !attr_done[dev].load(std::memory_order_acquire)) {
     FGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&part_dedup_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLdsBytes));
-    attr_done = true;
+    if (dev >= 0 && dev < kMaxAttrDevices) attr_done[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(part_dedup_kernel, dim3((unsigned)bins_grid), dim3(kPartDedupThreads), kPartLdsBytes, s, p, tv,
                      num_items, d_num_items, cap, ht->d_num_items, pos);
@@ -469,4 +485,6 @@ int partition_fill(PartWs *w, const fgnn_hashtable *ht, const uint32_t *items, s
 
 }  // namespace fgnn
 
-extern "C" void fgnn_debug_set_partition_lds_limit(int distinct_keys) { fgnn::g_part_lds_limit = distinct_keys; }
+extern "C" void fgnn_debug_set_partition_lds_limit(int distinct_keys) {
+  fgnn::g_part_lds_limit.store(distinct_keys, std::memory_order_relaxed);
+}

@@ -70,10 +70,8 @@ def load():
         L.fgnn_hashtable_d_num_items.argtypes = [C.c_void_p]
         L.fgnn_debug_set_scan_help_after.restype = None
         L.fgnn_debug_set_scan_help_after.argtypes = [C.c_int]
-        # tests force the helping path of the single-pass kernels for a whole process (tests/test_coresidency_gpu.py);
-        # the library itself reads nothing from the environment
-        if os.environ.get("FGNN_SCAN_HELP_AFTER") is not None:
-            L.fgnn_debug_set_scan_help_after(int(os.environ["FGNN_SCAN_HELP_AFTER"]))
+        # (neither the library nor this binding reads a switch from the environment: tests that force the helping path of
+        # the single-pass kernels call fgnn_debug_set_scan_help_after themselves, tests/conftest.py)
         _lib = L
     return _lib
 

@@ -329,6 +329,9 @@ typedef struct fgnn_batch_meta_s {
   uint64_t t_start, t_sampled, t_closed;
 } fgnn_batch_meta;
 
+/* Streams: a stream handed to any fgnn_sampler_* call must stay alive until fgnn_sampler_destroy (or until the caller
+ * has synchronised it AND made a later call on another stream for each of the sampler's 6 slots): the sampler records
+ * a slot's hand-over event lazily, on the stream that used the slot last, the first time another stream needs it. */
 fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);
 void fgnn_sampler_destroy(fgnn_sampler *s);
 /* weighted_khop_prefix samplers build, at creation, a 5-ary search tree over every prefix-table row longer than 64

@@ -709,6 +709,43 @@ def test_batch_driver_large_frontier(hip, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["khop1", "khop2"])
+def test_batch_driver_layer_beyond_the_one_launch_dedup(hip, oracle, kind):
+    """fanout [15,15,15] x batch 4000: the last layer's worst case (15.4 M edges) is beyond the one-launch count+assign
+    (~12.6 M items), so that fill takes the global-table passes.  khop1 never inserts into the table itself: its early,
+    small layers must then NOT go through the partitioned table-free path either, or the last fill would dedup against a
+    table that only knows the seeds (input_nodes with duplicates; the table-free decision is per batch, engine.hip)."""
+    from fgnn_hip import synth
+    num_node, batch, fanouts = 300_000, 4000, [15, 15, 15]
+    indptr, indices = synth.powerlaw_csr(num_node, 4_000_000, seed=23)
+    d_indices = dev(indices.copy())
+    st, ost = (hip.KHOP1, oracle.KHOP1) if kind == "khop1" else (hip.KHOP2, oracle.KHOP2)
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=st, seed=SEED)
+    assert sampler.max_edges(0) > 13_000_000
+    bt = sampler.new_batch()
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    for b in range(2):
+        seeds = _seeds(batch, num_node, seed=500 + b)
+        sampler.sample(dev(seeds), b, bt)
+        bt.finish()
+        m = bt.wait()
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, b, oht)
+        assert m.overflow == 0
+        nodes = host_u32(bt.input_nodes())
+        assert len(np.unique(nodes)) == len(nodes)
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        for li in range(3):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("limit", [0, 48])
 def test_partitioned_last_fill_falls_back_per_bin(hip, oracle, limit):
     """The batch's last dedup fill is partitioned by hash and deduplicated per bin in an LDS table
