@@ -1214,6 +1214,10 @@ class EngineBackend:
     def queue_stats(self, rings):
         return [self.sam.ext_queue_stats(r) for r in range(rings)]
 
+    def ring_mappings(self, rings):
+        """per sampler ring: how THIS process read its payloads (samgraph_ext_ring_mapping)"""
+        return [self.sam.ext_ring_mapping(r) for r in range(rings)]
+
     def shutdown(self):
         self.sam.shutdown()
 
@@ -1270,6 +1274,9 @@ class RehearsalBackend:
     def queue_stats(self, rings):
         return [None] * rings
 
+    def ring_mappings(self, rings):
+        return [None] * rings
+
     def shutdown(self):
         self.eng.fgnn_host_queue_close(self.q)
 
@@ -1291,6 +1298,7 @@ def run_pipeline_rank(args, rank, world):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     dev_id = local_rank % max(n_dev, 1)  # more ranks than GPUs (a functional check on one GPU): they share
     n1_child = None
+    exit_msg = None
     if rank == 0 and not (args.rehearse or args.no_n1_point or args.decoupled):
         # started now, before this process touches the GPU; it sleeps on its stdin until the spans are done
         env = {k: v for k, v in os.environ.items()
@@ -1474,6 +1482,10 @@ def run_pipeline_rank(args, rank, world):
         # where every rank's GPU hangs (NUMA node of its PCIe root) next to where the shared host feature table lives
         gnodes = [None] * world
         dist.all_gather_object(gnodes, None if args.rehearse else gpu_numa_node(dev_id))
+        # every trainer: how it read each sampler's ring (mapped device to device, or copied back through the host slot)
+        maps = [None] * world
+        dist.all_gather_object(maps, None if is_sampler else {"rank": rank, "device": dev_id,
+                                                             "rings": be.ring_mappings(S)})
         be.shutdown()
         dist.barrier()
         n1_point = None
@@ -1533,8 +1545,17 @@ def run_pipeline_rank(args, rank, world):
                                      else "MIXED: part of the messages fell back to the pinned host ring"),
                        "note": "per sampler ring: slots, messages by payload location, copies back on request, and the "
                                "warm-up messages the receiving trainers verified end to end (a mismatch aborts the job)"}
+            handoff["trainers"] = [m for m in maps if m]
             if live and handoff["check_failed"]:
                 sys.exit("bench.py: hand-off check failed: %s" % handoff)
+            # A run that was meant to read the samplers' HBM rings peer to peer but moved payloads through pinned host
+            # memory is a different (slower) system: it must not pass for the real thing.  Asked-for host transport
+            # (SAMGRAPH_DEVICE_RING_SLOTS=0, the forced-spill test switch) is fine
+            asked_host = os.environ.get("SAMGRAPH_DEVICE_RING_SLOTS") == "0" or \
+                os.environ.get("SAMGRAPH_DEVICE_RING_FORCE_SPILL") not in (None, "", "0")
+            refused = [(m["rank"], i) for m in handoff["trainers"] for i, g in enumerate(m["rings"]) if g and g["state"] == 3]
+            degraded = live and (refused or any(r["sent_host"] or r["spilled"] for r in live))
+            handoff["degraded"] = bool(degraded) and not asked_host
             row_b = w["feat_dim"] * 4
             hit_rows = rows - miss_rows
             handoff_bytes = graph_bytes + 8 * rows + 4 * bs * K  # COO arrays + (miss|cache) index pairs + output ids
@@ -1602,6 +1623,10 @@ def run_pipeline_rank(args, rank, world):
                 "edges_per_step": edges / K, "input_nodes_per_step": rows / K, "setup_s": setup_max,
             }
             print(json.dumps(out), flush=True)
+            if handoff.get("degraded") and n_dev >= world:
+                exit_msg = ("bench.py: every rank has its own GPU but payloads went through the pinned host ring "
+                            "(trainer, ring) refused: %s; rings: %s -- the line above is NOT the peer-read pipeline"
+                            % (refused, rings))
     finally:
         if n1_child is not None:  # never asked (an error above): an empty line ends it
             try:
@@ -1622,6 +1647,8 @@ def run_pipeline_rank(args, rank, world):
                         except OSError:
                             pass
     dist.destroy_process_group()
+    if exit_msg:
+        sys.exit(exit_msg)
 
 
 def limited_collective(dist, world, body, limit_s):

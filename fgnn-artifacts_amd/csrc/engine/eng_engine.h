@@ -103,6 +103,7 @@ class Engine {
   Dataset &Data() { return ds_; }
   void ForwardBarrier() { outer_counter_++; }
   bool QueueStats(int ring, uint64_t out[6]) const { return mq_ && mq_->RingStats(ring, out); }
+  bool RingMapping(int ring, int64_t out[3]) const { return mq_ && mq_->RingMapping(ring, out); }
   // the parent saw a child die (samgraph_wait_one_child): peers blocked on the queue give up instead of hanging
   void AbortQueue() { if (mq_) mq_->Abort(); }
   // sample_once only enqueues a batch; its profiler values appear when the publisher thread has published it.  The

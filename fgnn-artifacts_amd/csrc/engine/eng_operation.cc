@@ -119,6 +119,12 @@ int samgraph_ext_queue_stats(int ring, uint64_t out[6]) {
   return Engine::Get().QueueStats(ring, out) ? 0 : -1;
 }
 
+int samgraph_ext_ring_mapping(int ring, int64_t out[3]) {
+  out[0] = 0;
+  out[1] = out[2] = -1;
+  return Engine::Get().RingMapping(ring, out) ? 0 : -1;
+}
+
 void samgraph_data_init(void) {
   SAM_CHECK(RC().is_configured);
   SAM_CHECK(RC().run_arch == kArch5 || RC().run_arch == kArch6)

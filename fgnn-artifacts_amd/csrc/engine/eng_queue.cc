@@ -139,8 +139,17 @@ const void *MemoryQueue::Payload(size_t key, const void *host_msg, bool *on_devi
   SAM_CHECK(ring >= 0 && ring < kMaxRings);
   RingInfo &r = meta_->rings[ring];
   SAM_CHECK(r.ready && slot < r.slots);
+  auto note = [&](int state) {
+    if (map_state_[ring] < state) {
+      int dev = -1;
+      (void)hipGetDevice(&dev);
+      map_device_[ring] = dev;
+      map_state_[ring] = state;
+    }
+  };
   if (r.pid == (int)getpid()) {
     SAM_CHECK(local_slot_[ring][slot]);
+    note(1);
     return local_slot_[ring][slot];
   }
   if (!mapped_slot_[ring][slot] && !*(volatile int *)&meta_->ipc_broken) {
@@ -166,9 +175,20 @@ const void *MemoryQueue::Payload(size_t key, const void *host_msg, bool *on_devi
       std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     *on_device = false;
+    note(3);
     return host_msg;
   }
+  note(2);
   return mapped_slot_[ring][slot];
+}
+
+bool MemoryQueue::RingMapping(int ring, int64_t out[3]) const {
+  if (ring < 0 || ring >= kMaxRings) return false;
+  const RingInfo &r = meta_->rings[ring];
+  out[0] = map_state_[ring];
+  out[1] = r.ready ? r.device : -1;
+  out[2] = map_state_[ring] ? map_device_[ring] : -1;
+  return true;
 }
 
 void MemoryQueue::DrainDeviceRing(int ring, double timeout_s) {

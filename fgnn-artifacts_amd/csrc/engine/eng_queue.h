@@ -105,6 +105,8 @@ class MemoryQueue {
   }
   // out[6] as samgraph_ext_queue_stats (include/samgraph_ext.h); false: no such ring
   bool RingStats(int ring, uint64_t out[6]) const;
+  // out[3] as samgraph_ext_ring_mapping: how THIS process reads that ring's payloads
+  bool RingMapping(int ring, int64_t out[3]) const;
   size_t SlotBytes() const { return meta_->mq_nbytes; }
   size_t NumSlots() const { return meta_->max_size; }
   // slots claimed for sending and not yet claimed by a receiver -- NOT the number of receivable messages (a claimed
@@ -135,6 +137,8 @@ class MemoryQueue {
   void *local_slot_[kMaxRings][kMaxRingSlots] = {};   // slots of the rings this process owns
   void *mapped_slot_[kMaxRings][kMaxRingSlots] = {};  // slots of other processes' rings, opened through IPC on first use
   bool owns_ring_[kMaxRings] = {};
+  int map_state_[kMaxRings] = {};      // 0 none yet, 1 own ring, 2 mapped through IPC, 3 refused (read from the host slot)
+  int map_device_[kMaxRings] = {};     // current device of the thread that read the ring first (valid when state != 0)
   std::thread svc_;                    // answers spill requests for the ring this process owns
   std::atomic<bool> svc_stop_{false};
   std::atomic<bool> closing_{false};   // Close(): process-local

@@ -549,6 +549,12 @@ class Sampler:
                                                       C.c_uint64(batch_key), batch.h, _stream()),
                    "fgnn_sampler_sample_ordered")
 
+    def sample_indexed(self, seeds, batch_key, batch, cache_table=None):
+        """fgnn_sampler_sample_indexed: sample + cache index in one call (an arch5 sampler's batch), internal counter"""
+        _need_gpu(seeds)
+        _check(load().fgnn_sampler_sample_indexed(self.h, _ptr(seeds), C.c_size_t(seeds.numel()), C.c_uint64(batch_key),
+                                                  batch.h, _ptr(cache_table), _stream()), "fgnn_sampler_sample_indexed")
+
     def run_batch(self, seq, seeds, batch_key, batch, cache_table=None, feat=None, label=None, stream=None):
         """sample + cache index + extract + finish in ONE C call on `stream` (a torch stream; default current).
         Safe to call from several Python threads (ctypes releases the GIL)."""

@@ -147,6 +147,7 @@ _SIGNATURES = {
 # entry points the reference does not have (include/samgraph_ext.h); nothing reference-shaped depends on them
 _EXT_SIGNATURES = {
     'samgraph_ext_queue_stats': (_int, (_int, ctypes.POINTER(_u64))),
+    'samgraph_ext_ring_mapping': (_int, (_int, ctypes.POINTER(ctypes.c_int64))),
 }
 
 
@@ -187,6 +188,15 @@ class SamGraphBasics(object):
             return None
         return dict(zip(("ring_slots", "sent_device", "sent_host", "spilled", "verified", "check_failed"),
                         (int(x) for x in out)))
+
+    def ext_ring_mapping(self, ring):
+        """how THIS process reads sampler `ring`'s payloads (include/samgraph_ext.h), or None without a queue / ring"""
+        out = (ctypes.c_int64 * 3)()
+        if self.C_LIB_CTYPES.samgraph_ext_ring_mapping(ring, out) != 0:
+            return None
+        how = ("not read yet", "own ring", "mapped: device-to-device reads (hipIpcOpenMemHandle, lazy peer access)",
+               "mapping refused: payloads copied back to the pinned host slot")[int(out[0])]
+        return {"state": int(out[0]), "how": how, "ring_device": int(out[1]), "reader_device": int(out[2])}
 
     def sample_init(self, worker_id, ctx):
         return self.C_LIB_CTYPES.samgraph_sample_init(worker_id, str.encode(ctx))

@@ -29,7 +29,7 @@ for _name in ('config', 'init', 'start', 'num_class', 'feat_dim', 'num_epoch', '
               'report_init', 'report_step', 'report_step_average', 'report_epoch', 'report_epoch_average',
               'report_node_access', 'trace_step_begin', 'trace_step_end', 'trace_step_begin_now',
               'trace_step_end_now', 'dump_trace', 'forward_barrier', 'wait_one_child', 'switch_init', 'data_init',
-              'sample_init', 'train_init', 'extract_start', 'num_local_step', 'ext_queue_stats'):
+              'sample_init', 'train_init', 'extract_start', 'num_local_step', 'ext_queue_stats', 'ext_ring_mapping'):
     globals()[_name] = getattr(_basics, _name)
 
 _TYPESTR = {0: '<f4', 1: '<f8', 2: '<f2', 3: '|u1', 4: '<i4', 5: '|i1', 6: '<i8'}

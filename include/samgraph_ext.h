@@ -22,6 +22,15 @@ extern "C" {
  * Returns 0, or -1 when there is no queue / no such ring. */
 int samgraph_ext_queue_stats(int ring, uint64_t out[6]);
 
+/* How THIS process reads the payloads of sampler `ring` (per process, unlike the shared counters above):
+ *   out[0] 0 = it has not read a message of that ring yet; 1 = the ring is its own (plain device pointer);
+ *          2 = the sampler's HBM slots are mapped here (hipIpcOpenMemHandle with lazy peer access: payloads are read
+ *              device to device, over xGMI when the two GPUs differ); 3 = the mapping was refused -- the owner copies
+ *              every message back into the pinned host slot and this process reads it there
+ *   out[1] the GPU the ring lives on          out[2] the GPU this process read it from (-1: none yet)
+ * Returns 0, or -1 when there is no queue / no such ring. */
+int samgraph_ext_ring_mapping(int ring, int64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,6 +255,15 @@ def test_bench_pipeline_two_processes(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 12 and out["pipeline"]["samplers"] == 1
     assert out["value"] > 0 and out["edges_per_step"] > 1000 and 0 < out["pipeline"]["hit_rate"] <= 1
     assert out["epoch_time_s"]["with_training"] > 0
+    # steady-state windows out of one span, and the like-for-like N = 1 point measured by rank 0's child (arch3)
+    wd = out["windows"]
+    assert wd["count"] == 5 and len(wd["ms_per_step"]) == 5 and out["ms_per_step"] == sorted(wd["ms_per_step"])[2]
+    assert wd["lead_batches"] >= 340 and len(wd["median_window_keys"]) == 12
+    n1 = out["pipeline"]["n1_point_of_this_curve"]
+    assert n1["value"] > 0 and n1["n_gpus"] == 1 and len(n1["windows_ms_per_step"]) == 5, n1
+    # every trainer says how it read the sampler's ring: mapped device to device (two processes, one GPU here)
+    tr = out["pipeline"]["handoff"]["trainers"]
+    assert len(tr) == 1 and tr[0]["rings"][0]["state"] == 2 and not out["pipeline"]["handoff"]["degraded"]
     # the link self-test: with a GPU per rank RCCL must have seen both ranks; on a one-GPU box the line says why not
     links = out["pipeline"]["links"]
     if torch.cuda.device_count() >= 2:
@@ -273,7 +282,8 @@ def test_bench_pipeline_two_samplers_three_trainers(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--samplers", "2", "--workload",
-                        "small", "--steps", "15", "--warmup", "6", "--train-steps", "6", "--empty-feat-bits", "16"],
+                        "small", "--steps", "15", "--warmup", "6", "--train-steps", "6", "--empty-feat-bits", "16",
+                        "--no-n1-point"],  # (its child would be the 7th process on this box's one GPU: the limit is 6)
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])

@@ -56,7 +56,7 @@ def test_engine_library_exports_only_the_reference_symbol_list():
         [s for s in syms if not s.startswith("samgraph_")][:10]
     # the reference's list, plus the entry points of include/samgraph_ext.h (same prefix, documented as this build's)
     assert sorted(s for s in syms if s != "PyInit_c_lib") == sorted(_declared("samgraph.h") + _declared("samgraph_ext.h"))
-    assert _declared("samgraph_ext.h") == ["samgraph_ext_queue_stats"]
+    assert _declared("samgraph_ext.h") == ["samgraph_ext_queue_stats", "samgraph_ext_ring_mapping"]
 
 
 def test_python_binding_covers_abi():

@@ -687,8 +687,11 @@ def test_batch_driver_large_frontier(hip, oracle):
     rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
     for b in range(2):
         seeds = _seeds(batch, num_node, seed=300 + b)
-        sampler.sample(dev(seeds), 50 + b, bt)
-        bt.cache_index(d_table)
+        if b == 0:
+            sampler.sample(dev(seeds), 50 + b, bt)
+            bt.cache_index(d_table)
+        else:  # cache-table words looked up by the dedup launches, > 4 rounds per workgroup (fgnn::CacheLookup)
+            sampler.sample_indexed(dev(seeds), 50 + b, bt, d_table)
         bt.extract(d_feat, d_label)
         bt.finish()
         m = bt.wait()
@@ -743,6 +746,87 @@ def test_batch_driver_layer_beyond_the_one_launch_dedup(hip, oracle, kind):
             np.testing.assert_array_equal(host_u32(row), g["row"])
             np.testing.assert_array_equal(host_u32(col), g["col"])
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["khop2", "khop0", "khop1", "random_walk"])
+def test_run_batch_looks_the_cache_table_up_while_deduplicating(hip, oracle, kind):
+    """fgnn_sampler_run_batch with a cache table: the dedup's count+assign launches look the table up for every node as
+    they number it (fgnn::CacheLookup) and the split reads those words instead of making its own look-ups
+    (GetMissCacheIndex, cuda_cache.cu:33-158: same four lists).  Covered: the fused k-hop inserts, the partitioned
+    table-free fills (khop1, random walk), empty batches, batches of isolated seeds (no fill launches at all: the split
+    looks up itself), a short batch after a long one on the same buffer, and a second split of the same batch against
+    ANOTHER table (must not reuse the first table's words)."""
+    from fgnn_hip import synth
+    num_node = 60000
+    indptr, indices = synth.powerlaw_csr(num_node, 900000, seed=44)
+    deg = np.diff(indptr.astype(np.int64))
+    isolated = np.nonzero(deg == 0)[0].astype(np.uint32)
+    assert len(isolated) >= 20
+    fanouts, batch = ([5, 5, 5], 400) if kind == "random_walk" else ([7, 5], 700)
+    hst, ost = dict(khop2=(hip.KHOP2, oracle.KHOP2), khop0=(hip.KHOP0, oracle.KHOP0), khop1=(hip.KHOP1, oracle.KHOP1),
+                    random_walk=(hip.RANDOM_WALK, oracle.RANDOM_WALK))[kind]
+    skw = dict(walk_len=3, num_walks=8, restart_prob=0.5) if kind == "random_walk" else {}
+    okw = dict(walk_len=3, num_walks=8, num_neighbor=5, restart_prob=0.5) if kind == "random_walk" else {}
+    d_indices = dev(indices.copy())
+    o_indices = indices.copy()
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=hst, seed=SEED, **skw)
+    bt = sampler.new_batch()
+    rs = np.random.default_rng(9)
+    tables = [oracle.cache_table_build(rs.permutation(num_node).astype(np.uint32), num_node // k, num_node) for k in (4, 2)]
+    d_tables = [dev(t) for t in tables]
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    plans = [_seeds(batch, num_node, seed=1), np.empty(0, dtype=np.uint32), isolated[:20], _seeds(33, num_node, seed=2),
+             _seeds(batch, num_node, seed=3)]
+    for b, seeds in enumerate(plans):
+        d_seeds = dev(seeds) if len(seeds) else torch.empty(0, dtype=torch.int32, device="cuda")
+        sampler.run_batch(b, d_seeds, 900 + b, bt, d_tables[0])
+        m = bt.wait()
+        assert m.overflow == 0 and m.num_output == len(seeds)
+        if len(seeds) == 0:
+            assert m.num_input == 0 and m.num_miss == 0 and m.num_cache == 0
+            continue
+        want = oracle.do_sample(indptr, o_indices, seeds, fanouts, ost, rng, 900 + b, oht, **okw)
+        nodes = host_u32(bt.input_nodes())
+        np.testing.assert_array_equal(nodes, want["input_nodes"])
+        for got, w in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(tables[0], nodes)):
+            np.testing.assert_array_equal(host_u32(got), w)
+        assert m.num_miss + m.num_cache == m.num_input
+        # the same batch against the other table
+        bt.cache_index(d_tables[1])
+        bt.finish()
+        m2 = bt.wait()
+        for got, w in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(tables[1], nodes)):
+            np.testing.assert_array_equal(host_u32(got), w)
+        assert m2.num_miss + m2.num_cache == m2.num_input == len(nodes)
+    np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
+@pytest.mark.gpu
+def test_samplers_created_and_driven_from_two_threads(hip, oracle):
+    """Two host threads, each with its own sampler, batches in flight at the same time (an engine process whose sampler
+    and pre-sampler threads both use the kernel library; a second GPU's sampler in one process): per-device launch
+    attributes and occupancy look-ups are cached behind the C ABI (hashtable_partition.hip: the dynamic-LDS attribute
+    is asked once per DEVICE) and must not depend on which thread or device asked first.  Results stay the oracle's."""
+    import threading
+    errs = []
+
+    def run(kind, fanouts, batch, dim):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(2):
+                    test_batch_driver_matches_oracle(hip, oracle, kind, fanouts, batch, dim)
+        except BaseException as e:  # noqa: BLE001 (reported by the main thread)
+            errs.append((kind, repr(e)))
+    ths = [threading.Thread(target=run, args=a) for a in (("khop2", [25, 10], 3000, 128), ("khop0", [5, 10, 15], 200, 100),
+                                                          ("khop2", [3], 17, 4))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
 
 
 @pytest.mark.gpu
