@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
                                                                    uint32_t *__restrict__ cache_dst,
                                                                    uint32_t *__restrict__ d_counts, ScanWs scan,
                                                                    unsigned long long *stamp, uint32_t own_blocks,
-                                                                   FixTail fix, bool prefilled FGNN_ABLATE_PARAM) {
+                                                                   FixTail fix FGNN_ABLATE_PARAM) {
   if (blockIdx.x >= own_blocks) {  // the last fill's remap fix-up riding along (FixTail, fgnn_device.h)
     run_fix_tail(fix, own_blocks);
     return;
@@ -137,15 +137,14 @@ __global__ __launch_bounds__(kBlock) void cache_split_fused_kernel(const uint32_
       for (int u = 0; u < 4; ++u) {
         const size_t i = c0 + (size_t)(r0 + u) * kBlock + threadIdx.x;
         ok[u] = r0 + u < rounds && i < n;
-        // prefilled: slot[i] == table[nodes[i]] already (looked up by the dedup's count+assign launches, CacheLookup)
-        nd[u] = ok[u] ? (prefilled ? slot[i] : nodes[i]) : 0u;
+        nd[u] = ok[u] ? nodes[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sv[u] = prefilled ? nd[u] : ok[u] && !(ablate & 1u) ? table[nd[u]] : 0u;
+      for (int u = 0; u < 4; ++u) sv[u] = ok[u] && !(ablate & 1u) ? table[nd[u]] : 0u;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (ok[u]) {
-          if (own && !prefilled && !(ablate & 2u)) slot[c0 + (size_t)(r0 + u) * kBlock + threadIdx.x] = sv[u];
+          if (own && !(ablate & 2u)) slot[c0 + (size_t)(r0 + u) * kBlock + threadIdx.x] = sv[u];
           if (sv[u] == FGNN_EMPTY_KEY) {
             mm |= 1u << (r0 + u);
             ++cn;
@@ -329,7 +328,7 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
                                   const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src,
                                   uint32_t *miss_dst, uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts,
                                   void *ws, size_t ws_bytes, void *stream, ScanWsHost *scan,
-                                  unsigned long long *stamp, const FixTail *carry_fix, bool prefilled) {
+                                  unsigned long long *stamp, const FixTail *carry_fix) {
   auto s = static_cast<hipStream_t>(stream);
   size_t cap = d_num_nodes ? num_nodes_cap : num_nodes;
   if (!d_counts) return FGNN_EINVAL;
@@ -364,11 +363,10 @@ int fgnn::get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, 
 #endif
       hipLaunchKernelGGL(cache_split_fused_kernel, dim3(grid + carry.blocks), dim3(kBlock), 0, s, table, nodes,
                          num_nodes, d_num_nodes, cap, slot, miss_src, miss_dst, cache_src, cache_dst, d_counts,
-                         scan->next(2, grid), stamp, (uint32_t)grid, carry, prefilled FGNN_ABLATE_ARG(ablate));
+                         scan->next(2, grid), stamp, (uint32_t)grid, carry FGNN_ABLATE_ARG(ablate));
       return launch_status(__func__);
     }
   }
-  // (the three-launch path below looks every node up itself: a prefilled slot[] is simply overwritten)
   if (carry.mapped) {
     const int rc = hashtable_map_fix(carry, stream);
     if (rc != FGNN_OK) return rc;

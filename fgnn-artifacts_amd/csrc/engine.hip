@@ -63,7 +63,6 @@ struct fgnn_sampler {
   // weighted_khop_prefix: 5-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
   fgnn::PrefixTreeHost *ptree = nullptr;
   int opt_split_l0 = -1;        // FGNN_KHOP_SPLIT_L0 = 0 (profiling build): fused last layer
-  int opt_prelookup = 1;        // FGNN_SPLIT_PRELOOKUP = 0 (profiling build): the cache split looks every node up itself
   int opt_unordered = 0;        // FGNN_KHOP2_UNORDERED = 1 (profiling build): wrong results under overlap
 };
 
@@ -86,8 +85,6 @@ struct fgnn_batch {
   bool timed2;
   bool timing, timed;
   bool meta_copied;                       // the last extract launch of this batch also copied the summary to h_meta
-  bool slot_prefilled;                    // ws[0 .. num_input) holds slot_table[input_nodes[i]] (fgnn::CacheLookup)
-  const uint32_t *slot_table;
   fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
   uint32_t feat_row_mask;                 // SAMGRAPH_EMPTY_FEAT mock extraction (all ones = off)
 };
@@ -150,7 +147,6 @@ extern "C" fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int
   if (!s) return fail(FGNN_EHIP);
   s->cfg = *cfg;
   s->opt_split_l0 = fgnn::tune_int("FGNN_KHOP_SPLIT_L0", -1);
-  s->opt_prelookup = fgnn::tune_int("FGNN_SPLIT_PRELOOKUP", 1);
   s->opt_unordered = fgnn::tune_int("FGNN_KHOP2_UNORDERED", 0);
   // worst-case sizes, layer L-1 first (cuda_loops.cc:87)
   size_t count = cfg->max_batch_size;
@@ -362,13 +358,9 @@ struct SeqGuard {
 
 // DoGPUSample (cuda_loops.cc:50-267) for batch `seq`.  owed_fix != null: the caller takes over the last layer's remap
 // fix-up (it lets a later launch of the batch carry it, FixTail); null: the batch's edge lists are final on return.
-// cache_table (nullable): the direct map the batch's cache split will be made against -- its words are then looked up by
-// the dedup launches as they number the nodes (fgnn::CacheLookup) and out->slot_prefilled tells the split
 int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
-                fgnn_batch *out, void *stream, fgnn::FixTail *owed_fix, const uint32_t *cache_table = nullptr) {
+                fgnn_batch *out, void *stream, fgnn::FixTail *owed_fix) {
   if (owed_fix) *owed_fix = fgnn::no_fix_tail();
-  if (out) out->slot_prefilled = false;
-  if (s && !s->opt_prelookup) cache_table = nullptr;
   if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
     return FGNN_EINVAL;
   const hipStream_t st = static_cast<hipStream_t>(stream);
@@ -437,9 +429,6 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
     table_free = ec == 0 || fgnn::hashtable_can_partition(ht, ec);
     ic += ec;
   }
-  // slot[] of the cache split = the head of the batch's scratch (get_miss_cache_index_ex): nothing else uses it before
-  fgnn::CacheLookup lookup{cache_table, static_cast<uint32_t *>(out->ws), true, false};
-  bool all_looked_up = cache_table != nullptr && num_seeds > 0;
   const uint32_t *cur = d_seeds;
   const uint32_t *d_cur_n = nullptr;  // first layer: host count
   size_t cur_n_host = num_seeds;
@@ -507,11 +496,8 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
                                       LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
                                                    &out->d_meta->num_input},
                                       inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed,
-                                      table_free && l != 0,  // (the last fill decides for itself: nothing follows it)
-                                      cache_table ? &lookup : nullptr);
+                                      table_free && l != 0);  // (the last fill decides for itself: nothing follows it)
     if (rc != FGNN_OK) return rc;
-    all_looked_up = all_looked_up && lookup.done;  // (an empty layer launches nothing: the split looks up itself)
-    lookup.first_fill = lookup.done = false;
     owed = mine;
     in_cap += ecap;
     cur = out->input_nodes;
@@ -528,21 +514,17 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
   if (rc != FGNN_OK) return rc;
   guard.close_slot();
   guard.finished = true;
-  out->slot_prefilled = all_looked_up;
-  out->slot_table = cache_table;
   return launch_status(__func__);
 }
 
 int batch_cache_index(fgnn_batch *b, const uint32_t *cache_table, void *stream, const fgnn::FixTail *carry) {
   b->meta_copied = false;
-  const bool prefilled = b->slot_prefilled && b->slot_table == cache_table;
-  b->slot_prefilled = false;  // (the split may overwrite slot[]; a second split of the same batch looks up itself)
   fgnn::ScanErrorSink sink(&b->d_meta->overflow);
   // num_miss / num_cache are adjacent in the summary: the split kernel writes them in place
   return fgnn::get_miss_cache_index_ex(cache_table, b->input_nodes, 0, &b->d_meta->num_input, b->owner->max_nodes,
                                        b->cidx[0], b->cidx[1], b->cidx[2], b->cidx[3], &b->d_meta->num_miss, b->ws,
                                        b->ws_bytes, stream, b->scan,
-                                       reinterpret_cast<unsigned long long *>(&b->d_meta->t_sampled), carry, prefilled);
+                                       reinterpret_cast<unsigned long long *>(&b->d_meta->t_sampled), carry);
 }
 
 }  // namespace
@@ -575,7 +557,7 @@ extern "C" int fgnn_sampler_sample_indexed(fgnn_sampler *s, const uint32_t *d_se
     seq = s->next_seq++;
   }
   fgnn::FixTail owed = fgnn::no_fix_tail();
-  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr, cache_table);
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr);
   if (rc == FGNN_OK && cache_table) rc = batch_cache_index(out, cache_table, stream, &owed);
   return rc;
 }
@@ -586,7 +568,7 @@ extern "C" int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint3
                                       const void *feat, const void *label, void *stream) {
   fgnn::FixTail owed = fgnn::no_fix_tail();
   // with a cache split to follow, the last layer's remap fix-up rides on that launch
-  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr, cache_table);
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, cache_table ? &owed : nullptr);
   if (rc == FGNN_OK && cache_table) rc = batch_cache_index(out, cache_table, stream, &owed);
   if (rc == FGNN_OK && (feat || label)) rc = fgnn_batch_extract(out, feat, label, stream);
   if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);
@@ -717,7 +699,7 @@ extern "C" int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, cons
                                              void *stream) {
   if (!cache_table) return FGNN_EINVAL;
   fgnn::FixTail owed = fgnn::no_fix_tail();
-  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, &owed, cache_table);
+  int rc = sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, &owed);
   if (rc == FGNN_OK) rc = batch_cache_index(out, cache_table, stream, &owed);
   if (rc == FGNN_OK) rc = fgnn_batch_extract_cached(out, cache_rows, full_feat, label, stream);
   if (rc == FGNN_OK) rc = fgnn_batch_finish(out, stream);

@@ -658,24 +658,12 @@ struct LayerSummary {
   uint32_t *num_src;    // #items after the fill                (TrainGraph::num_src)
   uint32_t *num_total;  // same value again (the batch's running num_input)
 };
-// Cache-table look-ups riding on the dedup's count+assign launch (batch driver with the cache table known at sampling
-// time): slot[local id] = table[node] for every node the fill numbers -- and for the nodes the table held before the
-// batch's first fill (the seeds).  The loads go out before the workgroup waits for its prefix and complete under that
-// wait; the cache split (GetMissCacheIndex, cuda_cache.cu:33-158) then reads slot[] in order instead of making one
-// random look-up per input node into a table of 4 bytes per graph node.  `done` is set by the fill when its launch
-// carried the look-ups (the multi-pass path of very large fills does not).
-struct CacheLookup {
-  const uint32_t *table;  // direct map u32[num_node], FGNN_EMPTY_KEY = not cached; null: nothing to do
-  uint32_t *slot;         // u32[max_items]
-  bool first_fill;        // also look up n2o[0 .. count before the fill)
-  bool done;
-};
 int hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items, size_t num_items,
                                  const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                  size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                  ScanWsHost *scan, bool final_fill = false, bool resolved = false,
                                  FixTail *owed_fix = nullptr, const FixTail *carry_fix = nullptr,
-                                 bool table_free = false, CacheLookup *lookup = nullptr);
+                                 bool table_free = false);
 // table_free: nothing after this fill reads the global table (no fused sampler insert, no fgnn_hashtable_map, and every
 // later fill of the batch is table_free or final too) -- the fill may then go through the partitioned path although it
 // is not the batch's last (the batch driver's samplers that do not insert themselves: every layer).  The promise is
@@ -729,12 +717,11 @@ constexpr size_t kSharedGpuHostGrid = 64;
 constexpr size_t kSharedGpuGatherWgPerCu = 3;
 // fgnn_get_miss_cache_index with look-back descriptors for the one-launch path (scan == null: three launches)
 // carry_fix: an owed remap fix-up; rides on the one-launch split, launched on its own on the three-launch path
-// prefilled: ws[0 .. n) already holds table[nodes[i]] (CacheLookup) -- one-launch path only (scan != null)
 int get_miss_cache_index_ex(const uint32_t *table, const uint32_t *nodes, size_t num_nodes,
                             const uint32_t *d_num_nodes, size_t num_nodes_cap, uint32_t *miss_src, uint32_t *miss_dst,
                             uint32_t *cache_src, uint32_t *cache_dst, uint32_t *d_counts, void *ws, size_t ws_bytes,
                             void *stream, ScanWsHost *scan, unsigned long long *stamp = nullptr,
-                            const FixTail *carry_fix = nullptr, bool prefilled = false);
+                            const FixTail *carry_fix = nullptr);
 // fgnn_sample_weighted_khop_hash_dedup with the slot's look-back descriptors (scan == null: descriptors in ws)
 int sample_hash_dedup(const uint32_t *indptr, const uint32_t *indices, const float *prob_table,
                       const uint32_t *alias_table, const uint32_t *input, size_t num_input, const uint32_t *d_num_input,

@@ -215,8 +215,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
                                                                  uint32_t *d_num_items, uint32_t *__restrict__ n2o,
                                                                  size_t max_items, LayerSummary summary,
                                                                  uint32_t *mapped, ScanWs scan, bool final_fill,
-                                                                 const uint32_t *__restrict__ disp, bool exact,
-                                                                 CacheLookup lk) {
+                                                                 const uint32_t *__restrict__ disp, bool exact) {
   // disp != null (implies final_fill): pos[] holds the OUTCOMES of a resolving insert (fgnn_device.h), not buckets --
   // the value the bucket read below would have returned, up to take-overs noted in disp[]: no table access at all.
   // exact (implies final_fill, disp == null): pos[] holds the FINAL outcomes (the partitioned fill,
@@ -229,12 +228,9 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
   const uint32_t chunk = rounds * kBlock;
   const uint32_t ntiles = n ? (n - 1) / chunk + 1 : 1u;
   const uint32_t tile = scan_take_tile(scan, sh_tile);
-  const uint32_t old = d_num_items[1];
-  // CacheLookup, first fill of a batch: the nodes the table held before it (the seeds), a slice per workgroup
-  if (lk.table && lk.first_fill)
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < old; i += gridDim.x * kBlock) lk.slot[i] = lk.table[n2o[i]];
   if (tile >= ntiles) return;  // whole workgroup; nobody looks back at an unused tile
   phase_mark(scan, tile, 0);
+  const uint32_t old = d_num_items[1];
   // owners among the items of tile `tl` (bit r of *mask: this thread's item of round r is one).  own = true: this
   // workgroup's tile -- the remap entries of non-owners are written on the way.  own = false: another tile's count,
   // recomputed by a waiter that helps (scan_prefix_help): same reads, no writes.
@@ -308,15 +304,6 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
   // published: a helper that recounts this tile either still sees the pending values or -- release here, acquire +
   // descriptor re-check there -- finds the published word and takes that
   if (!final_fill && threadIdx.x == 0) __atomic_thread_fence(__ATOMIC_RELEASE);
-  // CacheLookup: the cache-table words of this tile's owners (first four rounds: all of them at mini-batch sizes) are
-  // requested now and arrive while the workgroup waits for its prefix below
-  constexpr int kPre = 4;
-  uint32_t pre_slot[kPre];
-#pragma unroll
-  for (int u = 0; u < kPre; ++u) {
-    pre_slot[u] = FGNN_EMPTY_KEY;
-    if (lk.table && ((owner_mask >> u) & 1u)) pre_slot[u] = lk.table[items[chunk0 + (size_t)u * kBlock + threadIdx.x]];
-  }
   const uint32_t before = scan_prefix_help(scan, tile, sh_tile, [&](uint32_t m) -> uint32_t {
     uint32_t mask_m, tot_m;
     const uint32_t cm = count_chunk(m, false, &mask_m);
@@ -332,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
     if (summary.num_total) *summary.num_total = now;
   }
   uint32_t running = old + before;
-  auto assign_round = [&](uint32_t r, uint32_t looked_up, bool have_lookup) {
+  for (uint32_t r = 0; r < rounds; ++r) {
     const size_t i = chunk0 + (size_t)r * kBlock + threadIdx.x;
     const bool owner = (owner_mask >> r) & 1u;
     uint32_t t2;
@@ -345,18 +332,12 @@ __global__ __launch_bounds__(kBlock) void ht_count_assign_kernel(HtView t, const
         if (!final_fill)
           __hip_atomic_store(reinterpret_cast<uint32_t *>(&t.table[pos[i]]), t.gen_base | local, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t key = items[i];
-        n2o[local] = key;
-        if (lk.table) lk.slot[local] = have_lookup ? looked_up : lk.table[key];
+        n2o[local] = items[i];
       }
       if (mapped) mapped[i] = local < max_items ? local : FGNN_EMPTY_KEY;
     }
     running += t2;
-  };
-#pragma unroll
-  for (int r = 0; r < kPre; ++r)
-    if ((uint32_t)r < rounds) assign_round((uint32_t)r, pre_slot[r], true);  // (uniform: barriers inside)
-  for (uint32_t r = kPre; r < rounds; ++r) assign_round(r, 0u, false);
+  }
   phase_mark(scan, tile, 3);
 }
 
@@ -573,7 +554,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
                                        const size_t *d_num_items, size_t num_items_cap, uint32_t *mapped, void *ws,
                                        size_t ws_bytes, void *stream, LayerSummary summary, bool already_inserted,
                                        ScanWsHost *scan, bool final_fill, bool resolved, FixTail *owed_fix,
-                                       const FixTail *carry_fix, bool table_free, CacheLookup *lookup) {
+                                       const FixTail *carry_fix, bool table_free) {
   if (!ht) return FGNN_EINVAL;
   if (owed_fix) *owed_fix = no_fix_tail();  // mapped != null on return: the caller owes this fill's fix-up
   FixTail carry = carry_fix && carry_fix->mapped ? *carry_fix : no_fix_tail();
@@ -632,9 +613,7 @@ int fgnn::hashtable_fill_duplicates_ex(fgnn_hashtable *ht, const uint32_t *items
       hipLaunchKernelGGL(ht_count_assign_kernel, dim3(grid), dim3(kBlock), 0, s, tv, items, num_items,
                          d_num_items, cap, pos, ht->d_num_items, ht->n2o, ht->max_items, summary, mapped,
                          scan->next(1, grid), (final_fill || exact) && mapped != nullptr,
-                         resolved && !exact ? ht->disp : nullptr, exact,
-                         lookup ? *lookup : CacheLookup{nullptr, nullptr, false, false});
-      if (lookup && lookup->table) lookup->done = true;
+                         resolved && !exact ? ht->disp : nullptr, exact);
       if (mapped) {
         const FixTail fix{mapped, d_num_items, num_items, cap, tv.pend, fix_tail_blocks(cap)};
         if (owed_fix) *owed_fix = fix;

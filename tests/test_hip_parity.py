@@ -690,7 +690,7 @@ def test_batch_driver_large_frontier(hip, oracle):
         if b == 0:
             sampler.sample(dev(seeds), 50 + b, bt)
             bt.cache_index(d_table)
-        else:  # cache-table words looked up by the dedup launches, > 4 rounds per workgroup (fgnn::CacheLookup)
+        else:  # sample + split as one call (what an arch5 sampler does), > 4 rounds per workgroup in the split
             sampler.sample_indexed(dev(seeds), 50 + b, bt, d_table)
         bt.extract(d_feat, d_label)
         bt.finish()
@@ -750,13 +750,13 @@ def test_batch_driver_layer_beyond_the_one_launch_dedup(hip, oracle, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["khop2", "khop0", "khop1", "random_walk"])
-def test_run_batch_looks_the_cache_table_up_while_deduplicating(hip, oracle, kind):
-    """fgnn_sampler_run_batch with a cache table: the dedup's count+assign launches look the table up for every node as
-    they number it (fgnn::CacheLookup) and the split reads those words instead of making its own look-ups
-    (GetMissCacheIndex, cuda_cache.cu:33-158: same four lists).  Covered: the fused k-hop inserts, the partitioned
-    table-free fills (khop1, random walk), empty batches, batches of isolated seeds (no fill launches at all: the split
-    looks up itself), a short batch after a long one on the same buffer, and a second split of the same batch against
-    ANOTHER table (must not reuse the first table's words)."""
+def test_run_batch_with_a_cache_table_then_a_second_split(hip, oracle, kind):
+    """fgnn_sampler_run_batch with a cache table (sample + GetMissCacheIndex in one call, cuda_cache.cu:33-158), per
+    sampler family: the fused k-hop inserts, the partitioned table-free fills (khop1, random walk); empty batches,
+    batches of isolated seeds (no fill launches at all), a short batch after a long one on the same buffer, and a
+    second split of the same batch against ANOTHER table (nothing of the first split may be reused).  (Written for a
+    variant that looked the table up inside the dedup launches -- profiles/NOTES_rejected_experiments.md, round 5 --
+    and kept: it is the only test that splits one batch twice.)"""
     from fgnn_hip import synth
     num_node = 60000
     indptr, indices = synth.powerlaw_csr(num_node, 900000, seed=44)
