@@ -1013,7 +1013,11 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
     model = MODELS["graphsage"](w["feat_dim"], 256, w["num_class"], L, 0.5).to(dev)
     loss_fcn = torch.nn.CrossEntropyLoss()
     graphed = not args.eager_train
-    opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True, capturable=graphed)
+    # Adam as ONE launch with the step count on the device (fgnn_hip.nn.Adam = torch.optim.Adam's update, checked
+    # against it in tests/test_train_ops_gpu.py); its step count also keys the fused ReLU + dropout masks
+    from fgnn_hip.nn import Adam as FusedAdam
+    opt = FusedAdam(model.parameters(), lr=0.003)
+    model.dropout_step = opt.step_count
     model.train()
     # the step replayed as a captured HIP graph (examples/graphed_step.py); --eager-train: op by op like the reference's
     # loop.  Eager, the step is bound by the ~40 ops Python launches (0.83 ms of host time for ~0.5 ms of kernels); a
@@ -1399,7 +1403,10 @@ def run_pipeline_rank(args, rank, world):
                 model = torch.nn.parallel.DistributedDataParallel(
                     model, device_ids=[dev_id] if n_dev >= world else None, process_group=tgroup)
             loss_fcn = torch.nn.CrossEntropyLoss()
-            opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=True)
+            from fgnn_hip.nn import softmax_xent
+            from fgnn_hip.nn import Adam as FusedAdam
+            opt = FusedAdam(model.parameters(), lr=0.003)
+            (model.module if T > 1 else model).dropout_step = opt.step_count
             model.train()
 
         now = lambda: time.clock_gettime(time.CLOCK_MONOTONIC)  # noqa: E731  (one node: every rank reads the same clock)
@@ -1432,9 +1439,10 @@ def run_pipeline_rank(args, rank, world):
                     key = be.next_batch()
                     if train:
                         blocks, feat, label = be.blocks(key)
-                        loss = loss_fcn(model(blocks, feat), label)
+                        out = model(blocks, feat)
+                        loss, g = softmax_xent(out, label)  # CrossEntropyLoss + its gradient, one launch
                         opt.zero_grad()
-                        loss.backward()
+                        out.backward(g)
                         opt.step()
                         torch.cuda.current_stream().synchronize()
                     stamps.append((now(), key))

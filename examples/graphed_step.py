@@ -39,10 +39,33 @@ class GraphedSageStep:
         self.eager_steps = self.replays = 0
         self._primed = False
 
-    def _eager(self, blocks, x, y):
-        loss = self.loss_fcn(self.model(blocks, x), y)
+    def _loss_backward(self, out, y):
+        """loss of the first batch_size rows of `out` + backward.  CrossEntropyLoss (mean, unweighted) on the GPU goes
+        through fgnn_softmax_xent: loss and the logits' gradient from one launch, the gradient already padded with
+        zero rows to out's shape -- log_softmax, nll_loss, their two backward ops, the slice's zeros + copy: six nodes
+        less in the replayed graph."""
+        n = min(self.batch_size, out.shape[0])
+        lf = self.loss_fcn
+        if (isinstance(lf, th.nn.CrossEntropyLoss) and lf.reduction == "mean" and lf.weight is None
+                and lf.label_smoothing == 0.0 and out.is_cuda and out.dtype == th.float32 and y.dtype == th.int64):
+            try:
+                from fgnn_hip.nn import softmax_xent
+            except ImportError:
+                softmax_xent = None
+            if softmax_xent is not None:
+                loss, g = softmax_xent(out[:n], y[:n].contiguous(), pad_rows=out.shape[0] - n)
+                self.opt.zero_grad(set_to_none=True)
+                out.backward(g)
+                return loss
+        loss = lf(out[:n], y[:n])
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
+        return loss
+
+    def _eager(self, blocks, x, y):
+        out = self.model(blocks, x)
+        self._ncls = out.shape[1]
+        loss = self._loss_backward(out, y)
         self.opt.step()
         self.eager_steps += 1
         # (detached: an autograd graph of an eager step that stays alive keeps its AccumulateGrad nodes bound to the
@@ -87,12 +110,16 @@ class GraphedSageStep:
         if entry is None:
             blocks = [make_block(bufs[l][0][:eb[l]], bufs[l][1][:eb[l]], sb0 if l == 0 else db[l - 1] + 1, db[l] + 1)
                       for l in range(L)]
+            if getattr(self, "_ncls", None) and x_full.is_cuda:  # the padded gradient buffer of the fused loss: not inside
+                try:                                              # the capture
+                    from fgnn_hip.nn import xent_grad_buffer
+                    xent_grad_buffer(x_full.device, db[L - 1] + 1, self._ncls)
+                except ImportError:
+                    pass
             g = th.cuda.CUDAGraph()
             with th.cuda.graph(g):
                 out = self.model(blocks, x_full[:sb0])
-                loss = self.loss_fcn(out[:self.batch_size], y)
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
+                loss = self._loss_backward(out, y)
                 self.opt.step()
             # (the entry keeps the batch object alive: its graphs replay on its buffers' addresses)
             entry = self.graphs[key] = (g, loss.detach(), bt)

@@ -123,28 +123,28 @@ class _FusedSageFn(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, weight, bias, block, num_dst):
-        from fgnn_hip.nn import aggregate_into
+        from fgnn_hip.nn import aggregate_into, sage_finish_z
         h = h.contiguous()
         din = h.shape[1]
-        z = th.zeros((num_dst, 2 * din), dtype=h.dtype, device=h.device)
-        inv = getattr(block, "_inv_in_degree", None)
-        deg = th.zeros(num_dst, dtype=h.dtype, device=h.device) if inv is None else None
+        # z and the in-degree counts out of ONE zeroed buffer (one fill), the neighbour sums and the counts by one
+        # launch, the mean's scaling and the copy of the destinations' own rows by one more (fgnn_sage_finish_z)
+        buf = th.zeros(num_dst * (2 * din + 1), dtype=h.dtype, device=h.device)
+        z = buf[:num_dst * 2 * din].view(num_dst, 2 * din)
+        deg = buf[num_dst * 2 * din:]
         aggregate_into(z[:, din:], h, block.row, block.col, in_degree=deg)
-        if inv is None:
-            inv = deg.clamp_(min=1).reciprocal_()
-            try:
-                block._inv_in_degree = inv  # a block is seen by one layer per step, forward and backward
-            except AttributeError:
-                pass
-        z[:, din:] *= inv.unsqueeze(1)
-        z[:, :din] = h[:num_dst]
+        if din % 4 == 0:
+            inv = sage_finish_z(z, h, deg, num_dst, din)
+        else:
+            inv = deg.clamp(min=1).reciprocal_()
+            z[:, din:] *= inv.unsqueeze(1)
+            z[:, :din] = h[:num_dst]
         ctx.save_for_backward(z, weight, block.row, block.col, inv)
         ctx.num_src = h.shape[0]
         return th.addmm(bias, z, weight.t())
 
     @staticmethod
     def backward(ctx, gout):
-        from fgnn_hip.nn import aggregate_into
+        from fgnn_hip.nn import aggregate_into, sage_grad_prep
         z, weight, row, col, inv_deg = ctx.saved_tensors
         gout = gout.contiguous()
         din = z.shape[1] // 2
@@ -153,9 +153,13 @@ class _FusedSageFn(th.autograd.Function):
         gh = None
         if ctx.needs_input_grad[0]:
             gz = gout.mm(weight)
-            gagg = gz[:, din:] * inv_deg.unsqueeze(1)  # (contiguous: a new tensor)
-            gh = aggregate_into(th.zeros((ctx.num_src, din), dtype=gz.dtype, device=gz.device), gagg, col, row)
-            gh[:z.shape[0]] += gz[:, :din]
+            if din % 4 == 0:  # self path + zero rows + scaled neighbour gradients in one launch
+                gh, gagg = sage_grad_prep(gz, inv_deg, ctx.num_src, din)
+                aggregate_into(gh, gagg, col, row)
+            else:
+                gagg = gz[:, din:] * inv_deg.unsqueeze(1)  # (contiguous: a new tensor)
+                gh = aggregate_into(th.zeros((ctx.num_src, din), dtype=gz.dtype, device=gz.device), gagg, col, row)
+                gh[:z.shape[0]] += gz[:, :din]
         return gh, gw, gb, None, None
 
 
@@ -230,13 +234,21 @@ class SAGE(nn.Module):
         conv = FusedSAGEConv if fused else SAGEConvMean
         self.layers = nn.ModuleList(conv(dims[i], dims[i + 1]) for i in range(n_layers))
         self.dropout = nn.Dropout(dropout)
+        # set by a training loop that uses fgnn_hip.nn.Adam: its device-side step count keys the dropout masks, so
+        # ReLU + dropout run as ONE launch (fgnn_relu_dropout) and a replayed graph still draws a fresh mask per step
+        self.dropout_step = None
+        self.dropout_seed = 0x5A4D47
 
     def forward(self, blocks, x):
         h = x
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
             h = layer(block, h)
             if l != len(self.layers) - 1:
-                h = self.dropout(F.relu(h))
+                if self.dropout_step is not None and h.is_cuda and h.dtype == th.float32 and h.numel() % 4 == 0:
+                    from fgnn_hip.nn import relu_dropout
+                    h = relu_dropout(h, self.dropout.p, self.training, self.dropout_seed, self.dropout_step, l)
+                else:
+                    h = self.dropout(F.relu(h))
         return h
 
 

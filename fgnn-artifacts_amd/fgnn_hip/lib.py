@@ -32,6 +32,8 @@ EXPORTS = [
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
     "fgnn_presample_count", "fgnn_presample_rank_scratch_bytes", "fgnn_presample_rank", "fgnn_cache_table_build",
     "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_gather_rows_shared", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
+    "fgnn_sage_finish_z", "fgnn_sage_grad_prep", "fgnn_relu_dropout", "fgnn_relu_dropout_backward",
+    "fgnn_softmax_xent_scratch_bytes", "fgnn_softmax_xent", "fgnn_adam_step",
 ]
 
 _lib = None

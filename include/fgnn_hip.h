@@ -267,6 +267,39 @@ int fgnn_block_aggregate_ex(const uint32_t *src_index, const uint32_t *dst_index
                             size_t num_edge, const float *h, size_t dim, float *out, size_t out_ld, float *in_degree,
                             void *stream);
 
+/* ---- fused pieces of a GraphSAGE training step (consumer side, csrc/train_ops.hip) ----------------------------------
+ * Elementwise work a training step otherwise does with two to four framework ops each; one launch apiece because the
+ * step is replayed as a captured HIP graph, where every node costs the GPU 15-20 us whatever it does.  fp32, the same
+ * arithmetic per element as the ops they replace (reference: the DGL / PyTorch layers and loop of
+ * example/samgraph/multi_gpu/train_graphsage.py:24-51,300-330). */
+/* SAGEConv('mean') forward, after fgnn_block_aggregate_ex has summed the neighbours into z[:, din:2 din) and counted the
+ * in-degrees: inv[i] = 1 / max(deg[i], 1); z[i, din:] *= inv[i]; z[i, :din] = h[i, :din].  din % 4 == 0, 16-byte
+ * aligned rows. */
+int fgnn_sage_finish_z(float *z, size_t ld, const float *h, size_t h_ld, const float *deg, float *inv, size_t num_dst,
+                       size_t din, void *stream);
+/* its backward half: gh[i, :] = gz[i, :din] for i < num_dst, 0 for num_dst <= i < num_src (the self path; the neighbour
+ * path is then ADDED by fgnn_block_aggregate with row / col swapped); gagg[i, :] = gz[i, din:] * inv[i]. */
+int fgnn_sage_grad_prep(const float *gz, size_t gz_ld, const float *inv, float *gh, float *gagg, size_t num_dst,
+                        size_t num_src, size_t din, void *stream);
+/* y = relu(x) * keep / (1 - p) with keep ~ Bernoulli(1 - p): Philox keyed by (seed, *d_step, layer_tag, element).
+ * d_step (device, nullable): the training step count fgnn_adam_step keeps.  n % 4 == 0.
+ * backward: gx = gy / (1 - p) where y > 0, else 0. */
+int fgnn_relu_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, const unsigned long long *d_step,
+                      uint32_t layer_tag, void *stream);
+int fgnn_relu_dropout_backward(const float *y, const float *gy, float *gx, size_t n, float p, void *stream);
+/* CrossEntropyLoss(reduction='mean') and its gradient in one launch: *loss = mean_i (logsumexp(x_i) - x_i[label_i]),
+ * dlogits[i, c] = (softmax(x_i)[c] - [c == label_i]) / n.  The mean is summed in a fixed order (bit-reproducible).
+ * ws: fgnn_softmax_xent_scratch_bytes(n) bytes, its first 16 zeroed ONCE by the caller (the launches keep them zero). */
+size_t fgnn_softmax_xent_scratch_bytes(size_t n);
+int fgnn_softmax_xent(const float *logits, size_t ld, const long long *labels, size_t n, size_t num_class, float *loss,
+                      float *dlogits, size_t dl_ld, void *ws, size_t ws_bytes, void *stream);
+/* torch.optim.Adam's update (no amsgrad) for up to 8 tensors in one launch; h_* are HOST arrays of device pointers /
+ * sizes.  d_step: device, two 64-bit words zeroed once by the caller -- [0] the number of steps taken (read, then
+ * advanced by this launch), [1] scratch. */
+int fgnn_adam_step(float *const *h_params, const float *const *h_grads, float *const *h_exp_avg,
+                   float *const *h_exp_avg_sq, const size_t *h_numel, int count, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, unsigned long long *d_step, void *stream);
+
 /* ---- pre-sampling cache policy (init-time) --------------------------------------------------
  * PreSampler (dist/pre_sampler.cc:75-162): freq[node] += 1 for every input node of every presample batch, then
  * rank = nodes by (frequency desc, id desc).  fgnn_cache_table_build = SampleCacheTableInit (dist_engine.cc:193-229):

@@ -1010,7 +1010,8 @@ def test_fused_sage_layer_matches_the_op_by_op_layer(hip, din, dout, first_layer
 
 
 @pytest.mark.gpu
-def test_graphed_training_step_equals_the_eager_step(hip):
+@pytest.mark.parametrize("fused_adam", [False, True])
+def test_graphed_training_step_equals_the_eager_step(hip, fused_adam):
     """examples/graphed_step.py: the GraphSAGE training step replayed as a captured HIP graph on the batch buffers'
     full-capacity tensors, sizes rounded up to buckets, padded edges pointed at a discarded row -- against the same
     steps taken op by op (the reference's loop, train_graphsage.py:300-330) from the same initial weights on the same
@@ -1038,6 +1039,10 @@ def test_graphed_training_step_equals_the_eager_step(hip):
     loss_fcn = torch.nn.CrossEntropyLoss()
     opt_e = torch.optim.Adam(model_e.parameters(), lr=0.01, fused=True, capturable=True)
     opt_g = torch.optim.Adam(model_g.parameters(), lr=0.01, fused=True, capturable=True)
+    if fused_adam:  # the one-launch Adam with its step count on the device (fgnn_hip.nn.Adam), as bench.py's train legs
+        from fgnn_hip.nn import Adam
+        opt_g = Adam(model_g.parameters(), lr=0.01)
+        model_g.dropout_step = opt_g.step_count  # (dropout 0.0 here: the fused ReLU launch without a mask)
     stepper = GraphedSageStep(model_g, opt_g, loss_fcn, batch, edge_bucket=2048, node_bucket=1024, inner_bucket=256)
     losses = []
     for b in range(4):

@@ -34,14 +34,28 @@ b1 = Block(torch.randint(0, D0, (E1,), device=dev, generator=g, dtype=torch.int3
 x = torch.randn(S0, 128, device=dev)
 y = torch.randint(0, 172, (8000,), device=dev)
 model = SAGE(128, 256, 172, 2, 0.5, fused=os.environ.get('SAGE_FUSED', '1') == '1').to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=os.environ.get('ADAM_FUSED', '1') == '1')
+# TRAIN_OPS=1 (default): the one-launch pieces of csrc/train_ops.hip as bench.py's train legs use them (fgnn_hip.nn.Adam,
+# fused ReLU + dropout keyed by its step count, fgnn_softmax_xent); 0: torch's fused Adam, F.relu + Dropout, CrossEntropyLoss
+TRAIN_OPS = os.environ.get('TRAIN_OPS', '1') == '1'
 lossf = nn.CrossEntropyLoss()
+if TRAIN_OPS:
+    from fgnn_hip.nn import Adam, softmax_xent
+    opt = Adam(model.parameters(), lr=0.003)
+    model.dropout_step = opt.step_count
+else:
+    opt = torch.optim.Adam(model.parameters(), lr=0.003, fused=os.environ.get('ADAM_FUSED', '1') == '1', capturable=True)
 
 
 def step():
-    loss = lossf(model([b0, b1], x), y)
-    opt.zero_grad()
-    loss.backward()
+    out = model([b0, b1], x)
+    if TRAIN_OPS:
+        loss, g = softmax_xent(out, y)
+        opt.zero_grad()
+        out.backward(g)
+    else:
+        loss = lossf(out, y)
+        opt.zero_grad()
+        loss.backward()
     opt.step()
 
 
@@ -54,7 +68,38 @@ for _ in range(20):
     step()
 e1.record()
 torch.cuda.synchronize()
-print("step %.3f ms (SAGE_FUSED=%s)" % (e0.elapsed_time(e1) / 20, os.environ.get('SAGE_FUSED', '1')))
+print("eager step %.3f ms (SAGE_FUSED=%s TRAIN_OPS=%s)" % (e0.elapsed_time(e1) / 20, os.environ.get('SAGE_FUSED', '1'), TRAIN_OPS))
+# the same step replayed as a captured graph (what examples/graphed_step.py does per size bucket)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(3):
+        graph.replay()
+    side.synchronize()
+    e0.record()
+    for _ in range(20):
+        graph.replay()
+    e1.record()
+    side.synchronize()
+    print("graph replay %.3f ms per step" % (e0.elapsed_time(e1) / 20))
+    with profile(activities=[ProfilerActivity.CUDA]) as gprof:
+        for _ in range(5):
+            graph.replay()
+        side.synchronize()
+    rows = [(e.key, e.count, e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total)
+            for e in gprof.key_averages()]
+    rows.sort(key=lambda r: -r[2])
+    nk = sum(r[1] for r in rows) / 5
+    print("graph: %.0f kernel / memset nodes per step, %.0f us of device time per step" % (nk, sum(r[2] for r in rows) / 5))
+    for k, c, t in rows[:40]:
+        print("  %-90s x%-3d %8.1f us per step" % (k[:90], c // 5, t / 5))
+torch.cuda.current_stream().wait_stream(side)
+if os.environ.get("GRAPH_ONLY"):
+    sys.exit(0)
 # weight-gradient GEMM gy^T x at the row counts a batch's layers have: library GEMM against the 32-slice batched GEMM
 for m in (8000, 22500, 88000, 302000):
     for (k, n) in ((128, 256), (256, 172)):
