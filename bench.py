@@ -60,6 +60,24 @@ SAMPLE_TYPES = {"khop0": lib.KHOP0, "khop1": lib.KHOP1, "khop2": lib.KHOP2, "wei
                 "weighted_khop_hash_dedup": lib.WEIGHTED_KHOP_HASH_DEDUP}
 
 
+class no_gc:
+    """Timed regions run with Python's cyclic garbage collector off (collected right before): a generation-2 pass over
+    the process's objects took 40-60 ms when it fell into a 64-batch region (the extract leg read 0.75-0.92 instead of
+    0.20 ms per batch for some --steps values and not for others: which allocation crosses the collector's threshold is
+    a function of everything allocated before; profiles/r05_i_gc_pause.txt)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 def gen_alias_on_gpu(indices, total, seed, device):
     """prob_table f32[E] / alias_table u32[E] (node ids) for the alias-method samplers: random acceptance
     probabilities, alias = the row neighbour one position further (any node id is a valid table entry) -- same memory
@@ -545,10 +563,11 @@ def run_single(args):
         for t in range(NT):
             host_busy[t] = 0.0
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_region(seq0 + r * args.steps, seq0 + (r + 1) * args.steps, True)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        with no_gc():
+            t0 = time.perf_counter()
+            run_region(seq0 + r * args.steps, seq0 + (r + 1) * args.steps, True)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
         assert len(metas) == args.steps, (len(metas), args.steps)
         windows.append(dict(elapsed=el, metas=list(metas), gather_ms=list(gather_ms),
                             host_enqueue_ms=sum(host_busy) / args.steps * 1e3))
@@ -579,10 +598,11 @@ def run_single(args):
         run_region(next_seq, next_seq + 8, False)
         next_seq += 8
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_region(next_seq, next_seq + n_stage, True)
-        torch.cuda.synchronize()
-        t_stage = time.perf_counter() - t1
+        with no_gc():
+            t1 = time.perf_counter()
+            run_region(next_seq, next_seq + n_stage, True)
+            torch.cuda.synchronize()
+            t_stage = time.perf_counter() - t1
         next_seq += n_stage
         stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
         ab_s = algorithmic_bytes(metas, w["feat_dim"], bs)
@@ -603,7 +623,8 @@ def run_single(args):
     if (NT > 1 or SPT > 1) and not args.timed_only:
         nt_saved, spt_saved = NT, SPT
         NT = SPT = 1
-        run_region(next_seq, next_seq + 24, True)
+        with no_gc():
+            run_region(next_seq, next_seq + 24, True)
         next_seq += 24
         torch.cuda.synchronize()
         gsel = [x for x in gather_ms if x >= 0]
@@ -923,10 +944,11 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     run_region(next_seq, next_seq + 6, False)
     next_seq += 6
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run_region(next_seq, next_seq + n, True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t1
+    with no_gc():
+        t1 = time.perf_counter()
+        run_region(next_seq, next_seq + n, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
     next_seq += n
     edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
     rows = sum(int(m.num_input) for m in metas)
@@ -1074,7 +1096,8 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
 
     region(next_seq, warm)  # untimed: GEMM kernel selection, optimizer state, lazily loaded code objects
     next_seq += warm
-    dt = region(next_seq, timed)
+    with no_gc():
+        dt = region(next_seq, timed)
     next_seq += timed
     return {"ms_per_step": dt / timed * 1e3, "steps": timed,
             "host_ms_per_step": {k: v / timed * 1e3 for k, v in phases.items()},
@@ -1417,6 +1440,9 @@ def run_pipeline_rank(args, rank, world):
             one CLOCK_MONOTONIC stamp per consumed batch).  Returns (stamps [(t, key)], seconds in this rank's loop)."""
             mine = split_count(total, S, idx) if is_sampler else split_count(total, T, idx)
             stamps = []
+            import gc
+            gc.collect()
+            gc.disable()  # (no_gc: a collector pass inside a rank's loop is a multi-millisecond hole in the stamps)
             dist.barrier()
             t0 = now()
             if is_sampler:
@@ -1448,6 +1474,7 @@ def run_pipeline_rank(args, rank, world):
                     stamps.append((now(), key))
                     keys.append((key // steps_per_epoch, key % steps_per_epoch))
                 loop_s = now() - t0
+            gc.enable()
             dist.barrier()  # every batch of the span has been consumed
             return stamps, loop_s
 
@@ -1789,9 +1816,10 @@ def run_n1_point_child():
     setup = time.time() - t0
     sam.start()
     stamps = []
-    for _ in range(total):
-        key = sam.get_next_batch()
-        stamps.append((time.clock_gettime(time.CLOCK_MONOTONIC), key))
+    with no_gc():
+        for _ in range(total):
+            key = sam.get_next_batch()
+            stamps.append((time.clock_gettime(time.CLOCK_MONOTONIC), key))
     _, wins = read_windows(stamps, lead, R, K)
     win_ms = [(b - a) / K * 1e3 for a, b, _ in wins]
     med = sorted(range(R), key=lambda r: win_ms[r])[(R - 1) // 2]
