@@ -1724,7 +1724,7 @@ def link_selftest(dist, rank, world, dev_id, n_dev, rehearse, limit_s=None):
     and the record says which ranks failed and why.  Returns (record on rank 0 | None, rccl_ok on every rank)."""
     import datetime
     if limit_s is None:
-        limit_s = float(os.environ.get("FGNN_BENCH_LINK_TIMEOUT", "90"))
+        limit_s = float(os.environ.get("FGNN_BENCH_LINK_TIMEOUT", "150"))
     if rehearse:
         return {"rccl_world": None, "why": "control-plane rehearsal: no GPU work"}, True
     ok = True

@@ -178,6 +178,23 @@ class FusedSAGEConv(nn.Module):
         bound = 1 / in_feats ** 0.5
         nn.init.uniform_(self.bias, -bound, bound)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """accepts the op-by-op layout too (fc_self.weight / fc_neigh.weight / fc_neigh.bias: SAGEConvMean here, DGL's
+        SAGEConv in the reference's checkpoints): the two maps side by side are this layer's weight"""
+        ks, kn, kb = prefix + "fc_self.weight", prefix + "fc_neigh.weight", prefix + "fc_neigh.bias"
+        if ks in state_dict and kn in state_dict and prefix + "weight" not in state_dict:
+            state_dict[prefix + "weight"] = th.cat([state_dict.pop(ks), state_dict.pop(kn)], 1)
+            if kb in state_dict:
+                state_dict[prefix + "bias"] = state_dict.pop(kb)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def split_state_dict(self, prefix=""):
+        """this layer's parameters in the op-by-op layout (what SAGEConvMean / DGL's SAGEConv load)"""
+        d = self.in_feats
+        return {prefix + "fc_self.weight": self.weight.detach()[:, :d].clone(),
+                prefix + "fc_neigh.weight": self.weight.detach()[:, d:].clone(),
+                prefix + "fc_neigh.bias": self.bias.detach().clone()}
+
     def forward(self, block, h):
         num_dst = block.number_of_dst_nodes()
         if (_fused_aggregate is not None and h.is_cuda and h.dtype == th.float32

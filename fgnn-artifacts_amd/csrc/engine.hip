@@ -385,9 +385,19 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
   // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
   // stream, by the slot's event otherwise
   sl.expect_cross = sl.was_used && sl.last_st != st;
+  // a late record goes to the stream that used the slot last -- a handle the caller may have destroyed meanwhile (a
+  // temporary pre-sampling stream): then everything that stream ever held has long been submitted, and waiting for the
+  // device covers it
+  auto late_record = [&](hipEvent_t ev, hipStream_t on) -> bool {
+    if (hipEventRecord(ev, on) == hipSuccess) return true;
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    return false;
+  };
   if (sl.expect_cross) {
-    if (!sl.done_recorded) FGNN_HIP_CHECK(hipEventRecord(sl.done, sl.last_st));  // late: covers more than needed
-    FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+    bool have = sl.done_recorded;
+    if (!have) have = late_record(sl.done, sl.last_st);  // late: covers more than needed
+    if (have) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
   }
   if (ordered && seq > 0) {
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
@@ -399,8 +409,9 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
     const bool cross = prev.last_st != st;
     s->csr_cross.store(cross, std::memory_order_relaxed);  // this batch records its own hand-over if it needed one
     if (cross) {
-      if (!prev.csr_recorded) FGNN_HIP_CHECK(hipEventRecord(prev.csr, prev.last_st));  // late (see csr_cross)
-      FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
+      bool have = prev.csr_recorded;
+      if (!have) have = late_record(prev.csr, prev.last_st);  // late (see csr_cross)
+      if (have) FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
     }
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)

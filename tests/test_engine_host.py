@@ -278,3 +278,37 @@ def test_profiler_reports_and_trace_dump(tmp_path, level):
     assert not [n for n in names if n[0].startswith("kL1Event_Copy-")] and "without end" in p.stderr
     t = {(e["name"], e["ph"]): e["ts"] for e in ev}
     assert t[("kL1Event_Train-5", "B")] == 1000 and t[("kL1Event_Train-5", "E")] == 1500
+
+
+def test_fused_sage_layer_loads_the_op_by_op_checkpoint_layout():
+    """examples/models.py: a state dict in the reference's layout (fc_self / fc_neigh per layer: dgl.nn.SAGEConv, this
+    repo's SAGEConvMean) loads into the default fused layers, and back (advisor, round 4); same outputs on the CPU path"""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    import models
+
+    class Block:
+        def __init__(self, row, col, ndst):
+            self.row, self.col, self.ndst = row, col, ndst
+
+        def number_of_dst_nodes(self):
+            return self.ndst
+
+    torch.manual_seed(0)
+    ref = models.SAGE(12, 16, 5, 2, 0.0, fused=False)
+    fused = models.SAGE(12, 16, 5, 2, 0.0, fused=True)
+    fused.load_state_dict(ref.state_dict())
+    b0 = Block(torch.randint(0, 40, (200,)), torch.sort(torch.randint(0, 20, (200,)))[0], 20)
+    b1 = Block(torch.randint(0, 20, (60,)), torch.sort(torch.randint(0, 7, (60,)))[0], 7)
+    x = torch.randn(40, 12)
+    ref.eval()
+    fused.eval()
+    torch.testing.assert_close(fused([b0, b1], x), ref([b0, b1], x), rtol=1e-5, atol=1e-6)
+    back = {}
+    for i, layer in enumerate(fused.layers):
+        back.update(layer.split_state_dict("layers.%d." % i))
+    ref2 = models.SAGE(12, 16, 5, 2, 0.0, fused=False)
+    ref2.load_state_dict(back)
+    torch.testing.assert_close(ref2([b0, b1], x), ref([b0, b1], x))
