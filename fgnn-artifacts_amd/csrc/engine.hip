@@ -453,7 +453,7 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
         s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
     {
       // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
-      // FGNN_RANK_BITMAP=0 (profiling build, A/B only): order the seeds with rocPRIM's radix sort like the stateless
+      // FGNN_RANK_BITMAP=0 (profiling build, A/B only): order the seeds with scan.hip's sort like the stateless
       // C entry points
       static const bool use_rank = fgnn::tune_int("FGNN_RANK_BITMAP", 1) != 0;
       const fgnn::RankWs rank{use_rank ? sl.rank_bitmap : nullptr, &sl.scan_sample};

@@ -556,6 +556,14 @@ int launch_scan_block_sums(uint32_t *sums, size_t n, size_t *total64, uint32_t *
 
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// Stable sort of n (key, value) uint32 pairs by key, ascending (defined in scan.hip): one launch up to 8 k pairs, five
+// up to 65 k, twelve beyond -- grids of independent workgroups.  keys_alt/vals_alt: n words each; ws:
+// sort_pairs_ws_words(n) words.  The sorted pairs are in *sorted_keys / *sorted_vals afterwards -- one of the two buffer
+// pairs, the other is clobbered.
+size_t sort_pairs_ws_words(size_t n);
+int launch_sort_pairs_u32(uint32_t *keys, uint32_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, size_t n,
+                          uint32_t *ws, hipStream_t stream, uint32_t **sorted_keys, uint32_t **sorted_vals);
+
 // compute units of the current device (256 on MI355X)
 inline int device_cu_count() {
   static const int n = [] {
@@ -755,7 +763,7 @@ struct BatchStart {
 // the three with-replacement samplers (khop1 / weighted_khop / weighted_khop_prefix by sample_type; table_f = prob or
 // prefix table) for callers that know the number of graph nodes, guarantee unique seeds and own a RankWs: the seed
 // order then comes from a bitmap over the id space instead of a radix sort (sample_weighted.hip) -- no library call.
-// rank == null: as the C entry points (rocPRIM sorts the seeds).  Scratch: fgnn_weighted_scratch_bytes.
+// rank == null: as the C entry points (scan.hip's sort orders the seeds).  Scratch: fgnn_weighted_scratch_bytes.
 struct RankWs {
   uint32_t *bitmap;   // rank_ws_bytes(num_node) bytes, ALL ZERO between calls (the call restores that): bitmap | pre | sums
   ScanWsHost *scan;   // look-back descriptors for the two single-pass launches

@@ -7,17 +7,15 @@
 // fgnn_oracle_sample_weighted_khop_prefix.
 //
 // MI355X design: seeds are unique, so the stable sort of the pairs by src is just the seeds' groups
-// reordered by seed id -- only the num_input seeds are sorted (rocPRIM radix sort, fanout x fewer
+// reordered by seed id -- only the num_input seeds are sorted (the radix sort of scan.hip, fanout x fewer
 // keys than the reference sorts), the draws are one-lane-per-draw (all 64 lanes busy, independent
 // binary searches in flight), adjacent-duplicate removal is a per-seed count known before the
 // compaction, and the offsets come from a scan in sorted-seed order.
 // Where the number of graph nodes is known (batch driver) the seeds are not sorted at all: they are unique node ids, so
 // a seed's position in id order is the number of seed bits below its own in a bitmap over the id space -- set bits,
-// popcount prefix per word, one lookup per seed -- ~5 small launches instead of rocPRIM's four radix passes
+// popcount prefix per word, one lookup per seed -- ~5 small launches instead of four radix passes
 // (183 -> ~80 us for 1.3 M seeds on the twitter shape), and independent of how the ids are distributed.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "fgnn_device.h"
 
@@ -444,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void weighted_emit_sp_kernel(const uint32_t
 using namespace fgnn;
 
 // scratch layout for cap seeds, fanout F (all uint32 unless noted):
-//   tmp_dst[cap*F] | keys[cap] | vals[cap] | keys_out[cap] | order[cap] | cnt[cap] | sums[nb+1] | rocprim temp
+//   tmp_dst[cap*F] | keys[cap] | vals[cap] | keys_out[cap] | order[cap] | cnt[cap] | sums[nb+1] | sort workspace
 // bitmap words of the seed ranking, padded to whole 16-byte groups (rank_prefix_kernel moves four words per lane)
 static size_t rank_words(size_t num_node) { return (fgnn::div_up(num_node, (size_t)32) + 3) & ~(size_t)3; }
 
@@ -454,11 +452,9 @@ size_t fgnn::rank_ws_bytes(size_t num_node) {
 }
 
 extern "C" size_t fgnn_weighted_scratch_bytes(size_t num_input_cap, size_t fanout) {
-  size_t temp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, temp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                  (uint32_t *)nullptr, num_input_cap ? num_input_cap : 1, 0, 32, (hipStream_t)0);
   const size_t nb = div_up(num_input_cap, kBlock);
-  return (num_input_cap * fanout + 5 * num_input_cap + nb + 8) * sizeof(uint32_t) + temp + 256;
+  return (num_input_cap * fanout + 5 * num_input_cap + nb + 8 + fgnn::sort_pairs_ws_words(num_input_cap)) *
+             sizeof(uint32_t) + 256;
 }
 
 namespace fgnn {
@@ -493,8 +489,7 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
   uint32_t *order = keys_out + cap;
   uint32_t *cnt = order + cap;
   uint32_t *sums = cnt + cap;
-  void *temp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(sums + nb + 8) + 255) & ~uintptr_t(255));
-  size_t temp_bytes = ws_bytes - (static_cast<char *>(temp) - static_cast<char *>(ws));
+  uint32_t *sort_ws = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(sums + nb + 8) + 255) & ~uintptr_t(255));
 
   uint32_t *bitmap = rank ? rank->bitmap : nullptr;
   if (F <= (uint32_t)kWave) {
@@ -558,7 +553,8 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
     }
     hipLaunchKernelGGL(rank_clear_kernel, dim3(nb), dim3(kBlock), 0, st, keys, cap, bitmap);
   } else {
-    FGNN_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, vals, order, cap, 0, 32, st));
+    // seeds of unknown range: sorted with their positions; `order` = the positions in seed-id order afterwards
+    if (launch_sort_pairs_u32(keys, keys_out, vals, order, cap, sort_ws, st, nullptr, &order) != FGNN_OK) return FGNN_EHIP;
   }
   hipLaunchKernelGGL(weighted_sorted_sums_kernel, dim3(nb), dim3(kBlock), 0, st, order, cnt, cap, sums);
   if (launch_scan_block_sums(sums, nb, d_num_out, nullptr, nullptr, nullptr, st) != FGNN_OK) return FGNN_EHIP;

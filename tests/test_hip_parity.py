@@ -387,6 +387,29 @@ def test_weighted_prefix_matches_oracle(hip, oracle, fanout):
             assert (np.diff(o_src.astype(np.int64)) >= 0).all()  # ordered by seed id (stable radix sort by src)
 
 
+def test_weighted_prefix_orders_many_seeds_of_unknown_range(hip, oracle):
+    """The stateless entry point cannot know the id range, so it sorts the seeds (scan.hip, where the reference calls
+    cub::DeviceRadixSort, cuda_sampling_weighted_khop_prefix.cu:200-215): by counting up to 8192 seeds, with one launch
+    per radix pass up to 32 sort tiles (65536 seeds), with three per pass beyond.  Seed counts either side of each
+    switch and of a tile, ids that use three of the four digits; empty rows share one key."""
+    from fgnn_hip import synth
+    num_node = 1 << 21
+    indptr, indices = synth.powerlaw_csr(num_node, 6000000, seed=77)
+    prefix = synth.prob_prefix_table(indptr, indices)
+    d = [dev(indptr), dev(indices), dev(prefix)]
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    for call, n in enumerate([2048, 2049, 8192, 8193, 22500, 65536, 65537, 300001]):
+        inp = _seeds(n, num_node, seed=78 + call)
+        assert (np.diff(indptr.astype(np.int64))[inp] == 0).any() and inp.max() >= 1 << 16
+        o_src, o_dst = oracle.sample_weighted_khop_prefix(indptr, indices, prefix, inp, 5, rng, 21 + call, 1)
+        src, dst, d_ne = hip.sample_weighted_khop_prefix(d[0], d[1], d[2], dev(inp), 5, SEED, 21 + call, 1)
+        ne = int(d_ne.cpu()[0])
+        assert ne == len(o_dst), n
+        np.testing.assert_array_equal(host_u32(src, ne), o_src)
+        np.testing.assert_array_equal(host_u32(dst, ne), o_dst)
+        assert (np.diff(o_src.astype(np.int64)) >= 0).all()
+
+
 @pytest.mark.parametrize("walk_len,num_walks,K,restart", [(3, 4, 5, 0.5), (3, 25, 5, 0.5), (2, 70, 3, 0.0),
                                                           (4, 3, 20, 0.9), (3, 1, 2, 0.3), (5, 32, 8, 0.2),
                                                           (2, 33, 4, 0.5), (600, 2, 6, 0.01)])
