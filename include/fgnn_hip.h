@@ -289,6 +289,7 @@ int fgnn_relu_dropout(const float *x, float *y, size_t n, float p, uint64_t seed
 int fgnn_relu_dropout_backward(const float *y, const float *gy, float *gx, size_t n, float p, void *stream);
 /* CrossEntropyLoss(reduction='mean') and its gradient in one launch: *loss = mean_i (logsumexp(x_i) - x_i[label_i]),
  * dlogits[i, c] = (softmax(x_i)[c] - [c == label_i]) / n.  The mean is summed in a fixed order (bit-reproducible).
+ * A label outside [0, num_class) adds nothing to the loss and marks no class (torch raises a device assert there).
  * ws: fgnn_softmax_xent_scratch_bytes(n) bytes, its first 16 zeroed ONCE by the caller (the launches keep them zero). */
 size_t fgnn_softmax_xent_scratch_bytes(size_t n);
 int fgnn_softmax_xent(const float *logits, size_t ld, const long long *labels, size_t n, size_t num_class, float *loss,
