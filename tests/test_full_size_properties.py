@@ -360,3 +360,26 @@ def test_products_shape_bit_exact_and_invariants(oracle, kind, fanout):
         np.testing.assert_array_equal(bt.label().cpu().numpy(), h_label[h_seeds])
     np.testing.assert_array_equal(d_indices.cpu().numpy().view(np.uint32), h_indices)  # khop2's swaps, all three batches
     assert (h_indices != indices.cpu().numpy().view(np.uint32)).any() == (kind == "khop2")  # khop0 never writes the CSR
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("help_after", [-1, 0])
+def test_products_shape_overlapped_batches_bit_exact(help_after):
+    """The loop bench.py times -- fgnn_sampler_run_range: whole batches in flight together over three streams, sample ->
+    cache split -> feature / label gather -- on the products-shaped graph, three layers: 72 consecutive batches, every
+    block, node list, cache index array, gathered row and label and khop2's mutated CSR identical to the oracle's replay
+    of the same sequence (tools/soak_overlapped.py; thousands of batches there: profiles/r05_j_soak_overlapped.txt).
+    help_after 0: the single-pass kernels' waits take the helping path."""
+    import argparse
+    import importlib.util
+    from fgnn_hip import lib
+    spec = importlib.util.spec_from_file_location("soak_overlapped", os.path.join(ROOT, "tools", "soak_overlapped.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        mod.run(argparse.Namespace(kind="khop2", fanout="10,5,5", rounds=3, per_round=24, streams=3, batch=8000,
+                                   seed=0x5A4D47, help_after=help_after))
+    finally:
+        if help_after >= 0:  # back to what the rest of the test process runs with (tests/conftest.py)
+            env = os.environ.get("FGNN_SCAN_HELP_AFTER")
+            lib.load().fgnn_debug_set_scan_help_after(int(env) if env is not None else -1)  # -1: no override
