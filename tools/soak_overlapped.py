@@ -6,7 +6,7 @@ compared bit-exactly with the oracle's replay of the same batch sequence (khop2:
 batch and round to round on both sides, and the mutated CSR is compared at the end).  The parity tests compare batches
 run one at a time; this is the same comparison with the batches in flight together, at a realistic size.
 
-usage: soak_overlapped.py [--kind khop2|khop0|khop1] [--fanout 10,5,5] [--rounds 12] [--per-round 48] [--streams 3]
+usage: soak_overlapped.py [--kind khop2|khop0|khop1|weighted_khop_prefix|weighted_khop|random_walk] [--fanout 10,5,5] [--rounds 12] [--per-round 48] [--streams 3]
        [--help-after 0]
 GPU box; the oracle (CPU) is most of the run time (~0.1-0.2 s per batch)."""
 import argparse
@@ -24,7 +24,8 @@ import torch
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kind", default="khop2", choices=["khop2", "khop0", "khop1"])
+    ap.add_argument("--kind", default="khop2", choices=["khop2", "khop0", "khop1", "weighted_khop_prefix", "weighted_khop",
+                                                         "random_walk"])
     ap.add_argument("--fanout", default="10,5,5")
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--per-round", type=int, default=48)
@@ -62,10 +63,26 @@ def run(args):
     h_table = table.cpu().numpy().view(np.uint32)
     h_train = train.cpu().numpy().view(np.uint32)
     h_label = label.cpu().numpy()
-    st, ost = dict(khop2=(lib.KHOP2, oracle.KHOP2), khop0=(lib.KHOP0, oracle.KHOP0),
-                   khop1=(lib.KHOP1, oracle.KHOP1))[args.kind]
+    st, ost = dict(khop2=(lib.KHOP2, oracle.KHOP2), khop0=(lib.KHOP0, oracle.KHOP0), khop1=(lib.KHOP1, oracle.KHOP1),
+                   weighted_khop_prefix=(lib.WEIGHTED_KHOP_PREFIX, oracle.WEIGHTED_KHOP_PREFIX),
+                   weighted_khop=(lib.WEIGHTED_KHOP, oracle.WEIGHTED_KHOP),
+                   random_walk=(lib.RANDOM_WALK, oracle.RANDOM_WALK))[args.kind]
     d_indices = indices.clone()
-    sampler = lib.Sampler(indptr, d_indices, fanout, B, sample_type=st, seed=args.seed)
+    kw, okw = {}, {}
+    to_dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)  # noqa: E731
+    if args.kind == "weighted_khop_prefix":
+        from fgnn_hip import synth
+        prefix = synth.prob_prefix_table(h_indptr, h_indices)
+        kw, okw = dict(prob_prefix=to_dev(prefix)), dict(prob_prefix=prefix)
+    elif args.kind == "weighted_khop":
+        from fgnn_hip import synth
+        prob, alias = synth.alias_tables(h_indptr, h_indices)
+        kw, okw = dict(prob_table=to_dev(prob), alias_table=to_dev(alias)), dict(prob_prefix=prob, alias_table=alias)
+    elif args.kind == "random_walk":  # PinSAGE's sampler as BASELINE config 5 runs it: 25 walks of 3 steps, top-K = fanout
+        assert len(set(fanout)) == 1
+        kw = dict(walk_len=3, num_walks=25, restart_prob=0.5)
+        okw = dict(walk_len=3, num_walks=25, num_neighbor=fanout[0], restart_prob=0.5)
+    sampler = lib.Sampler(indptr, d_indices, fanout, B, sample_type=st, seed=args.seed, **kw)
     batches = [sampler.new_batch(D, lib.F32, lib.I64) for _ in range(args.per_round)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
     rng = oracle.make_rng(oracle.RNG_PHILOX, args.seed)
@@ -85,7 +102,7 @@ def run(args):
             step = seq % steps
             seeds = h_train[step * B:min((step + 1) * B, len(h_train))]
             bt, m = batches[seq % len(batches)], metas[i]
-            want = oracle.do_sample(h_indptr, h_indices, seeds, fanout, ost, rng, step, oht)
+            want = oracle.do_sample(h_indptr, h_indices, seeds, fanout, ost, rng, step, oht, **okw)
             what = "%s round %d batch %d (seq %d, step %d)" % (args.kind, r, i, seq, step)
             assert m.overflow == 0 and m.num_output == len(seeds) and m.key == step, what
             nodes = bt.input_nodes().cpu().numpy().view(np.uint32)
@@ -96,6 +113,8 @@ def run(args):
                 assert (nsrc, ndst, int(m.num_edge[l])) == (gr["num_src"], gr["num_dst"], gr["num_edge"]), (what, l)
                 np.testing.assert_array_equal(row.cpu().numpy().view(np.uint32), gr["row"], err_msg="%s layer %d" % (what, l))
                 np.testing.assert_array_equal(col.cpu().numpy().view(np.uint32), gr["col"], err_msg="%s layer %d" % (what, l))
+                if args.kind == "random_walk":
+                    np.testing.assert_array_equal(bt.graph_data(l).cpu().numpy().view(np.uint32), gr["data"], err_msg=what)
                 edges += gr["num_edge"]
             for got, wv in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(h_table, nodes)):
                 np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), wv, err_msg=what)
