@@ -16,6 +16,9 @@ Arithmetic on the real rows is the eager step's (same kernels, same order; the w
 all-but-irrelevant rows: they multiply rows of the upstream gradient that are exactly zero).  Batches that do not fit
 the pattern (a short last batch of an epoch, sizes beyond a buffer) run eagerly.
 """
+import os
+import tempfile
+
 import torch as th
 
 
@@ -29,15 +32,41 @@ def _bucket(n, floor):
 
 class GraphedSageStep:
     def __init__(self, model, opt, loss_fcn, batch_size, edge_bucket=32768, node_bucket=32768, inner_bucket=4096,
-                 max_graphs=16):
+                 max_graphs=16, tune_gemms=False):
         """opt must be capturable (torch.optim.Adam(..., fused=True, capturable=True)).  *_bucket: the finest rounding
         of edge counts / input rows / inner-layer rows; max_graphs: batches of further shapes run eagerly (a capture
-        costs ~0.1 s: a workload whose shapes never repeat must not capture per batch)."""
+        costs ~0.1 s: a workload whose shapes never repeat must not capture per batch).
+        tune_gemms: before a shape is captured, its forward + backward run once with PyTorch's TunableOp choosing among
+        the rocBLAS / hipBLASLt solutions for every GEMM shape of the step (static shapes: each is tuned once, ~1 s
+        apiece), and the capture records the chosen kernels -- the library's default picks run the step's tall-skinny
+        fp32 GEMMs at about half the fp32 matrix peak (papers100M-shaped step: 164 -> 120 us of GEMMs, replay 0.363 ->
+        0.320 ms; profiles/r05_l_train_gemm_tuning.txt).  Same fp32 arithmetic, another summation order inside the
+        GEMMs (like any change of library version)."""
         self.model, self.opt, self.loss_fcn, self.batch_size = model, opt, loss_fcn, batch_size
         self.gE, self.gS, self.gI, self.max_graphs = edge_bucket, node_bucket, inner_bucket, max_graphs
         self.graphs = {}
         self.eager_steps = self.replays = 0
         self._primed = False
+        self.tune_gemms = bool(tune_gemms) and hasattr(th.cuda, "tunable")
+        self.tuned_shapes = 0
+
+    def _tune(self, blocks, x, y):
+        """one forward + backward of the padded shapes with GEMM tuning on; no optimizer step, the gradients are dropped
+        -- nothing of the training state moves (the dropout masks are keyed by the optimizer's step count)"""
+        tn = th.cuda.tunable
+        tn.enable(True)
+        if not os.environ.get("PYTORCH_TUNABLEOP_FILENAME") and not self.tuned_shapes:
+            # (TunableOp logs its picks to a file as it goes: not into the working directory)
+            tn.set_filename(os.path.join(tempfile.gettempdir(), "fgnn_tunableop_%d.csv" % os.getpid()))
+        tn.tuning_enable(True)
+        try:
+            out = self.model(blocks, x)
+            self._loss_backward(out, y)
+            self.opt.zero_grad(set_to_none=True)
+            th.cuda.synchronize()
+        finally:
+            tn.tuning_enable(False)  # tuned picks stay in use (enable stays on): the capture below records them
+        self.tuned_shapes += 1
 
     def _loss_backward(self, out, y):
         """loss of the first batch_size rows of `out` + backward.  CrossEntropyLoss (mean, unweighted) on the GPU goes
@@ -116,6 +145,8 @@ class GraphedSageStep:
                     xent_grad_buffer(x_full.device, db[L - 1] + 1, self._ncls)
                 except ImportError:
                     pass
+            if self.tune_gemms and x_full.is_cuda:
+                self._tune(blocks, x_full[:sb0], y)
             g = th.cuda.CUDAGraph()
             with th.cuda.graph(g):
                 out = self.model(blocks, x_full[:sb0])

@@ -1033,13 +1033,15 @@ def test_fused_sage_layer_matches_the_op_by_op_layer(hip, din, dout, first_layer
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused_adam", [False, True])
-def test_graphed_training_step_equals_the_eager_step(hip, fused_adam):
+@pytest.mark.parametrize("fused_adam,tune_gemms", [(False, False), (True, False), (True, True)])
+def test_graphed_training_step_equals_the_eager_step(hip, fused_adam, tune_gemms):
     """examples/graphed_step.py: the GraphSAGE training step replayed as a captured HIP graph on the batch buffers'
     full-capacity tensors, sizes rounded up to buckets, padded edges pointed at a discarded row -- against the same
     steps taken op by op (the reference's loop, train_graphsage.py:300-330) from the same initial weights on the same
     batches, dropout 0: every parameter after three steps within rtol 1e-4 (fp32; the padded rows add exact zeros to
-    the weight gradients but change how the GEMMs group their sums)."""
+    the weight gradients but change how the GEMMs group their sums).  tune_gemms: every shape's forward + backward runs
+    once more before its capture, with PyTorch's TunableOp choosing the GEMM kernels -- nothing of the training state
+    may move in that pass, and the chosen kernels give the same step within the same tolerance."""
     import copy
     import os
     import sys
@@ -1066,7 +1068,8 @@ def test_graphed_training_step_equals_the_eager_step(hip, fused_adam):
         from fgnn_hip.nn import Adam
         opt_g = Adam(model_g.parameters(), lr=0.01)
         model_g.dropout_step = opt_g.step_count  # (dropout 0.0 here: the fused ReLU launch without a mask)
-    stepper = GraphedSageStep(model_g, opt_g, loss_fcn, batch, edge_bucket=2048, node_bucket=1024, inner_bucket=256)
+    stepper = GraphedSageStep(model_g, opt_g, loss_fcn, batch, edge_bucket=2048, node_bucket=1024, inner_bucket=256,
+                              tune_gemms=tune_gemms)
     losses = []
     for b in range(4):
         bt = bufs[b % 2]
@@ -1080,7 +1083,10 @@ def test_graphed_training_step_equals_the_eager_step(hip, fused_adam):
         loss_g = stepper.step(bt, CooBlock)
         losses.append((float(loss_e), float(loss_g)))
         assert int(m.num_output) == batch
+    if tune_gemms:
+        torch.cuda.tunable.enable(False)  # (process-wide switch: the rest of the test process runs the defaults)
     assert stepper.eager_steps == 1 and stepper.replays == 3 and 1 <= len(stepper.graphs) <= 3
+    assert stepper.tuned_shapes == (len(stepper.graphs) if tune_gemms else 0)
     for le, lg in losses:
         assert abs(le - lg) <= 1e-4 * max(1.0, abs(le)), losses
     for pe, pg in zip(model_e.parameters(), model_g.parameters()):
