@@ -1043,7 +1043,8 @@ def run_train_leg(args, w, dev, sampler, batches, streams, seeds_of, table, feat
     model.train()
     # the step replayed as a captured HIP graph (examples/graphed_step.py); --eager-train: op by op like the reference's
     # loop.  Eager, the step is bound by the ~40 ops Python launches (0.83 ms of host time for ~0.5 ms of kernels); a
-    # replayed graph costs the host 0.12 ms and the GPU 0.58 ms.  (Every graph node costs the GPU 15-20 us on this
+    # replayed graph costs the host 0.12 ms and the GPU 0.58 ms (round 4; 28 nodes and ~0.33 ms since round 5's one-launch
+    # pieces and GEMM choice).  (Every graph node costs the GPU 15-20 us on this
     # runtime: with the 45 nodes of the op-by-op SAGEConv layers the replay took 0.93 ms and lost to eager; the fused
     # layer of examples/models.py is what made the graph worth it -- profiles/r04_c_train_graph_vs_eager.txt.)
     stepper = (GraphedSageStep(model, opt, loss_fcn, w["batch_size"], tune_gemms=not args.no_gemm_tuning)
