@@ -589,11 +589,11 @@ def run_single(args):
     sample_stage = None
     if not args.timed_only:
         mode[0] = "sample"
-        # two batch streams like an arch5 sampler process (eng_engine.cc: SampleInit): without the gather the stage is
-        # bound by khop2's order chain, and a third batch in flight only slows the chain's kernels
-        # (profiles/r03_sampler_streams_sweep.txt)
-        if NT == 1 and SPT > 2:
-            stage_streams[0] = 2
+        # two batch streams: without the gather the stage is bound by khop2's order chain and a third batch in flight only
+        # slows the chain's kernels (0.071 ms per batch against 0.076 with three; an arch5 sampler process, which also
+        # packs and publishes every batch, does better with three: profiles/r05_m_sampler_streams_sweep.txt)
+        if NT == 1 and 0 < args.stage_streams < SPT:
+            stage_streams[0] = args.stage_streams
         n_stage = min(args.steps, 64)
         run_region(next_seq, next_seq + 8, False)
         next_seq += 8
@@ -612,7 +612,8 @@ def run_single(args):
                         "hbm_frac": stage_bytes / (t_stage / n_stage) / 1e9 / HBM_PEAK_GBS,
                         "streams": stage_streams[0],
                         "note": "sample + dedup + remap + cache-index split only (no feature gather), batches over "
-                                "the two streams an arch5 sampler process uses"}
+                                "%d streams (the stage's optimum is two; an arch5 sampler process, which also packs "
+                                "and publishes, uses three)" % stage_streams[0]}
         mode[0] = "full"
         stage_streams[0] = len(streams)
     metas.clear()
@@ -1933,6 +1934,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams-per-thread", type=int, default=3,
                     help="N=1: HIP streams each host thread rotates over (batches in flight = threads x this); "
                          "measured on MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
+    ap.add_argument("--stage-streams", type=int, default=2,
+                    help="N=1: batch streams of the sample_stage measurement (0: all of --streams-per-thread)")
     ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the region with a training step per batch")
     ap.add_argument("--train-steps", type=int, default=40, help="N>=2: batches of the training region (<= --steps)")

@@ -429,11 +429,11 @@ void Engine::SampleInit(int worker_id, Context ctx) {
   // streams.  The chains of consecutive batches overlap on the GPU (fgnn_sampler_sample orders what has to stay ordered
   // with events; one batch alone cannot fill the chip); a batch buffer is reused in stream order, so the host may run
   // further ahead instead of waiting for a publication every call (with 3 buffers the sampler measured 142 us per
-  // papers100M batch, 60 of them waiting here, the GPU idle 21 % of the time).  Two streams, not three: the sampler
-  // side is bound by khop2's order chain, and a third batch in flight only slows the chain's kernels down
-  // (profiles/r03_sampler_streams_sweep.txt: 81.2 us per batch with 2 streams / 6 buffers, 85.4 with 3 / 6, 88.6 with
-  // 4 / 8, 121.7 with 1 / 2)
-  CreateSamplerSlots(2, 6);
+  // papers100M batch, 60 of them waiting here, the GPU idle 21 % of the time).  Three streams, nine buffers: with round
+  // 3's kernels a third batch in flight only slowed khop2's order chain down (profiles/r03_sampler_streams_sweep.txt:
+  // 81.2 us per batch with 2 / 6, 85.4 with 3 / 6); since round 4's partitioned dedup the chain leaves room -- 151
+  // batches in 14.7-14.9 ms with 3 / 9 against 15.6-15.8 with 2 / 6, 15.7 with 4 / 12 (profiles/r05_m_sampler_streams_sweep.txt)
+  CreateSamplerSlots(3, 9);
   if (RC().UseGPUCache()) {
     Timer tp;
     if (RC().cache_policy == kCacheByPreSample || RC().cache_policy == kCacheByPreSampleStatic) {
