@@ -448,7 +448,7 @@ def run_single(args):
                           restart_prob=w.get("restart_prob", 0.5), prob_table=prob_t, alias_table=alias_t)
     NT = 1 if args.no_overlap else args.host_threads
     SPT = 1 if args.no_overlap else max(1, args.streams_per_thread)
-    NBUF = 2 * NT * SPT
+    NBUF = max(1, args.buffers_per_stream) * NT * SPT
     batches = [sampler.new_batch(w["feat_dim"], lib.F32, lib.I64) for _ in range(NBUF)]
     # HIP events around the feature gather, on the stream it is launched on -- on every THIRD batch (buffers 0 and 4 of
     # six: streams 0 and 1): the two event records per batch cost the step 3 % when every batch carries them
@@ -1934,6 +1934,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams-per-thread", type=int, default=3,
                     help="N=1: HIP streams each host thread rotates over (batches in flight = threads x this); "
                          "measured on MI355X: 1x3 0.160 ms/step, 1x2 = 2x1 0.173, 3x1 0.167-0.177, 1x4 0.183")
+    ap.add_argument("--buffers-per-stream", type=int, default=2,
+                    help="N=1: batch buffers per stream (the host enqueues that many batches ahead on each stream)")
     ap.add_argument("--stage-streams", type=int, default=2,
                     help="N=1: batch streams of the sample_stage measurement (0: all of --streams-per-thread)")
     ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
