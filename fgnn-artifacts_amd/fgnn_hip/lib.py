@@ -572,32 +572,18 @@ class Sampler:
         """fgnn_sampler_run_range: batches first_seq .. first_seq+count-1 enqueued and collected by ONE native call (the
         reference's C++ loop thread, cuda_loops_arch1.cc:38-84).  Returns (metas, times, host_enqueue_seconds); times[i]
         = (ms, ms) HIP-event times of batch i, -1 where not timed.  Raises on a flagged batch."""
+        call = self.range_call(first_seq, count, train, batch_size, batches, streams, cache_table, feat, label,
+                               cache_rows, full_feat, cached)
+        call.run()
+        return call.results()
+
+    def range_call(self, first_seq, count, train, batch_size, batches, streams, cache_table=None, feat=None,
+                   label=None, cache_rows=None, full_feat=None, cached=False):
+        """run_range in three steps for callers that time the native call alone: the argument marshalling here,
+        .run() = the one C call (returns when every batch of the range has been collected), .results() afterwards."""
         _need_gpu(train)
-        L = load()
-        plan = RunPlan()
-        plan.d_train, plan.num_train, plan.batch_size = train.data_ptr(), train.numel(), batch_size
-        arr_b = (C.c_void_p * len(batches))(*[b.h for b in batches])
-        arr_s = (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams])
-        plan.batches, plan.num_batches = C.cast(arr_b, C.c_void_p), len(batches)
-        plan.streams, plan.num_streams = C.cast(arr_s, C.c_void_p), len(streams)
-        plan.cache_table = cache_table.data_ptr() if cache_table is not None else None
-        plan.feat = feat.data_ptr() if feat is not None else None
-        plan.label = label.data_ptr() if label is not None else None
-        plan.cached = 1 if cached else 0
-        plan.cache_rows = cache_rows.data_ptr() if cache_rows is not None else None
-        plan.full_feat = full_feat.data_ptr() if full_feat is not None else None
-        metas = (BatchMeta * max(count, 1))()
-        times = (C.c_float * (2 * max(count, 1)))()
-        busy = C.c_double(0.0)
-        _check(L.fgnn_sampler_run_range(self.h, C.byref(plan), C.c_uint64(first_seq), C.c_size_t(count), metas, times,
-                                        C.byref(busy)), "fgnn_sampler_run_range")
-        out = [metas[i] for i in range(count)]
-        for m in out:
-            if m.overflow:
-                raise FgnnError(f"batch {m.key} is invalid (overflow flag {m.overflow})")
-        for i in range(max(0, count - len(batches)), count):  # the buffers hold the last batches: views stay usable
-            batches[(first_seq + i) % len(batches)].meta = out[i]
-        return out, [(times[2 * i], times[2 * i + 1]) for i in range(count)], busy.value
+        return _RangeCall(self, first_seq, count, train, batch_size, batches, streams, cache_table, feat, label,
+                          cache_rows, full_feat, cached)
 
     def run_batch_cached(self, seq, seeds, batch_key, batch, cache_table, cache_rows, full_feat, label=None,
                          stream=None):
@@ -609,6 +595,46 @@ class Sampler:
                                                     C.c_uint64(batch_key), batch.h, _ptr(cache_table),
                                                     _ptr(cache_rows), _ptr(full_feat), _ptr(label), st),
                "fgnn_sampler_run_batch_cached")
+
+
+class _RangeCall:
+    def __init__(self, sampler, first_seq, count, train, batch_size, batches, streams, cache_table, feat, label,
+                 cache_rows, full_feat, cached):
+        self.L = load()
+        self.sampler, self.first_seq, self.count, self.batches = sampler, first_seq, count, batches
+        plan = self.plan = RunPlan()
+        plan.d_train, plan.num_train, plan.batch_size = train.data_ptr(), train.numel(), batch_size
+        self._keep = (train, cache_table, feat, label, cache_rows, full_feat, list(streams),
+                      (C.c_void_p * len(batches))(*[b.h for b in batches]),
+                      (C.c_void_p * len(streams))(*[st.cuda_stream for st in streams]))
+        plan.batches, plan.num_batches = C.cast(self._keep[-2], C.c_void_p), len(batches)
+        plan.streams, plan.num_streams = C.cast(self._keep[-1], C.c_void_p), len(streams)
+        plan.cache_table = cache_table.data_ptr() if cache_table is not None else None
+        plan.feat = feat.data_ptr() if feat is not None else None
+        plan.label = label.data_ptr() if label is not None else None
+        plan.cached = 1 if cached else 0
+        plan.cache_rows = cache_rows.data_ptr() if cache_rows is not None else None
+        plan.full_feat = full_feat.data_ptr() if full_feat is not None else None
+        self.metas = (BatchMeta * max(count, 1))()
+        self.times = (C.c_float * (2 * max(count, 1)))()
+        self.busy = C.c_double(0.0)
+        self.rc = None
+        self._args = (sampler.h, C.byref(plan), C.c_uint64(first_seq), C.c_size_t(count), self.metas, self.times,
+                      C.byref(self.busy))
+
+    def run(self):
+        self.rc = self.L.fgnn_sampler_run_range(*self._args)
+
+    def results(self):
+        _check(self.rc, "fgnn_sampler_run_range")
+        count, batches = self.count, self.batches
+        out = [self.metas[i] for i in range(count)]
+        for m in out:
+            if m.overflow:
+                raise FgnnError(f"batch {m.key} is invalid (overflow flag {m.overflow})")
+        for i in range(max(0, count - len(batches)), count):  # the buffers hold the last batches: views stay usable
+            batches[(self.first_seq + i) % len(batches)].meta = out[i]
+        return out, [(self.times[2 * i], self.times[2 * i + 1]) for i in range(count)], self.busy.value
 
 
 class Batch:
