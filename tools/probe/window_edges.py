@@ -24,7 +24,7 @@ feat = bench.gen_features_on_gpu(w["num_node"], w["feat_dim"], dev)
 g = torch.Generator(device=dev)
 g.manual_seed(7)
 label = torch.randint(0, w["num_class"], (w["num_node"],), generator=g, device=dev, dtype=torch.int64)
-train = torch.randperm(w["num_node"], generator=g, device=dev)[:w["num_train"]].to(torch.int32)
+train = bench.gen_train_set(None, w, dev)  # bench.py's train set (uniform ids, shuffled once)
 deg = (indptr[1:].to(torch.int64) - indptr[:-1].to(torch.int64)) & 0xFFFFFFFF
 table = torch.full((w["num_node"],), -1, dtype=torch.int32, device=dev)
 top = torch.argsort(deg, descending=True)[:int(w["num_node"] * 0.2)]
