@@ -65,7 +65,7 @@ class GraphedSageStep:
             self.opt.zero_grad(set_to_none=True)
             th.cuda.synchronize()
         finally:
-            tn.tuning_enable(False)  # tuned picks stay in use (enable stays on): the capture below records them
+            tn.tuning_enable(False)  # the picks stay in use while the switch is on: the capture that follows records them
         self.tuned_shapes += 1
 
     def _loss_backward(self, out, y):
@@ -145,13 +145,17 @@ class GraphedSageStep:
                     xent_grad_buffer(x_full.device, db[L - 1] + 1, self._ncls)
                 except ImportError:
                     pass
-            if self.tune_gemms and x_full.is_cuda:
+            tuned = self.tune_gemms and x_full.is_cuda
+            was_on = tuned and th.cuda.tunable.is_enabled()
+            if tuned:
                 self._tune(blocks, x_full[:sb0], y)
             g = th.cuda.CUDAGraph()
             with th.cuda.graph(g):
                 out = self.model(blocks, x_full[:sb0])
                 loss = self._loss_backward(out, y)
                 self.opt.step()
+            if tuned and not was_on:
+                th.cuda.tunable.enable(False)  # the graph holds the chosen kernels; eager code keeps the defaults
             # (the entry keeps the batch object alive: its graphs replay on its buffers' addresses)
             entry = self.graphs[key] = (g, loss.detach(), bt)
             del out, loss, blocks

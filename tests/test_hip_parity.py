@@ -1083,8 +1083,7 @@ def test_graphed_training_step_equals_the_eager_step(hip, fused_adam, tune_gemms
         loss_g = stepper.step(bt, CooBlock)
         losses.append((float(loss_e), float(loss_g)))
         assert int(m.num_output) == batch
-    if tune_gemms:
-        torch.cuda.tunable.enable(False)  # (process-wide switch: the rest of the test process runs the defaults)
+    assert not torch.cuda.tunable.is_enabled()  # the stepper leaves the process-wide switch as it found it
     assert stepper.eager_steps == 1 and stepper.replays == 3 and 1 <= len(stepper.graphs) <= 3
     assert stepper.tuned_shapes == (len(stepper.graphs) if tune_gemms else 0)
     for le, lg in losses:
