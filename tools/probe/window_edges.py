@@ -59,5 +59,7 @@ for K in [int(a) for a in sys.argv[1:]] or [20, 151]:
               "launch and synchronise latencies) | host enqueue %.1f us/batch"
               % (K, rep, el * 1e6, el / K * 1e3, steady, steady * K, starts[-1], el * 1e6 - starts[-1],
                  busy / K * 1e6))
+        if rep == 3:
+            print("   per batch: input nodes %.0f, cache-split misses %.0f, hits %.0f" % tuple(sum(int(getattr(m, f)) for m in metas) / len(metas) for f in ("num_input", "num_miss", "num_cache")))
         if rep == 3 and K <= 24:
             print("   batch starts (us):", [round(x) for x in starts])
