@@ -148,7 +148,15 @@ class GraphedSageStep:
             tuned = self.tune_gemms and x_full.is_cuda
             was_on = tuned and th.cuda.tunable.is_enabled()
             if tuned:
-                self._tune(blocks, x_full[:sb0], y)
+                try:
+                    self._tune(blocks, x_full[:sb0], y)
+                except Exception as e:  # the step works with the libraries' default picks: never lose it to the tuner
+                    import warnings
+                    warnings.warn("GEMM tuning switched off (%s: %s)" % (type(e).__name__, e))
+                    self.tune_gemms = tuned = False
+                    th.cuda.tunable.tuning_enable(False)
+                    th.cuda.tunable.enable(was_on)
+                    self.opt.zero_grad(set_to_none=True)
             g = th.cuda.CUDAGraph()
             with th.cuda.graph(g):
                 out = self.model(blocks, x_full[:sb0])
