@@ -37,6 +37,25 @@ extern "C" void fgnn_debug_set_scan_help_after(int polls) {
   fgnn::g_scan_help_after.store(polls, std::memory_order_relaxed);
 }
 
+extern "C" int fgnn_debug_sort_pairs(uint32_t *d_keys, uint32_t *d_vals, size_t n, void *stream) {
+  if (n == 0) return FGNN_OK;
+  if (!d_keys || !d_vals) return FGNN_EINVAL;
+  auto st = static_cast<hipStream_t>(stream);
+  uint32_t *tmp = nullptr;
+  const size_t words = 2 * n + fgnn::sort_pairs_ws_words(n);
+  if (hipMalloc(&tmp, words * sizeof(uint32_t)) != hipSuccess) return FGNN_EHIP;
+  uint32_t *sk = nullptr, *sv = nullptr;
+  int rc = fgnn::launch_sort_pairs_u32(d_keys, tmp, d_vals, tmp + n, n, tmp + 2 * n, st, &sk, &sv);
+  if (rc == FGNN_OK && sk != d_keys) {  // (the small-n paths leave the result in the alternate buffers)
+    if (hipMemcpyAsync(d_keys, sk, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_vals, sv, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      rc = FGNN_EHIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = FGNN_EHIP;
+  (void)hipFree(tmp);
+  return rc;
+}
+
 extern "C" size_t fgnn_debug_phase_log_bytes(void) {
   return (size_t)fgnn::kPhaseLogKinds * fgnn::kPhaseLogTiles * 8 * sizeof(unsigned long long);
 }

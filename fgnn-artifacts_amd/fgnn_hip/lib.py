@@ -22,7 +22,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
          torch.int8: I8, torch.int64: I64}
 
 EXPORTS = [
-    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_debug_set_scan_help_after", "fgnn_debug_set_partition_lds_limit", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_debug_set_scan_help_after", "fgnn_debug_set_partition_lds_limit", "fgnn_debug_sort_pairs", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
@@ -142,6 +142,14 @@ def sample_khop(kind, indptr, indices, inp, fanout, seed, batch_key, layer, src_
               C.c_uint64(batch_key), C.c_uint32(layer), _ptr(ws), C.c_size_t(ws.numel()), _stream())
     _check(code, "fgnn_sample_" + kind)
     return out_src, out_dst, d_num_out
+
+
+def debug_sort_pairs(keys, vals):
+    """fgnn_debug_sort_pairs: (keys, vals) int32 CUDA tensors sorted in place by key (as uint32), stable."""
+    _need_gpu(keys, vals)
+    assert keys.numel() == vals.numel()
+    _check(load().fgnn_debug_sort_pairs(_ptr(keys), _ptr(vals), C.c_size_t(keys.numel()), _stream()),
+           "fgnn_debug_sort_pairs")
 
 
 def sample_weighted_khop_prefix(indptr, indices, prefix, inp, fanout, seed, batch_key, layer, src_mode=SRC_GLOBAL,

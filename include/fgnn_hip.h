@@ -66,6 +66,10 @@ void fgnn_debug_set_scan_help_after(int polls);
  * table before the bin falls back to the global table; a small value forces the fall-back path, a negative one
  * restores the default (3/4 of the 8192 slots). */
 void fgnn_debug_set_partition_lds_limit(int distinct_keys);
+/* Diagnostics (tests): the stable (key, value) sort the stateless with-replacement samplers order their seeds with
+ * (scan.hip; where the reference calls cub::DeviceRadixSort, cuda_sampling_weighted_khop_prefix.cu:200-215), on its
+ * own: n uint32 pairs sorted by key in place, equal keys in their input order.  Allocates its scratch and waits. */
+int fgnn_debug_sort_pairs(uint32_t *d_keys, uint32_t *d_vals, size_t n, void *stream);
 
 /* Bytes of scratch that any single call below needs for `n_cap` items. */
 size_t fgnn_scratch_bytes(size_t n_cap);

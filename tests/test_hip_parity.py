@@ -387,6 +387,24 @@ def test_weighted_prefix_matches_oracle(hip, oracle, fanout):
             assert (np.diff(o_src.astype(np.int64)) >= 0).all()  # ordered by seed id (stable radix sort by src)
 
 
+@pytest.mark.parametrize("bits", [32, 9])
+def test_pair_sort_is_stable_for_any_keys(hip, bits):
+    """scan.hip's sort on its own (fgnn_debug_sort_pairs): random 32-bit keys (all four digit passes) and 9-bit keys
+    (heavy duplicates: stability decides the order of the values), at sizes either side of the switch from counting to
+    one-launch radix passes (8192) and to three-launch passes (65536), and of a tile -- against numpy's stable argsort."""
+    rng = np.random.default_rng(bits)
+    for n in [0, 1, 255, 257, 8192, 8193, 30000, 65536, 65537, 1 << 20, (1 << 20) + 77]:
+        keys = rng.integers(0, 1 << bits, size=n, dtype=np.uint64).astype(np.uint32)
+        if n > 3:
+            keys[rng.integers(0, n, size=3)] = 0xFFFFFFFF  # the samplers' padding key
+        vals = np.arange(n, dtype=np.uint32)
+        d_k, d_v = (dev(keys), dev(vals)) if n else (torch.empty(0, dtype=torch.int32, device="cuda"),) * 2
+        hip.debug_sort_pairs(d_k, d_v)
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(host_u32(d_k), keys[order], err_msg="n=%d" % n)
+        np.testing.assert_array_equal(host_u32(d_v), vals[order], err_msg="n=%d" % n)
+
+
 def test_weighted_prefix_orders_many_seeds_of_unknown_range(hip, oracle):
     """The stateless entry point cannot know the id range, so it sorts the seeds (scan.hip, where the reference calls
     cub::DeviceRadixSort, cuda_sampling_weighted_khop_prefix.cu:200-215): by counting up to 8192 seeds, with one launch
