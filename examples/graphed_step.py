@@ -58,6 +58,9 @@ class GraphedSageStep:
         if not os.environ.get("PYTORCH_TUNABLEOP_FILENAME") and not self.tuned_shapes:
             # (TunableOp logs its picks to a file as it goes: not into the working directory)
             tn.set_filename(os.path.join(tempfile.gettempdir(), "fgnn_tunableop_%d.csv" % os.getpid()))
+        if not self.tuned_shapes:  # bound the tuner's own time: a few timed runs per candidate kernel are enough
+            tn.set_max_tuning_duration(15)
+            tn.set_max_tuning_iterations(20)
         tn.tuning_enable(True)
         try:
             out = self.model(blocks, x)
