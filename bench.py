@@ -885,27 +885,16 @@ class HostTable:
 
 def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label, steps_per_epoch, next_seq, run_region,
                     timed_region, mode, leg, metas, cached_ms):
+    """BASELINE config 3's trainer-side leg on this GPU.  PRIMARY = the contract configuration, presample_epoch =
+    args.presample_epochs (default 1: the reference's default, common_config.py:70, and SURVEY 8(d)); every value of
+    --presample-variants (default 3) is measured the same way afterwards and reported under `variants` -- a longer
+    ranking is a CONFIGURATION change (higher hit rate, fewer host-link bytes), not a kernel change."""
     bs = w["batch_size"]
     num_node, dim = w["num_node"], w["feat_dim"]
     t_init = time.time()
-    # pre-sampling: --presample-epochs epochs of the sampling path, frequency of every input node (keys of their own so
-    # that the draws differ from the measured batches', eng_engine.cc:PreSample; RunConfig::presample_epoch)
     freq = torch.zeros(num_node, dtype=torch.int32, device=dev)
     bt = batches[0]
-    with torch.cuda.stream(streams[0]):
-        for step in range(steps_per_epoch * max(1, args.presample_epochs)):
-            s0 = step % steps_per_epoch
-            seeds = train[s0 * bs:min(train.numel(), (s0 + 1) * bs)]
-            sampler.sample(seeds, (1 << 63) | step, bt, seq=next_seq)
-            next_seq += 1
-            lib.presample_count(freq, bt.input_nodes_buffer(), d_num_nodes=bt.d_num_input())
-        bt.finish()
-        bt.wait()
-        rank = lib.presample_rank(freq)
-        n_cached = int(num_node * args.cache_ratio)
-        ptable = lib.cache_table_build(rank, n_cached)
-        streams[0].synchronize()
-    t_presample = time.time() - t_init
+    n_cached = int(num_node * args.cache_ratio)
     # host feature table: 2^k rows, node ids masked (SAMGRAPH_EMPTY_FEAT / the reference's papers100M_empty): the full
     # 57 GB table is not needed to exercise random host-DRAM row reads; 2^24 rows x 512 B = 8.6 GB is far beyond any cache
     bits = min(args.empty_feat_bits, int(np.floor(np.log2(num_node))))
@@ -929,9 +918,6 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
     numa_info = {"gpu_node": gnode, "nodes_with_memory": nodes, "host_feat_placement": placement,
                  "host_feat_pages_by_node": pages_by_numa_node(host_feat.data_ptr(), host_feat.numel() * 4),
                  "policy_requested": want}
-    # the cache holds the rows the trainer would read for the cached nodes: feat[rank[i] & mask]
-    cache_rows = torch.empty((n_cached, dim), dtype=torch.float32, device=dev)
-    lib.gather_rows(cache_rows, feat, src_index=rank[:n_cached], src_row_mask=mask)
     n_leg_streams = 4 if len(streams) == 3 else len(streams)
     leg_streams = list(streams) + [torch.cuda.Stream(device=dev) for _ in range(n_leg_streams - len(streams))]
     leg_batches = list(batches) + [sampler.new_batch(dim, lib.F32, lib.I64)
@@ -940,66 +926,121 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
         b.enable_timing(k == 0)
     for b in leg_batches:
         lib.load().fgnn_batch_set_feat_row_mask(b.h, mask)
-    # what the kernels get: the device-visible address of the table (== the host address for hipHostMalloc memory)
-    leg.update(table=ptable, cache_rows=cache_rows, streams=leg_streams, batches=leg_batches,
-               host_feat=lib.DevicePointer(table_obj.device_ptr, host_feat) if table_obj else host_feat)
-    torch.cuda.synchronize()
-    mode[0] = "cached"
-    # correctness of the leg, once: every row of one batch equals feat[input_nodes & mask]
-    step0 = 3
-    sampler.run_batch_cached(next_seq, train[step0 * bs:(step0 + 1) * bs], step0, bt, ptable, cache_rows,
-                             leg["host_feat"], label, stream=streams[0])
-    next_seq += 1
-    m = bt.wait()
-    torch.cuda.synchronize()
-    want = feat[(bt.input_nodes().to(torch.int64) & 0xFFFFFFFF) & mask]
-    if not torch.equal(bt.feat(), want):
-        raise RuntimeError("cached extraction differs from the direct gather")
-    del want
-    n = min(args.steps, 64)
-    metas.clear()
-    cached_ms.clear()
-    run_region(next_seq, next_seq + 6, False)
-    next_seq += 6
-    dt = timed_region(next_seq, next_seq + n)
-    next_seq += n
-    edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
-    rows = sum(int(m.num_input) for m in metas)
-    miss = sum(int(m.num_miss) for m in metas)
-    hit = sum(int(m.num_cache) for m in metas)
+    cache_rows = torch.empty((n_cached, dim), dtype=torch.float32, device=dev)
     row_b = dim * 4
-    ms_miss = [a for a, _ in cached_ms if a >= 0]
-    ms_hit = [b for _, b in cached_ms if b >= 0]
-    # per-launch rates from the HIP events of each launch (launches of different batches overlap on the link / in
-    # HBM, so these are what one launch gets while the others run); the whole-region rates are bytes / wall time
-    miss_bytes, hit_bytes = miss * (row_b + 8), hit * (2 * row_b + 8)
-    res = {
-        "workload": f"features in host memory ({1 << bits} rows, ids masked), HBM cache of {n_cached} rows "
-                    f"(ratio {args.cache_ratio}) ranked by the pre-sampler over {max(1, args.presample_epochs)} epoch(s), same batches "
-                    f"as the headline, "
-                    f"{n_leg_streams} batches in flight",
-        "streams": n_leg_streams,
-        "steps": n, "ms_per_step": dt / n * 1e3, "edges_per_s": edges / dt, "rows_per_s": rows / dt,
-        "hit_rate": hit / max(rows, 1), "miss_rows_per_step": miss / n, "hit_rows_per_step": hit / n,
-        "miss": {"bound": "host link", "bytes_per_step": miss * row_b / n,
-                 "achieved": miss * row_b / dt / 1e9, "peak": HOST_LINK_GBS, "unit": "GB/s",
-                 "frac": miss * row_b / dt / 1e9 / HOST_LINK_GBS,
-                 "avg_launch_ms": float(np.mean(ms_miss)) if ms_miss else None,
-                 "note": "host-link bytes = miss rows x row bytes, over the WALL time of the region (all batches)"},
-        "cached": {"bound": "hbm", "bytes_per_step": hit_bytes / n,
-                   "avg_launch_ms": float(np.mean(ms_hit)) if ms_hit else None,
-                   "achieved": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 if ms_hit else None,
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_hit else None,
-                   "note": "CombineCacheData launch: hit rows x (read + write + 2 index words) / its HIP-event time"},
-        "presample_s": t_presample, "init_s": time.time() - t_init - dt,
-        "checked": "one batch compared row by row with the direct gather",
-        "numa": numa_info,
-    }
+    state = {"epochs": 0, "seq": next_seq, "presample_s": 0.0}
+
+    def presample_to(epochs):
+        """continue the pre-sampling up to `epochs` epochs (keys of their own so that the draws differ from the measured
+        batches', eng_engine.cc:PreSample; RunConfig::presample_epoch), rank, rebuild the cache"""
+        t0 = time.time()
+        with torch.cuda.stream(streams[0]):
+            for step in range(steps_per_epoch * state["epochs"], steps_per_epoch * epochs):
+                s0 = step % steps_per_epoch
+                seeds = train[s0 * bs:min(train.numel(), (s0 + 1) * bs)]
+                sampler.sample(seeds, (1 << 63) | step, bt, seq=state["seq"])
+                state["seq"] += 1
+                lib.presample_count(freq, bt.input_nodes_buffer(), d_num_nodes=bt.d_num_input())
+            bt.finish()
+            bt.wait()
+            rank = lib.presample_rank(freq)
+            ptable = lib.cache_table_build(rank, n_cached)
+            # the cache holds the rows the trainer would read for the cached nodes: feat[rank[i] & mask]
+            lib.gather_rows(cache_rows, feat, src_index=rank[:n_cached], src_row_mask=mask)
+            streams[0].synchronize()
+        state["epochs"] = epochs
+        state["presample_s"] += time.time() - t0
+        return rank, ptable
+
+    def measure(epochs, ptable, checked):
+        # what the kernels get: the device-visible address of the table (== the host address for hipHostMalloc memory)
+        leg.update(table=ptable, cache_rows=cache_rows, streams=leg_streams, batches=leg_batches,
+                   host_feat=lib.DevicePointer(table_obj.device_ptr, host_feat) if table_obj else host_feat)
+        torch.cuda.synchronize()
+        mode[0] = "cached"
+        if not checked:
+            # correctness of the leg, once per ranking: every row of one batch equals feat[input_nodes & mask]
+            step0 = 3
+            sampler.run_batch_cached(state["seq"], train[step0 * bs:(step0 + 1) * bs], step0, bt, ptable, cache_rows,
+                                     leg["host_feat"], label, stream=streams[0])
+            state["seq"] += 1
+            bt.wait()
+            torch.cuda.synchronize()
+            ref = feat[(bt.input_nodes().to(torch.int64) & 0xFFFFFFFF) & mask]
+            if not torch.equal(bt.feat(), ref):
+                raise RuntimeError("cached extraction differs from the direct gather")
+            del ref
+        n = min(args.steps, 64)
+        metas.clear()
+        cached_ms.clear()
+        run_region(state["seq"], state["seq"] + 8, False)
+        state["seq"] += 8
+        dt = timed_region(state["seq"], state["seq"] + n)
+        state["seq"] += n
+        edges = sum(int(m.num_edge[l]) for m in metas for l in range(m.num_layers))
+        rows = sum(int(m.num_input) for m in metas)
+        miss = sum(int(m.num_miss) for m in metas)
+        hit = sum(int(m.num_cache) for m in metas)
+        ms_miss = [a for a, _ in cached_ms if a >= 0]
+        ms_hit = [b for _, b in cached_ms if b >= 0]
+        hit_bytes = hit * (2 * row_b + 8)
+        return {
+            "presample_epoch": epochs,
+            "workload": f"features in host memory ({1 << bits} rows, ids masked), HBM cache of {n_cached} rows "
+                        f"(ratio {args.cache_ratio}) ranked by the pre-sampler over {epochs} epoch(s), same batches as "
+                        f"the headline, {n_leg_streams} batches in flight",
+            "streams": n_leg_streams,
+            "steps": n, "ms_per_step": dt / n * 1e3, "edges_per_s": edges / dt, "rows_per_s": rows / dt,
+            "hit_rate": hit / max(rows, 1), "miss_rows_per_step": miss / n, "hit_rows_per_step": hit / n,
+            "kernel": "extract_fused_kernel: ONE launch per batch -- a band of %d workgroups pulls the miss rows over "
+                      "the host link while the rest of the grid streams the hit rows from the HBM cache; labels and the "
+                      "batch summary ride in the HBM band (SURVEY 8(f) rank 1)" % lib.LINK_WGS_SHARED,
+            "miss": {"bound": "host link", "bytes_per_step": miss * row_b / n,
+                     "achieved": miss * row_b / dt / 1e9, "peak": HOST_LINK_GBS, "unit": "GB/s",
+                     "frac": miss * row_b / dt / 1e9 / HOST_LINK_GBS,
+                     "band_ms": float(np.mean(ms_miss)) if ms_miss else None,
+                     "note": "host-link bytes = miss rows x row bytes over the WALL time of the region (all batches; "
+                             "this GPU also samples them); band_ms = first start .. last end of the link band's "
+                             "workgroups inside one launch (device clock; bands of up to %d batches share the link)"
+                             % n_leg_streams},
+            "cached": {"bound": "hbm", "bytes_per_step": hit_bytes / n,
+                       "band_ms": float(np.mean(ms_hit)) if ms_hit else None,
+                       "achieved": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 if ms_hit else None,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": (hit_bytes / n) / (float(np.mean(ms_hit)) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_hit else None,
+                       "note": "HBM band of the launch: hit rows x (read + write + 2 index words) / the band's first "
+                               "start .. last end (device clock stamps of its workgroups, timed batches only)"},
+        }
+
+    primary_epochs = max(1, args.presample_epochs)
+    variants = sorted({int(v) for v in str(args.presample_variants).split(",") if v.strip()} - {primary_epochs})
+    results = {}
+    rank1 = None
+    for ep in sorted({primary_epochs, *variants}):
+        rank, ptable = presample_to(ep)
+        results[ep] = measure(ep, ptable, checked=False)
+        if ep == primary_epochs:
+            rank1 = rank
+        else:
+            del rank
+        del ptable
+    res = results[primary_epochs]
+    res.update({"presample_s": state["presample_s"], "init_s": time.time() - t_init,
+                "checked": "one batch per ranking compared row by row with the direct gather", "numa": numa_info,
+                "contract": "presample_epoch = %d%s" % (primary_epochs, " (SURVEY 8(d); reference default, "
+                            "example/samgraph/common_config.py:70)" if primary_epochs == 1 else " (NOT the contract's 1)"),
+                "variants": {"presample_epoch_%d" % ep: {k: results[ep][k] for k in
+                                                         ("ms_per_step", "hit_rate", "miss_rows_per_step", "edges_per_s",
+                                                          "miss", "cached")}
+                             for ep in variants},
+                "variants_note": "same kernels, same batches, a longer pre-sampling ranking (the reference's runner "
+                                 "sweeps 1-3, exp/common/runner_helper.py:47-49): a configuration change"})
+    next_seq = state["seq"]
+    rank = rank1
     # How good is the pre-sampler's ranking?  One more epoch of sampling, counted: the hit rate of the pre-sampler's
     # cache on THAT epoch next to the cache that knows the epoch in advance (the reference's cache-by-fake-optimal tool,
     # utility/data-process/toolkit/cache/cache_by_fake_optimal.cc:66-185: rank by the frequencies of the measured
-    # epochs themselves) and next to the static in-degree ranking (cache_by_degree), all at the same ratio
+    # epochs themselves), all at the same ratio
     try:
         freq2 = torch.zeros(num_node, dtype=torch.int32, device=dev)
         with torch.cuda.stream(streams[0]):
@@ -1017,7 +1058,8 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
             hit_opt = float(f64[(rank2[:n_cached].to(torch.int64) & 0xFFFFFFFF)].sum()) / total
             streams[0].synchronize()
         res["hit_rate_by_policy"] = {
-            "pre_sample (%d epoch(s), what the leg above used)" % max(1, args.presample_epochs): hit_pre, "fake_optimal (hindsight on the same epoch)": hit_opt,
+            "pre_sample (%d epoch(s), what the leg above used)" % primary_epochs: hit_pre,
+            "fake_optimal (hindsight on the same epoch)": hit_opt,
             "note": "row-weighted hit rates of one further sampled epoch at cache ratio %.2f; fake_optimal ranks by that "
                     "epoch's own frequencies (cache_by_fake_optimal.cc), an upper bound for any static cache" % args.cache_ratio}
         del freq2, f64, rank2
@@ -1027,7 +1069,7 @@ def run_extract_leg(args, w, dev, sampler, batches, streams, train, feat, label,
         lib.load().fgnn_batch_set_feat_row_mask(b.h, 0xFFFFFFFF)
     mode[0] = "full"
     leg.clear()
-    del host_feat, cache_rows, ptable, freq, rank
+    del host_feat, cache_rows, freq, rank, rank1
     if table_obj is not None:
         torch.cuda.synchronize()
         table_obj.free()
@@ -1919,7 +1961,10 @@ def parse_args(argv=None):
     ap.add_argument("--graph", default=os.environ.get("FGNN_BENCH_GRAPH", "rmat"), choices=["rmat", "powerlaw"],
                     help="rmat: SURVEY.md 8(d)'s generator (default); powerlaw: round 1's locality-free generator")
     ap.add_argument("--cache-ratio", type=float, default=0.2)
-    ap.add_argument("--presample-epochs", type=int, default=3,
+    ap.add_argument("--presample-variants", default="3",
+                    help="N=1 extract leg: further presample_epoch values measured after the primary one and reported "
+                         "under roofline_extract.variants (comma-separated; empty: none)")
+    ap.add_argument("--presample-epochs", type=int, default=1,
                     help="RunConfig::presample_epoch of the pre-sample cache policy (dist/pre_sampler.cc:75-162): epochs "
                          "the access frequencies are counted over.  The reference's scripts default to 1 and its experiment "
                          "runner sweeps 1-3 (exp/common/runner_helper.py:47-49).  One epoch touches 0.105 N distinct nodes "
@@ -1972,6 +2017,10 @@ def parse_args(argv=None):
                     help="random_walk workloads: walks per seed (default: the workload's 25; the reference's PinSAGE "
                          "scripts default to 4, multi_gpu/train_pinsage.py:130-134)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A4D47)
+    ap.add_argument("--kernel-lib", default=None,
+                    help="tools/ only: another build of the kernel library for the N = 1 path ('prof' = "
+                         "lib/libfgnn_hip_prof.so, the build that reads FGNN_* A/B switches); the product loads "
+                         "lib/libfgnn_hip.so and reads nothing from the environment")
     ap.add_argument("--cpu-only", action="store_true",
                     help="BASELINE.json configs[0] only: the reference's CPU path (oracle/_ref) on the products shape, "
                          "fanout 10/5; needs no GPU and measures nothing of the product")
@@ -1983,6 +2032,8 @@ def main():
     # (samgraph_config sets the same default; here it also covers the torch side of a trainer rank)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args = parse_args()
+    if args.kernel_lib:  # measurement tools only: the profiling build of the kernel library
+        lib.use_library(lib.PROF_LIB_PATH if args.kernel_lib == "prof" else args.kernel_lib)
     if args.n1_point_child:
         return run_n1_point_child()
     if args.cpu_only:

@@ -16,6 +16,7 @@
 //    length is not a multiple of 16 (labels: dim 1 x 8 B).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "fgnn_device.h"
 
@@ -282,6 +283,162 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
   }
 }
 
+// ---- the one-launch trainer-side extraction (ExtractJob, fgnn_device.h) ----------------------------------------------
+// One band of workgroups `bid` of `nb` walking a list's rows as flat 16-byte chunks: the loop of gather_rows16_kernel
+// with both index arrays present, non-temporal loads and stores.
+template <int UNROLL, int CPR>
+__device__ __forceinline__ void gather_band(chunk16 *__restrict__ out, const chunk16 *__restrict__ src,
+                                            const uint32_t *__restrict__ src_index,
+                                            const uint32_t *__restrict__ dst_index, uint32_t n, uint32_t cpr_rt,
+                                            uint32_t src_mask, uint32_t bid, uint32_t nb) {
+  const uint32_t cpr = CPR ? (uint32_t)CPR : cpr_rt;
+  const uint32_t total = n * cpr;  // host guarantees cap * cpr < 2^32
+  constexpr uint32_t tile = kBlock * UNROLL;
+  const uint32_t full = total / tile * tile;
+  uint32_t tile0 = bid * tile;
+  for (; tile0 < full; tile0 += nb * tile) {
+    chunk16 v[UNROLL];
+    size_t dsts[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t cc = tile0 + u * kBlock + threadIdx.x;
+      const uint32_t row = cc / cpr;
+      const uint32_t col = cc - row * cpr;
+      const size_t srow = src_index[row] & src_mask;
+      const chunk16 *sp = src + srow * cpr + col;
+      v[u].a = __builtin_nontemporal_load(&sp->a);
+      v[u].b = __builtin_nontemporal_load(&sp->b);
+      v[u].c = __builtin_nontemporal_load(&sp->c);
+      v[u].d = __builtin_nontemporal_load(&sp->d);
+      dsts[u] = (size_t)dst_index[row] * cpr + col;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      chunk16 *dp = out + dsts[u];
+      __builtin_nontemporal_store(v[u].a, &dp->a);
+      __builtin_nontemporal_store(v[u].b, &dp->b);
+      __builtin_nontemporal_store(v[u].c, &dp->c);
+      __builtin_nontemporal_store(v[u].d, &dp->d);
+    }
+  }
+  if (tile0 == full && full < total) {  // ragged last tile: the workgroup whose turn it is
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t cc = full + u * kBlock + threadIdx.x;
+      if (cc < total) {
+        const uint32_t row = cc / cpr;
+        const uint32_t col = cc - row * cpr;
+        out[(size_t)dst_index[row] * cpr + col] = src[(size_t)(src_index[row] & src_mask) * cpr + col];
+      }
+    }
+  }
+}
+
+struct FusedArgs {
+  chunk16 *out;
+  const chunk16 *miss_rows, *cache_rows;
+  const uint32_t *miss_src, *miss_dst, *cache_src, *cache_dst;
+  size_t num_miss, num_cache;
+  const uint32_t *d_counts;
+  size_t cap;
+  uint32_t cpr, miss_mask;
+  uint32_t link_wgs;  // workgroups [0, link_wgs) are the link band
+  GatherTail tail;
+  unsigned long long *stamps;
+  // the word copies (arrays of a received message leaving its queue slot): flat index space over all segments
+  int num_segs;
+  uint32_t *seg_dst[FGNN_MAX_COPY_SEGMENTS];
+  const uint32_t *seg_src[FGNN_MAX_COPY_SEGMENTS];
+  uint32_t seg_begin[FGNN_MAX_COPY_SEGMENTS + 1];
+};
+
+// UL / UH: independent 16-byte loads in flight per lane in the link band / the HBM band
+template <int UL, int UH, int CPR>
+__global__ __launch_bounds__(kBlock) void extract_fused_kernel(const FusedArgs a) {
+  __shared__ uint32_t *s_dst[FGNN_MAX_COPY_SEGMENTS];
+  __shared__ const uint32_t *s_src[FGNN_MAX_COPY_SEGMENTS];
+  __shared__ uint32_t s_begin[FGNN_MAX_COPY_SEGMENTS + 1];
+  const uint32_t n_miss = (uint32_t)resolve_count(a.num_miss, a.d_counts, a.cap);
+  const uint32_t n_cache = (uint32_t)resolve_count(a.num_cache, a.d_counts ? a.d_counts + 1 : nullptr, a.cap);
+  // the link band is small on purpose: 16 workgroups x 4 loads per lane keep 256 KB of host reads in flight, twice what
+  // the link needs at its ~2 us latency; more of them only queue in front of everything else the chip has outstanding
+  // (profiles/r06_a_link_band_sweep.txt: 56 GB/s with 16 workgroups, 49 with 256 or with a launch of its own).  Packing
+  // the band onto one XCD (workgroups 0, 8, 16, ...) was measured too: no gain, the queueing is not per XCD
+  const bool in_link = blockIdx.x < a.link_wgs;
+  const uint32_t bid = in_link ? blockIdx.x : blockIdx.x - a.link_wgs;
+  // stamps are indexed by band position: [0, link_wgs) the link band, then the HBM band
+  const uint32_t stamp_at = in_link ? bid : a.link_wgs + bid;
+  if (a.stamps && threadIdx.x == 0) a.stamps[2 * stamp_at] = wall_clock64();
+  if (in_link) {
+    // link band: rows come over the host link, a few workgroups with several loads in flight each keep it full
+    gather_band<UL, CPR>(a.out, a.miss_rows, a.miss_src, a.miss_dst, n_miss, a.cpr, a.miss_mask, bid, a.link_wgs);
+  } else {
+    const uint32_t nb = gridDim.x - a.link_wgs;
+    const GatherTail &tail = a.tail;
+    if (tail.label_out) {
+      const uint32_t stride = nb * kBlock;
+      for (uint32_t i = bid * kBlock + threadIdx.x; i < tail.num_label; i += stride) {
+        const size_t r = tail.label_index[i];
+        switch (tail.label_esz) {
+          case 1: static_cast<uint8_t *>(tail.label_out)[i] = static_cast<const uint8_t *>(tail.label_src)[r]; break;
+          case 2: static_cast<uint16_t *>(tail.label_out)[i] = static_cast<const uint16_t *>(tail.label_src)[r]; break;
+          case 4: static_cast<uint32_t *>(tail.label_out)[i] = static_cast<const uint32_t *>(tail.label_src)[r]; break;
+          default:
+            static_cast<unsigned long long *>(tail.label_out)[i] = static_cast<const unsigned long long *>(tail.label_src)[r];
+        }
+      }
+    }
+    // the summary is final before this launch starts (every kernel that writes it is earlier in the stream)
+    if (tail.meta_dst && bid == nb - 1 && threadIdx.x < tail.meta_words) tail.meta_dst[threadIdx.x] = tail.meta_src[threadIdx.x];
+    if (a.num_segs) {
+      // the table goes to LDS with constant indices into the kernel arguments (a variable index would make the
+      // compiler copy them to scratch memory)
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < FGNN_MAX_COPY_SEGMENTS; ++k) {
+          s_dst[k] = a.seg_dst[k];
+          s_src[k] = a.seg_src[k];
+          s_begin[k] = a.seg_begin[k];
+        }
+        s_begin[FGNN_MAX_COPY_SEGMENTS] = a.seg_begin[FGNN_MAX_COPY_SEGMENTS];
+      }
+      __syncthreads();
+      const int ns = a.num_segs;
+      const uint32_t total = s_begin[ns];
+      const uint32_t stride = nb * kBlock;
+      constexpr int U = 8;
+      // (i0 + u * stride stays below 2^32: the host refuses copies of 2^31 words and more)
+      for (uint32_t i0 = bid * kBlock + threadIdx.x; i0 < total; i0 += U * stride) {
+        uint32_t v[U];
+        uint32_t *d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = i0 + u * stride;
+          d[u] = nullptr;
+          v[u] = 0;
+          if (i < total && i >= i0) {
+            int s = 0;
+            while (s + 1 < ns && i >= s_begin[s + 1]) ++s;
+            const uint32_t off = i - s_begin[s];
+            d[u] = s_dst[s] + off;
+            v[u] = s_src[s][off];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (d[u]) *d[u] = v[u];
+      }
+    }
+    if (a.link_wgs == 0)  // miss rows in HBM too: every workgroup takes its share of both lists
+      gather_band<UH, CPR>(a.out, a.miss_rows, a.miss_src, a.miss_dst, n_miss, a.cpr, a.miss_mask, bid, nb);
+    gather_band<UH, CPR>(a.out, a.cache_rows, a.cache_src, a.cache_dst, n_cache, a.cpr, 0xFFFFFFFFu, bid, nb);
+  }
+  if (a.stamps) {
+    __syncthreads();
+    if (threadIdx.x == 0) a.stamps[2 * stamp_at + 1] = wall_clock64();
+  }
+}
+
 // generic element gather (element = 1, 2, 4 or 8 bytes)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gather_rows_elem_kernel(T *__restrict__ out, const T *__restrict__ src,
@@ -416,7 +573,7 @@ bool fgnn::gather_takes_tail(const void *out, const void *src, size_t n_cap, siz
 // is `p` host memory the GPU reads over the host link?  Asked per launch that could be one (a registered table may be
 // freed and its address reused for device memory: no caching by pointer value); a microsecond next to a launch whose
 // rows cross the host link
-static bool pointer_is_host(const void *p) {
+bool fgnn::pointer_is_host(const void *p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) == hipSuccess) return a.type == hipMemoryTypeHost;
   (void)hipGetLastError();
@@ -517,6 +674,149 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
 #undef FGNN_ELEM
   }
   return launch_status(__func__);
+}
+
+// ---- one-launch extraction: host side ----------------------------------------------------------------------------------
+namespace {
+
+struct FusedPlan {
+  uint32_t cpr = 0;
+  size_t link = 0, hbm = 0;  // workgroups per band
+  int ul = 4;
+};
+
+// false: the job cannot take the one-launch path (row width / alignment / size)
+bool fused_plan(const ExtractJob &j, FusedPlan *p) {
+  const size_t esz = dtype_bytes(j.dtype);
+  const size_t row_bytes = j.dim * esz;
+  if (!row_bytes || row_bytes % 16 || row_bytes / 16 > 0xffffffffull) return false;
+  const size_t cap_m = j.d_counts ? j.cap : j.num_miss, cap_c = j.d_counts ? j.cap : j.num_cache;
+  if ((cap_m && (!j.miss_rows || !j.miss_src || !j.miss_dst)) || (cap_c && (!j.cache_rows || !j.cache_src || !j.cache_dst)))
+    return false;
+  if ((cap_m || cap_c) && !j.out) return false;
+  for (const void *q : {(const void *)j.out, j.miss_rows, j.cache_rows})
+    if (reinterpret_cast<uintptr_t>(q) % 16) return false;
+  const size_t cpr = row_bytes / 16;
+  if (cap_m * cpr >= 0xffffffffull || cap_c * cpr >= 0xffffffffull) return false;
+  if (j.num_segs < 0 || j.num_segs > FGNN_MAX_COPY_SEGMENTS || (j.num_segs && !j.segs)) return false;
+  size_t words = 0;
+  for (int k = 0; k < j.num_segs; ++k) words += j.segs[k].words;
+  if (words >= (size_t(1) << 31)) return false;
+  p->cpr = (uint32_t)cpr;
+  p->ul = tune_int("FGNN_FUSED_LINK_UNROLL", 4) == 8 ? 8 : 4;
+  const size_t cus = (size_t)device_cu_count();
+  const size_t per_cu = (size_t)tune_int("FGNN_GATHER_WG_PER_CU", j.wg_per_cu ? (int)j.wg_per_cu : 4);
+  const size_t link_wgs = (size_t)tune_int("FGNN_FUSED_LINK_WGS", (int)j.link_wgs);
+  p->link = cap_m && link_wgs ? std::min(link_wgs, div_up(cap_m * cpr, (size_t)kBlock * p->ul)) : 0;
+  size_t chunks = cap_c * cpr + (p->link ? 0 : cap_m * cpr);
+  size_t hbm = div_up(chunks, (size_t)kBlock * 4);
+  hbm = std::max(hbm, div_up(words, (size_t)kBlock * 8));
+  if (j.tail.label_out) hbm = std::max(hbm, div_up((size_t)j.tail.num_label, (size_t)kBlock));
+  if (j.tail.meta_dst) hbm = std::max<size_t>(hbm, 1);
+  p->hbm = std::min(hbm, cus * per_cu);
+  return true;
+}
+
+}  // namespace
+
+bool fgnn::extract_can_fuse(const ExtractJob &j) {
+  FusedPlan p;
+  return fused_plan(j, &p);
+}
+
+size_t fgnn::extract_fused_grid(const ExtractJob &j, size_t *link) {
+  FusedPlan p;
+  if (!fused_plan(j, &p)) return 0;
+  if (link) *link = p.link;
+  return p.link + p.hbm;
+}
+
+int fgnn::extract_fused(const ExtractJob &j, void *stream, size_t *grid_out) {
+  FusedPlan p;
+  if (!fused_plan(j, &p)) return FGNN_EINVAL;
+  const size_t grid = p.link + p.hbm;
+  if (grid_out) *grid_out = grid;
+  if (grid == 0) return FGNN_OK;
+  FusedArgs a;
+  memset(static_cast<void *>(&a), 0, sizeof(a));
+  a.out = static_cast<chunk16 *>(j.out);
+  a.miss_rows = static_cast<const chunk16 *>(j.miss_rows);
+  a.cache_rows = static_cast<const chunk16 *>(j.cache_rows);
+  a.miss_src = j.miss_src; a.miss_dst = j.miss_dst; a.cache_src = j.cache_src; a.cache_dst = j.cache_dst;
+  a.num_miss = j.num_miss; a.num_cache = j.num_cache;
+  a.d_counts = j.d_counts;
+  a.cap = j.d_counts ? j.cap : std::max(j.num_miss, j.num_cache);  // (the kernel clamps either count to it)
+  a.cpr = p.cpr;
+  a.miss_mask = j.miss_mask;
+  a.link_wgs = (uint32_t)p.link;
+  a.tail = j.tail;
+  a.stamps = j.stamps;
+  for (int k = 0; k < j.num_segs; ++k) {
+    if (!j.segs[k].words) continue;
+    if (!j.segs[k].dst || !j.segs[k].src) return FGNN_EINVAL;
+    a.seg_dst[a.num_segs] = j.segs[k].dst;
+    a.seg_src[a.num_segs] = j.segs[k].src;
+    a.seg_begin[a.num_segs + 1] = a.seg_begin[a.num_segs] + (uint32_t)j.segs[k].words;
+    ++a.num_segs;
+  }
+  auto s = static_cast<hipStream_t>(stream);
+#define FGNN_FUSED2(UL, C) \
+  hipLaunchKernelGGL((extract_fused_kernel<UL, 4, C>), dim3((unsigned)grid), dim3(kBlock), 0, s, a)
+#define FGNN_FUSED(C) do { if (p.ul == 4) FGNN_FUSED2(4, C); else FGNN_FUSED2(8, C); } while (0)
+  if (p.cpr == 32) FGNN_FUSED(32);
+  else if (p.cpr == 64) FGNN_FUSED(64);
+  else if (p.cpr == 25) FGNN_FUSED(25);
+  else FGNN_FUSED(0);
+#undef FGNN_FUSED
+#undef FGNN_FUSED2
+  return launch_status(__func__);
+}
+
+namespace {
+ExtractJob job_from_c(const fgnn_extract_job *c) {
+  ExtractJob j;
+  memset(static_cast<void *>(&j), 0, sizeof(j));
+  j.out = c->out;
+  j.miss_rows = c->miss_rows; j.cache_rows = c->cache_rows;
+  j.miss_src = c->miss_src; j.miss_dst = c->miss_dst; j.cache_src = c->cache_src; j.cache_dst = c->cache_dst;
+  j.num_miss = c->num_miss; j.num_cache = c->num_cache;
+  j.d_counts = c->d_counts;
+  j.cap = c->cap;
+  j.dim = c->dim;
+  j.dtype = c->dtype;
+  j.miss_mask = c->miss_row_mask;
+  if (c->label_out && c->num_label) {
+    j.tail.label_out = c->label_out;
+    j.tail.label_src = c->label_src;
+    j.tail.label_index = c->label_index;
+    j.tail.num_label = (uint32_t)c->num_label;
+    j.tail.label_esz = (uint32_t)dtype_bytes(c->label_dtype);
+  }
+  j.segs = c->segs;
+  j.num_segs = c->num_segs;
+  j.link_wgs = c->link_workgroups > 0 ? (size_t)c->link_workgroups : 0;
+  j.stamps = c->stamps;
+  return j;
+}
+bool job_ok(const fgnn_extract_job *c) {
+  if (!c || c->num_label > 0xffffffffull) return false;
+  if (c->label_out && c->num_label && (!c->label_src || !c->label_index || dtype_bytes(c->label_dtype) == 0)) return false;
+  return true;
+}
+}  // namespace
+
+extern "C" int fgnn_extract_fused(const fgnn_extract_job *c, void *stream) {
+  if (!job_ok(c)) return FGNN_EINVAL;
+  return fgnn::extract_fused(job_from_c(c), stream, nullptr);
+}
+
+extern "C" size_t fgnn_extract_fused_link_grid(const fgnn_extract_job *c) {
+  size_t link = 0;
+  return job_ok(c) && fgnn::extract_fused_grid(job_from_c(c), &link) ? link : 0;
+}
+
+extern "C" size_t fgnn_extract_fused_grid(const fgnn_extract_job *c) {
+  return job_ok(c) ? fgnn::extract_fused_grid(job_from_c(c)) : 0;
 }
 
 // ---- dynamic cache index (the arch4 prototype): GPUDynamicCacheManager::ReplaceCacheGPU -----------------------------

@@ -83,6 +83,8 @@ struct fgnn_batch {
                                           // fgnn_batch_extract / the miss-row gather of fgnn_batch_extract_cached,
                                           // t1..t2 the cached-row gather
   bool timed2;
+  unsigned long long *h_stamps;           // pinned: per-workgroup start / end clocks of the one-launch cached extraction
+  size_t stamp_cap, stamp_grid, stamp_link;
   bool timing, timed;
   bool meta_copied;                       // the last extract launch of this batch also copied the summary to h_meta
   fgnn::ScanWsHost *scan;                 // look-back descriptors of the one-launch cache split
@@ -247,6 +249,7 @@ extern "C" void fgnn_batch_destroy(fgnn_batch *b) {
   if (b->t0) (void)hipEventDestroy(b->t0);
   if (b->t1) (void)hipEventDestroy(b->t1);
   if (b->t2) (void)hipEventDestroy(b->t2);
+  if (b->h_stamps) (void)hipHostFree(b->h_stamps);
   delete b;
 }
 
@@ -613,9 +616,29 @@ extern "C" int fgnn_batch_extract_cached_ms(fgnn_batch *b, float out[2]) {
   if (!b || !out) return FGNN_EINVAL;
   out[0] = out[1] = -1.0f;
   if (!b->timed2) return FGNN_OK;
+  if (b->stamp_grid) {
+    // one launch: a band's duration = first start .. last end over its workgroups (100 MHz wall clock)
+    auto span = [&](size_t lo, size_t hi) -> float {
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (size_t k = lo; k < hi; ++k) {
+        t0 = b->h_stamps[2 * k] < t0 ? b->h_stamps[2 * k] : t0;
+        t1 = b->h_stamps[2 * k + 1] > t1 ? b->h_stamps[2 * k + 1] : t1;
+      }
+      return hi > lo && t1 >= t0 ? (float)((double)(t1 - t0) * 1e-5) : -1.0f;
+    };
+    out[0] = span(0, b->stamp_link);
+    out[1] = span(b->stamp_link, b->stamp_grid);
+    return FGNN_OK;
+  }
   if (hipEventElapsedTime(&out[0], b->t0, b->t1) != hipSuccess) out[0] = -1.0f;
   if (hipEventElapsedTime(&out[1], b->t1, b->t2) != hipSuccess) out[1] = -1.0f;
   return FGNN_OK;
+}
+
+extern "C" float fgnn_batch_extract_launch_ms(fgnn_batch *b) {
+  float ms = -1.0f;
+  if (b && b->timed2 && hipEventElapsedTime(&ms, b->t0, b->t2) != hipSuccess) ms = -1.0f;
+  return ms;
 }
 
 extern "C" int fgnn_batch_set_feat_row_mask(fgnn_batch *b, uint32_t mask) {
@@ -677,12 +700,55 @@ extern "C" int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, 
   int rc = FGNN_OK;
   auto st = static_cast<hipStream_t>(stream);
   const bool timing = b->timing && full_feat && cache_rows;
-  // the tail rides on the LAST gather of the batch
   fgnn::GatherTail tail;
   const void *last_src = cache_rows ? cache_rows : full_feat;
   const bool tailed = last_src && make_tail(b, last_src, label, &tail);
+  // ONE launch (CombineMissData + CombineCacheData, cuda_cache_manager_device.cu:165-210,339-442,
+  // with ExtractMissData's fetch fused in): a band of workgroups pulls the miss rows over the host link while the rest
+  // of the grid streams the hit rows out of the HBM cache; labels and the summary ride in the HBM band
+  fgnn::ExtractJob job;
+  std::memset(static_cast<void *>(&job), 0, sizeof(job));
+  job.out = b->feat;
+  job.miss_rows = full_feat;
+  job.cache_rows = cache_rows;
+  job.miss_src = b->cidx[0]; job.miss_dst = b->cidx[1]; job.cache_src = b->cidx[2]; job.cache_dst = b->cidx[3];
+  job.d_counts = &b->d_meta->num_miss;  // num_miss, num_cache: adjacent words of the summary
+  job.cap = b->feat_rows_cap;
+  job.dim = b->feat_dim;
+  job.dtype = b->feat_dtype;
+  job.miss_mask = b->feat_row_mask;
+  if (tailed) job.tail = tail;
+  if (full_feat && cache_rows && tailed && fgnn::extract_can_fuse(job)) {
+    job.link_wgs = fgnn::pointer_is_host(full_feat) ? FGNN_LINK_WGS_SHARED : 0;  // this GPU samples too
+    if (timing) {
+      const size_t grid = fgnn::extract_fused_grid(job);
+      if (grid > b->stamp_cap) {
+        if (b->h_stamps) (void)hipHostFree(b->h_stamps);
+        b->h_stamps = nullptr;
+        b->stamp_cap = 0;
+        // pinned host memory: every workgroup posts its two clock words there, no copy behind the launch
+        FGNN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b->h_stamps), 2 * grid * sizeof(unsigned long long),
+                                     hipHostMallocDefault));
+        b->stamp_cap = grid;
+      }
+      job.stamps = b->h_stamps;
+      FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
+    }
+    size_t grid = 0;
+    rc = fgnn::extract_fused(job, stream, &grid);
+    if (timing) {
+      FGNN_HIP_CHECK(hipEventRecord(b->t2, st));
+      b->stamp_grid = grid;
+      (void)fgnn::extract_fused_grid(job, &b->stamp_link);
+      b->timed2 = true;
+    }
+    if (rc == FGNN_OK) b->meta_copied = true;
+    return rc;
+  }
+  // rows that are not whole 16-byte chunks, or one source missing: one launch per list
+  b->stamp_grid = 0;
   if (timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
-  if (full_feat)  // CombineMissData with the row fetch fused in
+  if (full_feat)
     rc = fgnn::gather_rows_ex(b->feat, full_feat, b->cidx[0], b->cidx[1], 0, &b->d_meta->num_miss, b->feat_rows_cap,
                               b->feat_dim, b->feat_dtype, b->feat_row_mask, stream,
                               tailed && !cache_rows ? &tail : nullptr,

@@ -845,6 +845,7 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     b->input_nodes = d_input;
     b->input_device = tdevice_;
   }
+  const uint32_t *slot_output = p;
   uint32_t *d_output = to_device(p, hdr.output_size);
   p += hdr.output_size;
   b->output_nodes = d_output;
@@ -895,17 +896,66 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
                         << ") does not verify on the receiving GPU -- the payload read through the "
                         << "mapped slot differs from what the sampler packed";
   }
-  SAM_FGNN(LaunchUnpack(ua, tstream_));
-
   // features (DoCacheFeatureCopy / DoSwitchCacheFeatureCopy / DoCPUFeatureExtract+DoFeatureCopy)
   const size_t row_bytes = ds_.feat_dim * 4;
   void *d_feat = dev_pool_.Alloc(hdr.input_size * row_bytes);
   b->pooled.push_back(d_feat);
   b->feat = d_feat;
   b->feat_rows = hdr.input_size;
+  void *d_lab = dev_pool_.Alloc(hdr.output_size * 8);
+  b->pooled.push_back(d_lab);
+  b->label = d_lab;
   size_t miss_rows = num_miss;
-  bool timed_gathers = false;
-  if (!use_cache) {
+  bool timed_gathers = false, unpacked = false, labelled = false;
+  x.stamp_grid = 0;
+  if (use_cache && dist_type_ != DistType::Switch) {
+    // the whole batch in ONE launch: a band of workgroups pulls the miss rows over the host link
+    // (CombineMissData with ExtractMissData's fetch fused in) while the rest of the grid streams the hit rows out of
+    // the HBM cache (CombineCacheData), gathers the labels (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) and copies
+    // the arrays that outlive the queue slot out of it (ParseData); the reference: ~10 copies, an OpenMP gather and two
+    // kernels with a sync after each (dist_loops.cc:713-929)
+    fgnn_copy_segment segs[UnpackArgs::kMaxSegments];
+    for (int k = 0; k < ua.num_segments; ++k) segs[k] = fgnn_copy_segment{ua.seg[k].dst, ua.seg[k].src, ua.seg[k].words};
+    fgnn_extract_job j;
+    memset(&j, 0, sizeof(j));
+    j.out = d_feat;
+    j.miss_rows = dev_host_feat_;
+    j.cache_rows = d_cache_rows_;
+    j.miss_src = d_cidx[0]; j.miss_dst = d_cidx[1]; j.cache_src = d_cidx[2]; j.cache_dst = d_cidx[3];
+    j.num_miss = num_miss;
+    j.num_cache = num_cache;
+    j.dim = ds_.feat_dim;
+    j.dtype = FGNN_F32;
+    j.miss_row_mask = FeatRowMask();
+    j.label_out = d_lab;
+    j.label_src = d_label_;
+    j.label_index = in_place(slot_output);  // read where the message has them: the copy above is this launch's own
+    j.num_label = hdr.output_size;
+    j.label_dtype = FGNN_I64;
+    j.segs = segs;
+    j.num_segs = ua.num_segments;
+    j.link_workgroups = ExtractorSharesGpu() ? FGNN_LINK_WGS_SHARED : FGNN_LINK_WGS_DEDICATED;
+    const size_t grid = fgnn_extract_fused_grid(&j);
+    if (grid) {
+      // per-band durations (kLogL3CacheCombine{Miss,Cache}Time): every workgroup posts its start / end clock into
+      // pinned host memory -- no event records around the launch, no copy behind it
+      if (grid > x.stamp_cap) {
+        if (x.h_stamps) (void)hipHostFree(x.h_stamps);
+        x.stamp_cap = grid + 256;
+        SAM_HIP(hipHostMalloc(reinterpret_cast<void **>(&x.h_stamps), 2 * x.stamp_cap * sizeof(unsigned long long),
+                              hipHostMallocDefault));
+      }
+      j.stamps = x.h_stamps;
+      SAM_FGNN(fgnn_extract_fused(&j, tstream_));
+      x.stamp_grid = grid;
+      x.stamp_link = fgnn_extract_fused_link_grid(&j);  // (fewer than asked for when the miss rows are few)
+      timed_gathers = unpacked = labelled = true;
+    }
+  }
+  if (!unpacked) SAM_FGNN(LaunchUnpack(ua, tstream_));
+  if (unpacked) {
+    // everything went with the one launch above
+  } else if (!use_cache) {
     SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, d_input, nullptr, hdr.input_size, nullptr, hdr.input_size,
                                      ds_.feat_dim, FGNN_F32, FeatRowMask(), ExtractorSharesGpu(), tstream_));
     miss_rows = hdr.input_size;
@@ -920,11 +970,28 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     uint32_t *d_counts = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + ws_bytes);
     SAM_FGNN(fgnn_get_miss_cache_index(d_cache_table_, d_input, n, nullptr, n, idx[0], idx[1], idx[2], idx[3], d_counts,
                                        ws, ws_bytes, tstream_));
-    SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32,
-                                     FeatRowMask(), ExtractorSharesGpu(), tstream_));
-    SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
-                              tstream_));
+    fgnn_extract_job j;
+    memset(&j, 0, sizeof(j));
+    j.out = d_feat;
+    j.miss_rows = dev_host_feat_;
+    j.cache_rows = d_cache_rows_;
+    j.miss_src = idx[0]; j.miss_dst = idx[1]; j.cache_src = idx[2]; j.cache_dst = idx[3];
+    j.d_counts = d_counts;
+    j.cap = n;
+    j.dim = ds_.feat_dim;
+    j.dtype = FGNN_F32;
+    j.miss_row_mask = FeatRowMask();
+    j.link_workgroups = FGNN_LINK_WGS_SHARED;  // a switcher shares its GPU with a sampler
+    if (fgnn_extract_fused_grid(&j)) {
+      SAM_FGNN(fgnn_extract_fused(&j, tstream_));
+    } else {
+      SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, idx[0], idx[1], 0, d_counts, n, ds_.feat_dim, FGNN_F32,
+                                       FeatRowMask(), ExtractorSharesGpu(), tstream_));
+      SAM_FGNN(fgnn_gather_rows(d_feat, d_cache_rows_, idx[2], idx[3], 0, d_counts + 1, n, ds_.feat_dim, FGNN_F32,
+                                tstream_));
+    }
   } else {
+    // rows that are not whole 16-byte chunks: one launch per list, bracketed by events
     SAM_HIP(hipEventRecord(te_[0], tstream_));
     if (num_miss)   // CombineMissData with the host fetch fused in
       SAM_FGNN(fgnn_gather_rows_shared(d_feat, dev_host_feat_, d_cidx[0], d_cidx[1], num_miss, nullptr, num_miss,
@@ -937,11 +1004,9 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     timed_gathers = true;
   }
   // labels (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) -- gathered on the GPU from the HBM copy
-  void *d_lab = dev_pool_.Alloc(hdr.output_size * 8);
-  b->pooled.push_back(d_lab);
-  b->label = d_lab;
-  SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
-                            tstream_));
+  if (!labelled)
+    SAM_FGNN(fgnn_gather_rows(d_lab, d_label_, d_output, nullptr, hdr.output_size, nullptr, hdr.output_size, 1, FGNN_I64,
+                              tstream_));
   xstat_.recv += recv_time;
   xstat_.issue += t_copy.Passed();
   ++xstat_.n;
@@ -981,8 +1046,22 @@ void Engine::TrainerComplete(ExtractCtx &x) {
   P.LogStep(b->key, kLogL2CacheCopyTime, copy_time);
   if (timed_gathers) {  // device time of the two gathers (the reference times them on the host around syncs)
     float ms_miss = 0, ms_cache = 0;
-    (void)hipEventElapsedTime(&ms_miss, te_[0], te_[1]);
-    (void)hipEventElapsedTime(&ms_cache, te_[1], te_[2]);
+    if (x.stamp_grid) {
+      // one launch: a band's time = first start .. last end over its workgroups (100 MHz device wall clock)
+      auto span = [&](size_t lo, size_t hi) -> float {
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t k = lo; k < hi; ++k) {
+          t0 = std::min(t0, x.h_stamps[2 * k]);
+          t1 = std::max(t1, x.h_stamps[2 * k + 1]);
+        }
+        return hi > lo && t1 >= t0 ? (float)((double)(t1 - t0) * 1e-5) : 0.0f;
+      };
+      ms_miss = span(0, x.stamp_link);
+      ms_cache = span(x.stamp_link, x.stamp_grid);
+    } else {
+      (void)hipEventElapsedTime(&ms_miss, te_[0], te_[1]);
+      (void)hipEventElapsedTime(&ms_cache, te_[1], te_[2]);
+    }
     P.LogStep(b->key, kLogL3CacheCombineMissTime, ms_miss * 1e-3);
     P.LogStep(b->key, kLogL3CacheCombineCacheTime, ms_cache * 1e-3);
   }
@@ -1124,6 +1203,7 @@ void Engine::Shutdown() {
       if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (x.st) { (void)hipStreamDestroy(x.st); x.st = nullptr; }
     if (x.d_check) { (void)hipFree(x.d_check); x.d_check = nullptr; }
+    if (x.h_stamps) { (void)hipHostFree(x.h_stamps); x.h_stamps = nullptr; x.stamp_cap = 0; }
     x.b.reset();
   }
   if (mq_ && ring_id_ >= 0) {

@@ -178,6 +178,10 @@ class Engine {
     Timer t_copy;
     bool timed_gathers = false;
     uint32_t *d_check = nullptr;  // SAMGRAPH_HANDOFF_CHECK: result word of the verification kernel
+    // one-launch extraction: per-workgroup start / end clocks (pinned host memory), workgroups of the launch and of
+    // its link band
+    unsigned long long *h_stamps = nullptr;
+    size_t stamp_cap = 0, stamp_grid = 0, stamp_link = 0;
   };
   ExtractCtx xctx_[kExtractDepth];
   // where the extraction thread's time goes (reported at shutdown, log level info)

@@ -715,6 +715,33 @@ bool gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t di
 int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,
                    const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask, void *stream,
                    const GatherTail *tail, size_t host_grid = 0, size_t wg_per_cu = 0);
+// The trainer-side extraction of one batch as ONE launch (extract_fused_kernel, cache_gather.hip): CombineMissData with
+// the host row fetch fused in + CombineCacheData + the label rows + the summary copy + (engine) the word copies that
+// take a message's arrays out of its queue slot.  link_wgs > 0: the first link_wgs workgroups pull the miss rows (their
+// source is host memory behind the host link) while the others stream the hit rows from the HBM cache; 0: every
+// workgroup takes its share of both lists (miss source in HBM).
+struct ExtractJob {
+  void *out;
+  const void *miss_rows, *cache_rows;              // full table (indexed by miss_src & miss_mask) / cache (by cache_src)
+  const uint32_t *miss_src, *miss_dst, *cache_src, *cache_dst;
+  size_t num_miss, num_cache;                      // host counts, used when d_counts == null
+  const uint32_t *d_counts;                        // device: {num_miss, num_cache}
+  size_t cap;                                      // capacity of either list under device counts
+  size_t dim;
+  int dtype;
+  uint32_t miss_mask;
+  GatherTail tail;
+  const fgnn_copy_segment *segs;                   // host array of word copies (null: none)
+  int num_segs;
+  size_t link_wgs;                                 // workgroups of the link band (0: no band)
+  size_t wg_per_cu;                                // persistent workgroups per CU of the HBM band (0: default 4)
+  unsigned long long *stamps;                      // null, or u64[2 * grid]: every workgroup's start / end wall clock
+};
+// can the batch take the one-launch path (16-byte row chunks, 32-bit chunk index)?
+bool extract_can_fuse(const ExtractJob &j);
+int extract_fused(const ExtractJob &j, void *stream, size_t *grid_out = nullptr);
+size_t extract_fused_grid(const ExtractJob &j, size_t *link = nullptr);  // workgroups of that launch (of its link band)
+bool pointer_is_host(const void *p);             // host memory the GPU reads over the host link?
 // workgroups of a host-source gather on a GPU that also runs the sampling chain (see gather_rows_ex)
 constexpr size_t kSharedGpuHostGrid = 64;
 // persistent workgroups per CU of the batch driver's HBM feature gather (the stateless entry points keep 4, which is

@@ -11,11 +11,23 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FGNN_HIP_LIB: another build of the library -- tools/ use lib/libfgnn_hip_prof.so (`make -C csrc prof`), the only build
-# whose kernels read A/B switches and ablation masks from the environment
-LIB_PATH = os.environ.get("FGNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip.so")
+# The product library.  Nothing in the environment changes which file is loaded: the measurement tools under tools/ that
+# want the profiling build (lib/libfgnn_hip_prof.so, `make -C csrc prof`: the only build whose kernels read A/B switches
+# and ablation masks) say so in their own code, with use_library(path), before anything calls load()
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip.so")
+PROF_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfgnn_hip_prof.so")
+
+
+def use_library(path):
+    """tools/ only: bind another build of the kernel library (before the first call of load())."""
+    global LIB_PATH
+    if _lib is not None:
+        raise FgnnError("use_library() after the kernel library has been loaded")
+    LIB_PATH = os.path.abspath(path)
+
 
 SRC_GLOBAL, SRC_LOCAL = 0, 1
+LINK_WGS_SHARED, LINK_WGS_DEDICATED = 16, 16  # FGNN_LINK_WGS_* (fgnn_hip.h)
 EMPTY = 0xFFFFFFFF
 F32, F64, F16, U8, I32, I8, I64 = range(7)
 _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8: U8, torch.int32: I32,
@@ -31,7 +43,7 @@ EXPORTS = [
     "fgnn_hashtable_d_num_items", "fgnn_hashtable_set_n2o", "fgnn_hashtable_start_batch",
     "fgnn_extract_neighbour_scratch_bytes", "fgnn_extract_neighbour", "fgnn_neighbourhood_expand",
     "fgnn_presample_count", "fgnn_presample_rank_scratch_bytes", "fgnn_presample_rank", "fgnn_cache_table_build",
-    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_gather_rows_shared", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
+    "fgnn_cache_table_replace", "fgnn_get_miss_cache_index", "fgnn_gather_rows", "fgnn_gather_rows_masked", "fgnn_gather_rows_shared", "fgnn_extract_fused", "fgnn_extract_fused_grid", "fgnn_extract_fused_link_grid", "fgnn_block_aggregate", "fgnn_block_aggregate_ex", "fgnn_batch_set_feat_row_mask",
     "fgnn_sage_finish_z", "fgnn_sage_grad_prep", "fgnn_relu_dropout", "fgnn_relu_dropout_backward",
     "fgnn_softmax_xent_scratch_bytes", "fgnn_softmax_xent", "fgnn_adam_step",
 ]
@@ -434,6 +446,63 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_
     return out
 
 
+class CopySegment(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("words", C.c_size_t)]
+
+
+class ExtractJob(C.Structure):
+    """fgnn_extract_job (include/fgnn_hip.h)"""
+    _fields_ = [("out", C.c_void_p), ("miss_rows", C.c_void_p), ("cache_rows", C.c_void_p),
+                ("miss_src", C.c_void_p), ("miss_dst", C.c_void_p), ("cache_src", C.c_void_p), ("cache_dst", C.c_void_p),
+                ("num_miss", C.c_size_t), ("num_cache", C.c_size_t), ("d_counts", C.c_void_p), ("cap", C.c_size_t),
+                ("dim", C.c_size_t), ("dtype", C.c_int), ("miss_row_mask", C.c_uint32),
+                ("label_out", C.c_void_p), ("label_src", C.c_void_p), ("label_index", C.c_void_p),
+                ("num_label", C.c_size_t), ("label_dtype", C.c_int),
+                ("segs", C.POINTER(CopySegment)), ("num_segs", C.c_int), ("link_workgroups", C.c_int),
+                ("stamps", C.c_void_p)]
+
+
+def _raw(t):
+    """device-visible address of a tensor, a DevicePointer or None (C.c_void_p field value)"""
+    p = _ptr(t)
+    return p.value if isinstance(p, C.c_void_p) else p
+
+
+def extract_fused(out, miss_rows, cache_rows, miss_src, miss_dst, cache_src, cache_dst, num_miss=None, num_cache=None,
+                  d_counts=None, miss_row_mask=0xFFFFFFFF, label_out=None, label_src=None, label_index=None,
+                  copies=(), link_workgroups=0, stamps=None):
+    """fgnn_extract_fused: out[miss_dst] = miss_rows[miss_src & mask], out[cache_dst] = cache_rows[cache_src], the label
+    rows and the word copies `copies` = [(dst, src, words)] in ONE launch.  Counts: host values (default: the index
+    lists' lengths) or d_counts = device {num_miss, num_cache}.  Returns (workgroups, link-band workgroups)."""
+    _need_gpu(out)
+    dim = 1
+    for s in out.shape[1:]:
+        dim *= s
+    j = ExtractJob()
+    j.out, j.miss_rows, j.cache_rows = _raw(out), _raw(miss_rows), _raw(cache_rows)
+    j.miss_src, j.miss_dst, j.cache_src, j.cache_dst = _raw(miss_src), _raw(miss_dst), _raw(cache_src), _raw(cache_dst)
+    j.num_miss = (miss_src.numel() if miss_src is not None else 0) if num_miss is None else num_miss
+    j.num_cache = (cache_src.numel() if cache_src is not None else 0) if num_cache is None else num_cache
+    if d_counts is not None:
+        j.d_counts = _raw(d_counts)
+        j.cap = max(miss_src.numel() if miss_src is not None else 0, cache_src.numel() if cache_src is not None else 0)
+    j.dim, j.dtype, j.miss_row_mask = dim, _T2DT[out.dtype], miss_row_mask
+    if label_out is not None:
+        j.label_out, j.label_src, j.label_index = _raw(label_out), _raw(label_src), _raw(label_index)
+        j.num_label, j.label_dtype = label_index.numel(), _T2DT[label_out.dtype]
+    segs = (CopySegment * max(len(copies), 1))()
+    for k, (d, s, words) in enumerate(copies):
+        segs[k].dst, segs[k].src, segs[k].words = _raw(d), _raw(s), words
+    j.segs, j.num_segs = segs, len(copies)
+    j.link_workgroups = link_workgroups
+    j.stamps = _raw(stamps)
+    L = load()
+    L.fgnn_extract_fused_grid.restype = C.c_size_t
+    L.fgnn_extract_fused_link_grid.restype = C.c_size_t
+    _check(L.fgnn_extract_fused(C.byref(j), _stream()), "fgnn_extract_fused")
+    return int(L.fgnn_extract_fused_grid(C.byref(j))), int(L.fgnn_extract_fused_link_grid(C.byref(j)))
+
+
 # ---------------------------------------------------------------------------------------------------
 # batch driver (fgnn_sampler / fgnn_batch)
 
@@ -444,7 +513,7 @@ EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
     "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_sampler_sample_ordered",
     "fgnn_sampler_run_batch", "fgnn_batch_enable_timing", "fgnn_batch_gather_ms", "fgnn_batch_cache_index", "fgnn_batch_extract",
-    "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
+    "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_extract_launch_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta", "fgnn_batch_host_meta", "fgnn_batch_meta_copied",
     "fgnn_sampler_run_range", "fgnn_sampler_sample_indexed", "fgnn_sampler_prefix_tree_stats",
@@ -689,6 +758,11 @@ class Batch:
         out = (C.c_float * 2)()
         _check(load().fgnn_batch_extract_cached_ms(self.h, out), "fgnn_batch_extract_cached_ms")
         return float(out[0]), float(out[1])
+
+    def extract_launch_ms(self):
+        """HIP-event time around the whole one-launch cached extraction (-1 when not timed)"""
+        load().fgnn_batch_extract_launch_ms.restype = C.c_float
+        return float(load().fgnn_batch_extract_launch_ms(self.h))
 
     def d_num_input(self):
         """device view (int32[1]) of the batch summary's num_input"""

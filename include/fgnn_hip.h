@@ -256,6 +256,59 @@ int fgnn_gather_rows_shared(void *out, const void *src, const uint32_t *src_inde
                             const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
                             int shared_gpu, void *stream);
 
+/* The trainer-side feature extraction of one batch as ONE launch: ExtractMissData's row fetch
+ * (cuda_cache_manager_host.cc:38-56) + CombineMissData + CombineCacheData (cuda_cache_manager_device.cu:165-210,339-442)
+ * + the label rows (DoCPULabelExtractAndCopy, dist_loops.cc:886-929) + the copies that take a received message's arrays
+ * out of its queue slot (ParseData, task_queue.cc:257-347):
+ *   out[miss_dst[i], :]  = miss_rows[miss_src[i] & miss_row_mask, :]   i < num_miss
+ *   out[cache_dst[i], :] = cache_rows[cache_src[i], :]                 i < num_cache
+ *   label_out[i]         = label_src[label_index[i]]                   i < num_label   (label_out NULL: none)
+ *   segs[k].dst[0:words] = segs[k].src[0:words]                        k < num_segs    (32-bit words)
+ * link_workgroups > 0: miss_rows is host memory the GPU reads over the host link; that many workgroups (the "link
+ * band") pull the miss rows while the rest of the grid streams the hit rows out of the HBM cache -- the link never
+ * waits behind the HBM gather and the HBM gather never waits behind the link.  0: miss_rows is in HBM too, every
+ * workgroup takes its share of both lists.  Counts are host values, or d_counts = {num_miss, num_cache} on the device
+ * with `cap` the capacity of either list.  Rows must be a multiple of 16 bytes and 16-byte aligned (FGNN_EINVAL
+ * otherwise: use fgnn_gather_rows per list); num_segs <= FGNN_MAX_COPY_SEGMENTS.
+ * stamps: NULL, or u64[2 * fgnn_extract_fused_grid()] receiving every workgroup's start and end time (100 MHz wall
+ * clock; workgroups [0, link_workgroups) are the link band): per-band durations of one launch. */
+typedef struct {
+  uint32_t *dst;
+  const uint32_t *src;
+  size_t words;
+} fgnn_copy_segment;
+#define FGNN_MAX_COPY_SEGMENTS 32
+typedef struct {
+  void *out;
+  const void *miss_rows, *cache_rows;
+  const uint32_t *miss_src, *miss_dst, *cache_src, *cache_dst;
+  size_t num_miss, num_cache;
+  const uint32_t *d_counts;
+  size_t cap;
+  size_t dim;
+  int dtype;
+  uint32_t miss_row_mask;
+  void *label_out;
+  const void *label_src;
+  const uint32_t *label_index;
+  size_t num_label;
+  int label_dtype;
+  const fgnn_copy_segment *segs;
+  int num_segs;
+  int link_workgroups;
+  unsigned long long *stamps;
+} fgnn_extract_job;
+int fgnn_extract_fused(const fgnn_extract_job *job, void *stream);
+/* workgroups the launch of `job` would use (the size of `stamps` / 2; 0: the job cannot take this path), and how many
+ * of them form the link band (<= link_workgroups: a short miss list needs fewer) */
+size_t fgnn_extract_fused_grid(const fgnn_extract_job *job);
+size_t fgnn_extract_fused_link_grid(const fgnn_extract_job *job);
+/* link_workgroups for a GPU that also runs the sampling chain / for a GPU that only extracts (an arch5 trainer).  Small
+ * on purpose: 16 workgroups keep 256 KB of host reads in flight, twice what the link needs at its latency; more of them
+ * only sit in the memory pipeline in front of every other access (56 GB/s with 16, 49 with 256: profiles/r06_a_*). */
+#define FGNN_LINK_WGS_SHARED 16
+#define FGNN_LINK_WGS_DEDICATED 16
+
 /* ---- neighbourhood aggregation over a sampled block (consumer side of the path) ----------- */
 
 /* out[dst_index[e], :] += edge_weight[e] * h[src_index[e], :]  for e < num_edge (edge_weight NULL = 1), fp32.
@@ -447,9 +500,12 @@ int fgnn_batch_extract_cached(fgnn_batch *b, const void *cache_rows, const void 
 int fgnn_sampler_run_batch_cached(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                                   uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table,
                                   const void *cache_rows, const void *full_feat, const void *label, void *stream);
-/* with fgnn_batch_enable_timing: out[0] = ms of the miss-row gather, out[1] = ms of the cached-row gather of the last
- * fgnn_batch_extract_cached (valid after fgnn_batch_wait; -1 when not bracketed) */
+/* with fgnn_batch_enable_timing: out[0] = ms of the miss rows, out[1] = ms of the cached rows of the last
+ * fgnn_batch_extract_cached (valid after fgnn_batch_wait; -1 when not bracketed).  The extraction is ONE launch: the two
+ * figures are the durations of its link band and of its HBM band (first start .. last end over the band's workgroups,
+ * device wall clock); fgnn_batch_extract_launch_ms is the HIP-event time around the whole launch. */
 int fgnn_batch_extract_cached_ms(fgnn_batch *b, float out[2]);
+float fgnn_batch_extract_launch_ms(fgnn_batch *b);
 /* Optional HIP-event bracket around the feature gather launched by fgnn_batch_extract (on its stream);
  * fgnn_batch_gather_ms returns the elapsed time of the last bracketed launch after fgnn_batch_wait, or -1. */
 int fgnn_batch_enable_timing(fgnn_batch *b, int on);

@@ -11,8 +11,18 @@ for p in (os.path.join(ROOT, "fgnn-artifacts_amd"), os.path.join(ROOT, "oracle")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--kernel-lib", default=None,
+                     help="tools/ab_variants.sh only: run the suite against another build of the kernel library "
+                          "('prof' = lib/libfgnn_hip_prof.so); the product binding reads nothing from the environment")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    which = config.getoption("--kernel-lib")
+    if which:
+        from fgnn_hip import lib
+        lib.use_library(lib.PROF_LIB_PATH if which == "prof" else which)
 
 
 @pytest.fixture(scope="session")

@@ -264,6 +264,84 @@ def test_gather_from_pinned_host_rows_with_the_shared_gpu_hint(hip, oracle, shar
         assert got.cpu().numpy().tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("dim,dtype", [(128, np.float32), (100, np.float32), (256, np.float32), (24, np.float16),
+                                       (4, np.float32), (2, np.float64)])
+@pytest.mark.parametrize("host_source,link", [(True, 64), (True, 3), (False, 0), (True, 0)])
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_fused_extraction_matches_oracle(hip, oracle, dim, dtype, host_source, link, device_counts):
+    """fgnn_extract_fused: ExtractMissData's fetch + CombineMissData + CombineCacheData
+    (cuda_cache_manager_device.cu:165-210,339-442) + the label rows + the word copies out of a message slot, ONE launch
+    -- against the oracle's split and extraction: miss rows from pinned host memory through a link band of `link`
+    workgroups (0: no band), or from HBM; host counts or device counts; masked miss ids (SAMGRAPH_EMPTY_FEAT)."""
+    rs = np.random.default_rng(11)
+    n_node, n_tab, n = 1 << 15, 1 << 12, 23117
+    src = (rs.standard_normal((n_tab, dim)) * 100).astype(dtype)          # the (masked) feature table
+    rank = rs.permutation(n_node).astype(np.uint32)
+    n_cached = n_node // 5
+    table = oracle.cache_table_build(rank, n_cached, n_node)
+    nodes = rs.permutation(n_node)[:n].astype(np.uint32)
+    ms, md, cs, cd = oracle.get_miss_cache_index(table, nodes)
+    cache_rows = oracle.extract(src, rank[:n_cached] & (n_tab - 1))         # the trainer's cache: feat[rank[i] & mask]
+    want = oracle.extract(src, nodes & (n_tab - 1))
+    label = rs.integers(0, 1000, size=n_node).astype(np.int64)
+    seeds = nodes[:997]
+    # arrays of a "message slot" at odd word offsets, copied out by the same launch
+    slot = rs.integers(0, 1 << 32, size=60000, dtype=np.uint64).astype(np.uint32)
+    d_slot = dev(slot)
+    pieces = [(3, 997), (1001, 1), (1003, 33333), (40001, 0), (40001, 7777)]
+    keeps = [torch.zeros(max(w, 1), dtype=torch.int32, device="cuda") for _, w in pieces]
+    copies = [(k, hip.DevicePointer(d_slot.data_ptr() + 4 * off), w) for k, (off, w) in zip(keeps, pieces)]
+    t_dtype = torch.from_numpy(src).dtype
+    miss_rows = torch.from_numpy(src).pin_memory() if host_source else dev(src)
+    out = torch.zeros((n, dim), dtype=t_dtype, device="cuda")
+    lab = torch.zeros(len(seeds), dtype=torch.int64, device="cuda")
+    pad = 100  # lists longer than the counts under device counts: the tail must not be touched
+    d = [dev(np.concatenate([a, np.full(pad, 0x7FFFFFF0, np.uint32)])) if device_counts else dev(a) for a in (ms, md, cs, cd)]
+    kw = dict(d_counts=dev(np.array([len(ms), len(cs)], np.uint32))) if device_counts else \
+        dict(num_miss=len(ms), num_cache=len(cs))
+    grid, band = hip.extract_fused(out, miss_rows, dev(cache_rows), d[0], d[1], d[2], d[3], miss_row_mask=n_tab - 1,
+                                   label_out=lab, label_src=dev(label), label_index=dev(seeds), copies=copies,
+                                   link_workgroups=link, **kw)
+    torch.cuda.synchronize()
+    assert grid > band and (band > 0) == (link > 0)
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+    np.testing.assert_array_equal(lab.cpu().numpy(), label[seeds])
+    for k, (off, w) in zip(keeps, pieces):
+        np.testing.assert_array_equal(host_u32(k, w), slot[off:off + w])
+
+
+def test_fused_extraction_edge_cases(hip, oracle):
+    """all hits / all misses / nothing at all / labels only; rows that are not whole 16-byte chunks are refused (the
+    callers then take one launch per list)"""
+    rs = np.random.default_rng(12)
+    n_tab, dim = 4096, 64
+    src = rs.standard_normal((n_tab, dim)).astype(np.float32)
+    cache = rs.standard_normal((512, dim)).astype(np.float32)
+    host = torch.from_numpy(src).pin_memory()
+    for n_miss, n_cache in ((0, 3000), (3000, 0), (0, 0), (1, 1)):
+        n = n_miss + n_cache
+        dst = rs.permutation(max(n, 1))[:n].astype(np.uint32)
+        msrc = rs.integers(0, n_tab, size=n_miss).astype(np.uint32)
+        csrc = rs.integers(0, 512, size=n_cache).astype(np.uint32)
+        want = np.zeros((max(n, 1), dim), np.float32)
+        want[dst[:n_miss]] = src[msrc]
+        want[dst[n_miss:]] = cache[csrc]
+        out = torch.zeros((max(n, 1), dim), dtype=torch.float32, device="cuda")
+        lab = torch.zeros(5, dtype=torch.int64, device="cuda")
+        hip.extract_fused(out, host, dev(cache), dev(msrc) if n_miss else None, dev(dst[:n_miss]) if n_miss else None,
+                          dev(csrc) if n_cache else None, dev(dst[n_miss:]) if n_cache else None, link_workgroups=64,
+                          label_out=lab, label_src=dev(np.arange(100, dtype=np.int64) * 3),
+                          label_index=dev(np.array([5, 0, 99, 7, 7], np.uint32)))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == want.tobytes()
+        assert lab.cpu().tolist() == [15, 0, 297, 21, 21]
+    odd = torch.zeros((10, 7), dtype=torch.float32, device="cuda")
+    with pytest.raises(hip.FgnnError):
+        hip.extract_fused(odd, dev(np.zeros((4, 7), np.float32)), dev(np.zeros((4, 7), np.float32)),
+                          dev(np.zeros(2, np.uint32)), dev(np.zeros(2, np.uint32)), dev(np.zeros(2, np.uint32)),
+                          dev(np.ones(2, np.uint32)))
+
+
 @pytest.mark.parametrize("kind,fanouts,batch", [("khop2", [25, 10], 2000), ("khop0", [5, 10, 15], 300),
                                                 ("khop2", [10, 5], 1)])
 def test_layered_pipeline_matches_oracle(hip, oracle, kind, fanouts, batch):

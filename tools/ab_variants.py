@@ -20,9 +20,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("FGNN_HIP_LIB", os.path.join(ROOT, "fgnn-artifacts_amd", "lib", "libfgnn_hip_prof.so"))
 import bench  # noqa: E402
 from fgnn_hip import lib  # noqa: E402
+
+lib.use_library(lib.PROF_LIB_PATH)  # the build whose kernels read the FGNN_* switches
 
 
 def main():

@@ -9,7 +9,7 @@ for v in "${VS[@]}"; do
   case "$v" in *UNORDERED*|*ABLATE*|*GATHER*) continue;; esac
   envs=$(echo "$v" | tr ',' ' ')
   log=gpurun_out/$tag/pytest_$(echo $v | tr '=,' '__').log
-  env FGNN_HIP_LIB=$GRAFT_REPO_ROOT/fgnn-artifacts_amd/lib/libfgnn_hip_prof.so $envs timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_coresidency_gpu.py -m gpu -x -q -k "driver or pipeline or coresid or stream" > $log 2>&1
+  env $envs timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_coresidency_gpu.py -m gpu -x -q --kernel-lib prof -k "driver or pipeline or coresid or stream" > $log 2>&1
   rc=$?; echo "parity [$v] rc=$rc $(tail -1 $log)"
   [ $rc -ne 0 ] && { tail -30 $log; exit $rc; }
 done

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "fgnn-artifacts_amd"))
 sys.path.insert(0, ROOT)
 from fgnn_hip import lib  # noqa: E402
 
-lib.LIB_PATH = os.path.abspath(sys.argv[1])
+lib.use_library(sys.argv[1])
 sys.argv = ["bench.py"] + sys.argv[2:]
 import bench  # noqa: E402
 

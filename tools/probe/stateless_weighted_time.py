@@ -14,7 +14,7 @@ import torch
 from fgnn_hip import lib, synth
 
 if len(sys.argv) > 1:
-    lib.LIB_PATH = os.path.abspath(sys.argv[1])
+    lib.use_library(sys.argv[1])
 
 
 def main():
