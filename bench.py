@@ -1185,6 +1185,144 @@ def default_samplers(n_gpus):
     return max(1, n_gpus // 4)
 
 
+def choose_samplers(world, t_sampler_ms, t_trainer_ms):
+    """S of 1 .. world-1 minimising the pipeline's time per batch max(t_s / S, t_t / (world - S)) for the measured
+    per-process rates (a sampler process alone, a trainer process alone); ties go to fewer samplers.  The reference
+    tunes S per workload by hand (exp/table4/README.md:79-90: 4S / 2S / 2S / 1S).  Returns (S, {S: predicted ms})."""
+    pred = {s: max(t_sampler_ms / s, t_trainer_ms / (world - s)) for s in range(1, world)}
+    best = min(pred, key=lambda s: (pred[s], s))
+    return best, pred
+
+
+class _FileBarrier:
+    """barrier between processes that share nothing but a directory"""
+
+    def __init__(self, d, me, n):
+        self.dir, self.me, self.n, self.round = d, me, n, 0
+
+    def wait(self, limit=600.0):
+        tag = "cal%d." % self.round
+        self.round += 1
+        open(os.path.join(self.dir, tag + self.me), "w").close()
+        t0 = time.time()
+        while len([f for f in os.listdir(self.dir) if f.startswith(tag)]) < self.n:
+            if time.time() - t0 > limit:
+                raise RuntimeError("calibration barrier %s: only %s arrived" % (tag, sorted(os.listdir(self.dir))))
+            time.sleep(0.002)
+
+
+def run_calibrate_child():
+    """--samplers auto: one role of a 1S+1T arch5 job of its own (named regions, the job's dataset) in a child process
+    that rank 0 (sampler) / rank 1 (trainer) started before touching the GPU.  The sampler child fills the queue
+    ALONE (nobody consumes: warm + K batches, fewer than the queue has slots), then the trainer child drains it ALONE
+    -- each stage's own time per batch, the --decoupled measurement in miniature.  Request: one JSON line on stdin
+    (an empty line: not needed); answer: one JSON line on stdout."""
+    line = sys.stdin.readline()
+    if not line.strip():
+        return
+    req = json.loads(line)
+    for k, v in req["env"].items():
+        os.environ[k] = v
+    import samgraph.torch as sam
+    torch.cuda.set_device(req["dev_id"])
+    ctx = "cuda:%d" % req["dev_id"]
+    warm, K = req["warm"], req["steps"]
+    spe = req["steps_per_epoch"]
+    cfg = dict(dataset_path=req["dir"], _arch=sam.kArch5, _sample_type=sam.sample_types[req["sample_type"]],
+               batch_size=req["batch_size"], num_epoch=(warm + K + spe - 1) // spe + 1,
+               _cache_policy=sam.cache_policies["pre_sample"], presample_epoch=req["presample_epochs"],
+               cache_percentage=req["cache_ratio"], max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8,
+               num_sample_worker=1, num_train_worker=1, num_fanout=len(req["fanout"]), fanout=req["fanout"],
+               seed=req["seed"])
+    sam.config(cfg)
+    sam.data_init()
+    bar = _FileBarrier(req["sync_dir"], req["role"], 2)
+    bar.wait()  # both children have attached to every region
+    now = lambda: time.clock_gettime(time.CLOCK_MONOTONIC)  # noqa: E731
+    if req["role"] == "s":
+        sam.sample_init(0, ctx)  # pre-samples: the ranking the trainer's cache is built from
+        bar.wait()
+        bar.wait()  # the trainer has built its cache
+        for _ in range(warm):
+            sam.sample_once()
+        sam.get_log_step_value((warm - 1) // spe, (warm - 1) % spe, sam.kLogL1NumSample)  # everything so far published
+        with no_gc():
+            t0 = now()
+            for _ in range(K):
+                sam.sample_once()
+            last = warm + K - 1
+            sam.get_log_step_value(last // spe, last % spe, sam.kLogL1NumSample)  # ... the K timed ones too
+            ms = (now() - t0) / K * 1e3
+        bar.wait()  # the queue holds warm + K batches
+        bar.wait()  # drained
+    else:
+        bar.wait()
+        sam.train_init(0, ctx)
+        bar.wait()
+        bar.wait()
+        sam.extract_start(warm + K)
+        for _ in range(warm):
+            sam.get_next_batch()
+        with no_gc():
+            t0 = now()
+            for _ in range(K):
+                sam.get_next_batch()
+            ms = (now() - t0) / K * 1e3
+        bar.wait()
+    print(json.dumps({"role": req["role"], "ms_per_batch": ms, "steps": K, "warm": warm}), flush=True)
+    sam.shutdown()
+
+
+def calibrate_roles(args, w, dist, rank, world, dev_id, job, steps_per_epoch, cal_child, warm=16, steps=96):
+    """collective over the job's ranks: ranks 0 and 1 drive their calibration children (run_calibrate_child), rank 0
+    chooses S from the two measured rates and every rank learns it.  A calibration that fails costs the choice, not the
+    job: the reference's split is used and the line says why.  --rehearse: no GPU, the rates are --rehearse-rates."""
+    mine = None
+    if args.rehearse:
+        rates = [float(x) for x in args.rehearse_rates.split(",")]
+        mine = {"role": "s" if rank == 0 else "t", "ms_per_batch": rates[0] if rank == 0 else rates[1]} if rank < 2 else None
+    elif cal_child is not None:
+        sync = os.path.join(job["dir"], "calibration_sync")
+        os.makedirs(sync, exist_ok=True)
+        req = {"env": {"SAMGRAPH_SHM_PREFIX": job["prefix"] + "_cal", "SAMGRAPH_SHM_KEEP": "1",
+                       "SAMGRAPH_EMPTY_FEAT": str(args.empty_feat_bits),
+                       "SAMGRAPH_LOG_LEVEL": os.environ.get("SAMGRAPH_LOG_LEVEL", "warn")},
+               "role": "s" if rank == 0 else "t", "dev_id": dev_id, "dir": job["dir"], "sync_dir": sync, "warm": warm,
+               "steps": steps, "steps_per_epoch": steps_per_epoch, "sample_type": args.sample_type,
+               "batch_size": w["batch_size"], "cache_ratio": args.cache_ratio,
+               "presample_epochs": max(1, args.presample_epochs), "fanout": w["fanout"], "seed": args.seed}
+        try:
+            o, _ = cal_child.communicate((json.dumps(req) + "\n").encode(),
+                                         timeout=float(os.environ.get("FGNN_BENCH_CAL_TIMEOUT", "600")))
+            lines = [ln for ln in o.decode(errors="replace").splitlines() if ln.startswith("{")]
+            mine = json.loads(lines[-1]) if lines else {"error": "calibration child: rc %s" % cal_child.returncode}
+        except Exception as e:
+            cal_child.kill()
+            mine = {"error": "%s: %s" % (type(e).__name__, e)}
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    if rank == 0 and not args.rehearse and os.path.isdir("/dev/shm"):
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(job["prefix"] + "_cal"):
+                try:
+                    os.unlink(os.path.join("/dev/shm", f))
+                except OSError:
+                    pass
+    ts = next((g["ms_per_batch"] for g in got if g and g.get("role") == "s" and "ms_per_batch" in g), None)
+    tt = next((g["ms_per_batch"] for g in got if g and g.get("role") == "t" and "ms_per_batch" in g), None)
+    ref = default_samplers(world)
+    if ts is None or tt is None:  # (every rank sees the same list: the same decision everywhere)
+        return ref, {"mode": "auto: calibration failed, the reference's split is used", "reference_split": ref,
+                     "errors": [g.get("error") for g in got if g and "error" in g]}
+    S, pred = choose_samplers(world, ts, tt)
+    return S, {"mode": "auto", "sampler_ms_per_batch_alone": ts, "trainer_ms_per_batch_alone": tt,
+               "predicted_ms_per_batch_by_samplers": {str(k): v for k, v in pred.items()}, "chosen": S,
+               "reference_split": ref, "batches_timed": steps,
+               "note": "a sampler process alone (queue filling, nobody consuming) and a trainer process alone (draining "
+                       "it) as a 1S+1T job of their own before the roles are given out; S = argmin max(t_s / S, "
+                       "t_t / (N - S)); --samplers <n> overrides"}
+
+
 def split_count(total, parts, index):
     """how many of `total` units part `index` of `parts` takes (the trainers' share, multi_gpu/train_graphsage.py:293-298)"""
     return total // parts + (1 if index < total % parts else 0)
@@ -1234,7 +1372,8 @@ def read_windows(stamps, lead, windows, steps):
 
 
 def pipeline_roles(world, samplers=None):
-    s = samplers if samplers else default_samplers(world)
+    """(samplers, trainers); samplers: a count, or None / 0 / "auto" before the choice is made = the reference's split"""
+    s = int(samplers) if samplers and samplers != "auto" else default_samplers(world)
     if not (0 < s < world):
         raise ValueError("need at least one sampler and one trainer: %d samplers of %d ranks" % (s, world))
     return s, world - s
@@ -1390,9 +1529,6 @@ def run_pipeline_rank(args, rank, world):
         faulthandler.dump_traceback_later(float(os.environ["FGNN_BENCH_WATCHDOG"]), exit=True)
     import torch.distributed as dist
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
-    S, T = pipeline_roles(world, args.samplers)
-    is_sampler = rank < S
-    idx = rank if is_sampler else rank - S
     n_dev = torch.cuda.device_count()
     if n_dev == 0 and not args.rehearse:
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -1400,15 +1536,24 @@ def run_pipeline_rank(args, rank, world):
     dev_id = local_rank % max(n_dev, 1)  # more ranks than GPUs (a functional check on one GPU): they share
     n1_child = None
     exit_msg = None
+    child_env = {k: v for k, v in os.environ.items()
+                 if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                              "TORCHELASTIC_RUN_ID", "FGNN_BENCH_CHILD")}
     if rank == 0 and not (args.rehearse or args.no_n1_point or args.decoupled):
         # started now, before this process touches the GPU; it sleeps on its stdin until the spans are done
-        env = {k: v for k, v in os.environ.items()
-               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
-                            "TORCHELASTIC_RUN_ID", "FGNN_BENCH_CHILD")}
         # FGNN_BENCH_N1_WRAP (tools): a profiler in front of the child, e.g. "rocprofv3 --kernel-trace --stats -d DIR --"
         wrap = os.environ.get("FGNN_BENCH_N1_WRAP", "").split()
-        n1_child = subprocess.Popen(wrap + [sys.executable, os.path.abspath(__file__), "--n1-point-child"], env=env,
+        n1_child = subprocess.Popen(wrap + [sys.executable, os.path.abspath(__file__), "--n1-point-child"], env=child_env,
                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    # --samplers auto (the default): how many of the ranks sample is chosen from MEASURED rates -- a sampler process
+    # alone and a trainer process alone, a few dozen batches each, in two child processes of ranks 0 and 1 (a 1S+1T job
+    # of their own over the job's dataset; started now, before anything here touches the GPU).  Two ranks leave no choice
+    auto = str(args.samplers).lower() in ("auto", "0", "none")
+    calibrate = auto and world >= 3 and not args.decoupled
+    cal_child = None
+    if calibrate and not args.rehearse and rank in (0, 1):
+        cal_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--calibrate-child"], env=child_env,
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE)
     w = WORKLOADS[args.workload]
     if args.num_walks and "num_walks" in w:
         w = dict(w, num_walks=args.num_walks)
@@ -1416,18 +1561,7 @@ def run_pipeline_rank(args, rank, world):
         args.sample_type = w["sample_type"]
     bs = w["batch_size"]
     W, K = args.warmup, args.steps
-    # Steady-state timing (no barrier inside the measured span): one SPAN of lead + R x K + tail batches goes through the
-    # pipeline with the samplers free-running (bounded by the ring) and every trainer stamping CLOCK_MONOTONIC -- one
-    # node, one clock for all ranks -- when a batch has been consumed; rank 0 merges the stamps and reads R back-to-back
-    # windows of K consecutively consumed batches out of the middle.  `lead` covers the pipeline's fill (first message =
-    # one sample chain + one extract) and the warm-up, `tail` the drain (trainers finishing their shares at slightly
-    # different times).  The reference times the same loop per epoch (multi_gpu/train_graphsage.py:286-330).
-    R = 1 if args.decoupled else max(1, args.windows)
-    T_ = pipeline_roles(world, args.samplers)[1]
-    lead, tail = span_margins(W, T_, args.decoupled)
-    K2 = 0 if (args.no_train_leg or args.rehearse) else train_region_batches(K, args.train_steps, T_)[1]
-    total1 = span_total(lead, R, K, tail, T_, False)
-    total2 = span_total(lead, R, K2, tail, T_, True) if K2 else 0
+    steps_per_epoch = (w["num_train"] + bs - 1) // bs
     # ---- job-wide names from rank 0: shared-memory prefix (the processes have no common forking parent) and the
     # dataset directory
     obj = [None]
@@ -1452,8 +1586,30 @@ def run_pipeline_rank(args, rank, world):
             ne, desc = write_dataset(args, w, torch.device("cuda", dev_id), job["dir"])
             info[0] = {"num_edge": ne, "graph": desc}
     dist.broadcast_object_list(info, 0)
+    # ---- roles
+    sampler_choice = {"mode": "fixed (--samplers)" if not auto else "auto: two ranks leave no choice" if world < 3
+                      else "auto switched off by --decoupled (a per-stage diagnostic run)",
+                      "reference_split": default_samplers(world)}
+    S = pipeline_roles(world, None if auto else args.samplers)[0]
+    if calibrate:
+        S, sampler_choice = calibrate_roles(args, w, dist, rank, world, dev_id, job, steps_per_epoch, cal_child)
+        cal_child = None
+    T = world - S
+    is_sampler = rank < S
+    idx = rank if is_sampler else rank - S
+    # Steady-state timing (no barrier inside the measured span): one SPAN of lead + R x K + tail batches goes through the
+    # pipeline with the samplers free-running (bounded by the ring) and every trainer stamping CLOCK_MONOTONIC -- one
+    # node, one clock for all ranks -- when a batch has been consumed; rank 0 merges the stamps and reads R back-to-back
+    # windows of K consecutively consumed batches out of the middle.  `lead` covers the pipeline's fill (first message =
+    # one sample chain + one extract) and the warm-up, `tail` the drain (trainers finishing their shares at slightly
+    # different times).  The reference times the same loop per epoch (multi_gpu/train_graphsage.py:286-330).
+    R = 1 if args.decoupled else max(1, args.windows)
+    T_ = T
+    lead, tail = span_margins(W, T_, args.decoupled)
+    K2 = 0 if (args.no_train_leg or args.rehearse) else train_region_batches(K, args.train_steps, T_)[1]
+    total1 = span_total(lead, R, K, tail, T_, False)
+    total2 = span_total(lead, R, K2, tail, T_, True) if K2 else 0
     try:
-        steps_per_epoch = (w["num_train"] + bs - 1) // bs
         min_local = steps_per_epoch // S
         per_sampler = max(sum(split_count(n, S, 0) for n in (total1, total2)), 1)
         num_epoch = (per_sampler + min_local - 1) // min_local + 1
@@ -1695,16 +1851,18 @@ def run_pipeline_rank(args, rank, world):
                                        "in every trainer's HBM; arch5 through "
                                        "samgraph.torch / c_lib.so, one process per GPU",
                            "global_batch": bs, "parallelism": f"{S}S+{T}T (samplers -> device ring -> trainers)"},
-                "roofline": {"bound": "hbm", "kernel": "gather_rows16_kernel (CombineCacheData on the trainer GPUs)",
+                "roofline": {"bound": "hbm", "kernel": "extract_fused_kernel, HBM band (CombineCacheData on the trainer GPUs; the "
+                                                        "same launch's link band pulls the miss rows over the host link)",
                              "achieved": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 if ms_cache else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": cache_launch_bytes / (ms_cache * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cache else None,
                              "traffic": None, "avg_launch_ms": ms_cache / n_launch, "timed_launches": n_launch,
                              "algorithmic_bytes_per_launch": cache_launch_bytes / n_launch,
-                             "note": "hit rows x (row read + row write + 2 index words) / HIP-event time of the launch, "
+                             "note": "hit rows x (row read + row write + 2 index words) / the HBM band's first start .. "
+                                     "last end inside the one-launch extraction (device clock stamps of its workgroups), "
                                      "summed over the trainers' batches"},
                 "pipeline": {
-                    "samplers": S, "trainers": T, "devices": min(n_dev, world),
+                    "samplers": S, "trainers": T, "devices": min(n_dev, world), "sampler_choice": sampler_choice,
                     "sampler_loop_ms_per_batch": s_loop / max(split_count(total1, S, 0), 1) * 1e3,
                     "trainer_loop_ms_per_batch": t_loop / max(split_count(total1, T, 0), 1) * 1e3,
                     "loop_note": "wall time of a rank's whole span loop / its batches (MAX within the role): a sampler's "
@@ -1722,8 +1880,10 @@ def run_pipeline_rank(args, rank, world):
                     "miss": {"bound": "host link", "bytes_per_step": miss_rows * row_b / K,
                              "achieved": miss_rows * row_b / t_max / 1e9 / T, "peak": HOST_LINK_GBS,
                              "unit": "GB/s per trainer GPU", "frac": miss_rows * row_b / t_max / 1e9 / T / HOST_LINK_GBS,
-                             "avg_launch_ms": ms_miss / n_launch,
-                             "launch_GBps": miss_rows_a * row_b / (ms_miss * 1e-3) / 1e9 if ms_miss else None},
+                             "avg_band_ms": ms_miss / n_launch,
+                             "band_GBps": miss_rows_a * row_b / (ms_miss * 1e-3) / 1e9 if ms_miss else None,
+                             "note": "achieved = miss bytes / wall time per trainer; band = the link band of one launch "
+                                     "(up to four batches' bands share a trainer's link)"},
                 },
                 "epoch_time_s": {"sample_plus_extract": steps_per_epoch * t_max / K,
                                  "with_training": steps_per_epoch * t_train / K2 if K2 else None,
@@ -1995,7 +2155,13 @@ def parse_args(argv=None):
                     help="N=1: batch buffers per stream (the host enqueues that many batches ahead on each stream)")
     ap.add_argument("--stage-streams", type=int, default=2,
                     help="N=1: batch streams of the sample_stage measurement (0: all of --streams-per-thread)")
-    ap.add_argument("--samplers", type=int, default=0, help="N>=2: sampler processes (default: 1 below 8 GPUs, 2 at 8)")
+    ap.add_argument("--samplers", default="auto",
+                    help="N>=2: sampler processes; auto (default): chosen from the measured rates of one sampler process "
+                         "and one trainer process alone (calibrate_roles) -- the reference tunes it per workload by hand "
+                         "(exp/table4: 2 at 8 GPUs for this workload)")
+    ap.add_argument("--rehearse-rates", default="0.1,0.29",
+                    help="--rehearse with --samplers auto: the (sampler, trainer) ms per batch the choice is made from")
+    ap.add_argument("--calibrate-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-train-leg", action="store_true", help="skip the region with a training step per batch")
     ap.add_argument("--train-steps", type=int, default=40, help="N>=2: batches of the training region (<= --steps)")
     ap.add_argument("--decoupled", action="store_true",
@@ -2036,6 +2202,8 @@ def main():
         lib.use_library(lib.PROF_LIB_PATH if args.kernel_lib == "prof" else args.kernel_lib)
     if args.n1_point_child:
         return run_n1_point_child()
+    if args.calibrate_child:
+        return run_calibrate_child()
     if args.cpu_only:
         dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
         r = cpu_baseline_products(dev, budget_s=10.0)

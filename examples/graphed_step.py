@@ -78,8 +78,10 @@ class GraphedSageStep:
         less in the replayed graph."""
         n = min(self.batch_size, out.shape[0])
         lf = self.loss_fcn
+        # (the kernel ignores every row whose label is outside [0, C) -- torch's ignore_index semantics for the default
+        # -100 and any other negative value; an ignore_index that names a real class stays with torch)
         if (isinstance(lf, th.nn.CrossEntropyLoss) and lf.reduction == "mean" and lf.weight is None
-                and lf.label_smoothing == 0.0 and out.is_cuda and out.dtype == th.float32 and y.dtype == th.int64):
+                and lf.label_smoothing == 0.0 and lf.ignore_index < 0 and out.is_cuda and out.dtype == th.float32 and y.dtype == th.int64):
             try:
                 from fgnn_hip.nn import softmax_xent
             except ImportError:
@@ -144,8 +146,9 @@ class GraphedSageStep:
                       for l in range(L)]
             if getattr(self, "_ncls", None) and x_full.is_cuda:  # the padded gradient buffer of the fused loss: not inside
                 try:                                              # the capture
-                    from fgnn_hip.nn import xent_grad_buffer
+                    from fgnn_hip.nn import xent_grad_buffer, xent_scratch
                     xent_grad_buffer(x_full.device, db[L - 1] + 1, self._ncls)
+                    xent_scratch(x_full.device, min(self.batch_size, db[L - 1] + 1))  # (its zeroing must not be replayed)
                 except ImportError:
                     pass
             tuned = self.tune_gemms and x_full.is_cuda

@@ -182,10 +182,14 @@ class FusedSAGEConv(nn.Module):
         """accepts the op-by-op layout too (fc_self.weight / fc_neigh.weight / fc_neigh.bias: SAGEConvMean here, DGL's
         SAGEConv in the reference's checkpoints): the two maps side by side are this layer's weight"""
         ks, kn, kb = prefix + "fc_self.weight", prefix + "fc_neigh.weight", prefix + "fc_neigh.bias"
+        ksb = prefix + "fc_self.bias"
         if ks in state_dict and kn in state_dict and prefix + "weight" not in state_dict:
             state_dict[prefix + "weight"] = th.cat([state_dict.pop(ks), state_dict.pop(kn)], 1)
-            if kb in state_dict:
-                state_dict[prefix + "bias"] = state_dict.pop(kb)
+            # DGL < 0.8 keeps a bias in BOTH maps (their sum is what the layer adds); DGL >= 0.8 a separate `bias`
+            # (already under this layer's name); SAGEConvMean here: fc_neigh.bias only
+            parts = [state_dict.pop(k) for k in (kb, ksb) if k in state_dict]
+            if parts and prefix + "bias" not in state_dict:
+                state_dict[prefix + "bias"] = parts[0] if len(parts) == 1 else parts[0] + parts[1]
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def split_state_dict(self, prefix=""):

@@ -34,7 +34,11 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="graphsage", choices=list(MODELS))
     ap.add_argument("--dataset-path", default="/tmp/fgnn_ds/synth")
-    ap.add_argument("--make-dataset", default=None, choices=["products", "small"])
+    ap.add_argument("--make-dataset", default=None, choices=["products", "small", "learnable"])
+    ap.add_argument("--report-acc", type=int, default=0,
+                    help="trainer 0: validation accuracy every N of its steps and test accuracy at the end (the "
+                         "reference's --report-acc, multi_gpu/train_graphsage.py:65,214-220,344-347,395-397); 0: off")
+    ap.add_argument("--op-by-op", action="store_true", help="graphsage: the op-by-op layers instead of the fused ones")
     ap.add_argument("--sample-type", default=None)
     ap.add_argument("--fanout", nargs="+", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=8000)
@@ -84,7 +88,7 @@ def get_run_config(args):
         rc["sample_workers"] = ["cuda:%d" % i for i in range(ns)]
         rc["train_workers"] = ["cuda:%d" % (ns + i) for i in range(nt)]
     rc.update(model=args.model, num_hidden=args.num_hidden, lr=args.lr, dropout=args.dropout,
-              pipeline=not args.no_pipeline, no_train=args.no_train)
+              pipeline=not args.no_pipeline, no_train=args.no_train, report_acc=args.report_acc, op_by_op=args.op_by_op)
     return rc
 
 
@@ -126,7 +130,13 @@ def run_train(worker_id, rc):
     sam.wait_for_sampler_ready(barrier)
     sam.train_init(worker_id, ctx)
     num_layer = rc["num_layer"]
-    model = MODELS[rc["model"]](sam.feat_dim(), rc["num_hidden"], sam.num_class(), num_layer, rc["dropout"]).to(dev)
+    kw = dict(fused=False) if rc["op_by_op"] and rc["model"] == "graphsage" else {}
+    model = MODELS[rc["model"]](sam.feat_dim(), rc["num_hidden"], sam.num_class(), num_layer, rc["dropout"], **kw).to(dev)
+    accuracy = None
+    if rc["report_acc"] and worker_id == 0 and rc["model"] != "pinsage":
+        import train_accuracy
+        graph, valid_set, test_set, feat, label = train_accuracy.load_accuracy_data(rc["dataset_path"])
+        accuracy = train_accuracy.Accuracy(graph, valid_set, test_set, feat, label, rc["fanout"], rc["batch_size"], dev)
     if nt > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev)
     loss_fcn = nn.CrossEntropyLoss().to(dev)
@@ -162,6 +172,11 @@ def run_train(worker_id, rc):
             torch.cuda.current_stream().synchronize()
             t_copy += t1 - t0
             t_train += time.time() - t1
+            if accuracy is not None and (epoch * my_step + step) % rc["report_acc"] == 0:
+                tt = time.time()
+                acc = accuracy.valid_acc(model.module if nt > 1 else model, dev)
+                print("Valid Acc: {:.2f}% | Acc Time: {:.4f} | Total Step: {:d}".format(
+                    acc * 100.0, time.time() - tt, epoch * my_step + step))
         totals.append(time.time() - tic)
         copies.append(t_copy)
         trains.append(t_train)
@@ -170,6 +185,11 @@ def run_train(worker_id, rc):
                 epoch, totals[-1], t_copy, t_train, float(loss)))
         barrier.wait()  # epoch end
     barrier.wait()  # results
+    if accuracy is not None:
+        tt = time.time()
+        acc = accuracy.test_acc(model.module if nt > 1 else model, dev)
+        print("Test Acc: {:.2f}% | Acc Time: {:.4f}".format(acc * 100.0, time.time() - tt))
+        print("test_result:test_acc={:.4f}".format(acc))
     if worker_id == 0:
         sl = slice(1, None) if len(totals) > 1 else slice(None)
         print("test_result:pipeline_train_epoch_time={:.4f}".format(float(np.mean(totals[sl]))))
@@ -183,16 +203,18 @@ def main():
     if args.make_dataset:
         from fgnn_hip import synth
         shape = dict(synth.DATASET_SHAPES["products"]) if args.make_dataset == "products" else \
+            synth.LEARNABLE_SHAPE if args.make_dataset == "learnable" else \
             dict(num_node=200000, num_edge=4000000, feat_dim=100, num_class=47, num_train=40000)
         root, name = os.path.split(args.dataset_path.rstrip("/"))
         synth.write_dataset(root, name, shape["num_node"], shape["num_edge"], shape["feat_dim"], shape["num_class"],
-                            shape["num_train"], 1000, 1000,
+                            shape["num_train"], shape.get("num_valid", 1000), shape.get("num_test", 1000),
+                            learnable=args.make_dataset == "learnable",
                             with_prefix=args.sample_type == "weighted_khop_prefix",
                             with_alias=args.sample_type in ("weighted_khop", "weighted_khop_hash_dedup"))
     rc = get_run_config(args)
     ns, nt = rc["num_sample_worker"], rc["num_train_worker"]
     sam.config({k: v for k, v in rc.items() if isinstance(v, (int, float, str, list)) and k not in
-                ("sample_workers", "train_workers", "model", "no_train")})
+                ("sample_workers", "train_workers", "model", "no_train", "report_acc", "op_by_op")})
     sam.data_init()  # before fork: nothing here touches the GPU
     ctx = mp.get_context("fork")
     rc["global_barrier"] = ctx.Barrier(ns + nt)

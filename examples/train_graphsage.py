@@ -33,8 +33,9 @@ from models import SAGE  # noqa: E402  (examples/models.py: torch-op SAGEConv on
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dataset-path", default="/tmp/fgnn_ds/synth")
-    ap.add_argument("--make-dataset", default=None, choices=["products", "small"],
-                    help="write a synthetic dataset of that shape to --dataset-path first")
+    ap.add_argument("--make-dataset", default=None, choices=["products", "small", "learnable"],
+                    help="write a synthetic dataset of that shape to --dataset-path first (learnable: a small graph whose "
+                         "labels follow from features and neighbourhoods, for --report-acc)")
     ap.add_argument("--fanout", nargs="+", type=int, default=[25, 10])
     ap.add_argument("--batch-size", type=int, default=8000)
     ap.add_argument("--num-epoch", type=int, default=3)
@@ -47,6 +48,10 @@ def main():
                          "arch1 with one")
     ap.add_argument("--cache-percentage", type=float, default=0.0, help="arch2-4: presample cache on the trainer GPU")
     ap.add_argument("--pipeline", action="store_true", help="arch2-4: sam.start() background threads")
+    ap.add_argument("--report-acc", type=int, default=0,
+                    help="validation accuracy every N steps and test accuracy at the end (the reference's --report-acc, "
+                         "multi_gpu/train_graphsage.py:65,344-347,395-397); 0: off")
+    ap.add_argument("--op-by-op", action="store_true", help="the op-by-op SAGE layers instead of the fused ones")
     ap.add_argument("--cache-policy", default="pre_sample",
                     help="a key of sam.cache_policies: pre_sample, presample_static, degree, ..., or dynamic_cache "
                          "(arch4 only: the cache is the previous batch's feature tensor; khop0 / khop1 / weighted_khop, "
@@ -56,11 +61,13 @@ def main():
     if args.make_dataset:
         from fgnn_hip import synth
         shape = dict(synth.DATASET_SHAPES["products"]) if args.make_dataset == "products" else \
+            synth.LEARNABLE_SHAPE if args.make_dataset == "learnable" else \
             dict(num_node=200000, num_edge=4000000, feat_dim=100, num_class=47, num_train=40000)
         root, name = os.path.split(args.dataset_path.rstrip("/"))
         t0 = time.time()
         synth.write_dataset(root, name, shape["num_node"], shape["num_edge"], shape["feat_dim"], shape["num_class"],
-                            shape["num_train"], 1000, 1000)
+                            shape["num_train"], shape.get("num_valid", 1000), shape.get("num_test", 1000),
+                            learnable=args.make_dataset == "learnable")
         print("dataset written in {:.1f}s".format(time.time() - t0))
 
     two = th.cuda.device_count() >= 2
@@ -82,7 +89,14 @@ def main():
         sam.start()
     dev = th.device(trainer_ctx)
     num_layer = len(args.fanout)
-    model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout).to(dev)
+    model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout,
+                 fused=not args.op_by_op).to(dev)
+    accuracy = None
+    if args.report_acc:
+        import train_accuracy
+        graph, valid_set, test_set, feat, label = train_accuracy.load_accuracy_data(args.dataset_path)
+        accuracy = train_accuracy.Accuracy(graph, valid_set, test_set, feat, label, args.fanout, args.batch_size,
+                                           th.device(sampler_ctx))
     loss_fcn = nn.CrossEntropyLoss()
     opt = th.optim.Adam(model.parameters(), lr=args.lr, fused=True)  # one kernel per step instead of one per tensor and op
     num_epoch, num_step = sam.num_epoch(), sam.steps_per_epoch()
@@ -107,12 +121,22 @@ def main():
             t_train += time.time() - t1
             if epoch == num_epoch - 1:
                 edges += sam.get_log_step_value(epoch, step, sam.kLogL1NumSample)
+            if accuracy is not None and (epoch * num_step + step) % args.report_acc == 0:
+                tt = time.time()
+                acc = accuracy.valid_acc(model, dev)
+                print("Valid Acc: {:.2f}% | Acc Time: {:.4f} | Total Step: {:d}".format(
+                    acc * 100.0, time.time() - tt, epoch * num_step + step))
         epoch_total.append(time.time() - t_epoch)
         epoch_sample.append(sam.get_log_epoch_value(epoch, sam.kLogEpochSampleTime))
         epoch_copy.append(sam.get_log_epoch_value(epoch, sam.kLogEpochCopyTime))
         epoch_train.append(t_train)
         print("Epoch {:03d} | {:.4f} s | sample {:.4f} | extract {:.4f} | train {:.4f} | loss {:.4f}".format(
             epoch, epoch_total[-1], epoch_sample[-1], epoch_copy[-1], t_train, float(loss)))
+    if accuracy is not None:
+        tt = time.time()
+        acc = accuracy.test_acc(model, dev)
+        print("Test Acc: {:.2f}% | Acc Time: {:.4f}".format(acc * 100.0, time.time() - tt))
+        print("test_result:test_acc={:.4f}".format(acc))
     sam.report_step_average(num_epoch - 1, num_step - 1)
     # test_result lines in the reference's format (multi_gpu/train_graphsage.py:198-199)
     for k, v in (("epoch_time:total", np.mean(epoch_total[1:])), ("epoch_time:sample_time", np.mean(epoch_sample[1:])),

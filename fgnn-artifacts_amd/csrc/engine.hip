@@ -57,8 +57,9 @@ struct fgnn_sampler {
   // caller orders everything by the stream, a caller rotating over 2, 3 or 6 streams meets every slot on its own
   // stream again.  So a slot's `done` is recorded only if the slot's LAST reuse came from another stream, the CSR
   // hand-over `csr` only if the last batch followed its predecessor on another stream (what happened last is the guess
-  // for what happens next); a reuse that finds no recorded event records it late, on the other stream -- it then covers
-  // more than needed: correct, and only at a change of pattern (e.g. the pre-sampling epoch's stream -> batch streams).
+  // for what happens next); a reuse that finds no recorded event waits for the device -- it then covers more than
+  // needed: correct, and only at a change of pattern (e.g. the pre-sampling epoch's stream -> batch streams).  No stream
+  // handle of an earlier call is ever used again.
   std::atomic<bool> csr_cross{false};
   // weighted_khop_prefix: 5-ary search trees over the long rows of the prefix table (prefix_tree.hip), built once
   fgnn::PrefixTreeHost *ptree = nullptr;
@@ -388,19 +389,13 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
   // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
   // stream, by the slot's event otherwise
   sl.expect_cross = sl.was_used && sl.last_st != st;
-  // a late record goes to the stream that used the slot last -- a handle the caller may have destroyed meanwhile (a
-  // temporary pre-sampling stream): then everything that stream ever held has long been submitted, and waiting for the
-  // device covers it
-  auto late_record = [&](hipEvent_t ev, hipStream_t on) -> bool {
-    if (hipEventRecord(ev, on) == hipSuccess) return true;
-    (void)hipGetLastError();
-    (void)hipDeviceSynchronize();
-    return false;
-  };
+  // Events are recorded where the LAST hand-over crossed streams (the guess for the next one).  A hand-over that crosses
+  // without a recorded event -- a change of pattern: the pre-sampling epoch's stream -> the batch streams -- waits for
+  // the device instead.  (Until round 5 the event was recorded late on the other stream's handle, which the caller may
+  // have destroyed by then: a dangling hipStream_t is undefined behaviour, not an error return.)
   if (sl.expect_cross) {
-    bool have = sl.done_recorded;
-    if (!have) have = late_record(sl.done, sl.last_st);  // late: covers more than needed
-    if (have) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+    if (sl.done_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+    else FGNN_HIP_CHECK(hipDeviceSynchronize());
   }
   if (ordered && seq > 0) {
     // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
@@ -412,9 +407,8 @@ int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t n
     const bool cross = prev.last_st != st;
     s->csr_cross.store(cross, std::memory_order_relaxed);  // this batch records its own hand-over if it needed one
     if (cross) {
-      bool have = prev.csr_recorded;
-      if (!have) have = late_record(prev.csr, prev.last_st);  // late (see csr_cross)
-      if (have) FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
+      if (prev.csr_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
+      else FGNN_HIP_CHECK(hipDeviceSynchronize());  // change of pattern (see above)
     }
   }
   // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)

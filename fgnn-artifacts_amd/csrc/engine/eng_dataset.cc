@@ -25,13 +25,12 @@ namespace sam {
 // initialises and publishes it, everybody else blocks in SharedCreate until then.  A header page in front of the user
 // pointer carries the hand-shake; it exists in both modes so that the two differ in nothing else.
 namespace {
-constexpr size_t kShmHeader = 4096;
+constexpr size_t kShmHeader = kShmHeaderBytes;
 struct ShmHeader {
   uint64_t magic;
   uint64_t bytes;
   int ready;
 };
-constexpr uint64_t kShmMagic = 0x46474e4e53484d31ull;  // "FGNNSHM1"
 std::vector<std::string> &OwnedNames() {
   static std::vector<std::string> v;
   return v;

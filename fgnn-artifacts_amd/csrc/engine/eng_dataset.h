@@ -32,6 +32,9 @@ struct SharedRegion {
   bool creator;
 };
 SharedRegion SharedCreate(size_t bytes);
+// layout of a named region ("/<SAMGRAPH_SHM_PREFIX>.<k>"): a header page, then the user bytes
+constexpr size_t kShmHeaderBytes = 4096;
+constexpr uint64_t kShmMagic = 0x46474e4e53484d31ull;  // "FGNNSHM1"; followed by the user byte count (u64)
 void SharedPublish(void *ptr);
 void *SharedAnonymous(size_t bytes);  // a region without initial content (published at once)
 HostArray MapFile(const std::string &path, size_t expect_bytes, bool required);

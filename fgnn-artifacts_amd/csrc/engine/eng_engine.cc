@@ -647,10 +647,6 @@ void Engine::SampleOnceArch5() {
   if (check) {  // checksum of the packed words, appended behind them in the slot the payload went to
     uint32_t *where = static_cast<uint32_t *>(a.payload ? a.payload : a.slot);
     SAM_FGNN(LaunchMessageChecksum(where, s.d_msg_words, 0, 0, nullptr, s.st));
-    // SAMGRAPH_HANDOFF_CHECK_SELFTEST=corrupt: the stored checksum is flipped after it was taken, so the message no
-    // longer verifies (its arrays stay intact) -- the receivers must refuse it (tests prove the check can fail)
-    static const bool corrupt = [] { const char *e = getenv("SAMGRAPH_HANDOFF_CHECK_SELFTEST"); return e && !strcmp(e, "corrupt"); }();
-    if (corrupt) SAM_FGNN(LaunchMessageChecksum(where, s.d_msg_words, 0, 2, nullptr, s.st));
   }
   SAM_FGNN(fgnn_batch_meta_copied(s.fb));  // by the pack kernel
   SAM_FGNN(fgnn_batch_finish(s.fb, s.st));
@@ -763,6 +759,16 @@ void Engine::ExtractLoop(size_t count) {
     TrainerComplete(xctx_[head]);
     head = (head + 1) % kExtractDepth;
     --inflight;
+  }
+  // leaving with batches still in flight (shutdown, or the queue closed under a blocking receive): their queue slots go
+  // back -- a sampler of another process that wraps around to an unreleased slot would wait for it forever
+  for (; inflight; --inflight, head = (head + 1) % kExtractDepth) {
+    ExtractCtx &x = xctx_[head];
+    if (!x.b) continue;
+    (void)hipStreamSynchronize(x.st);  // the launches read the slot in place
+    mq_->Release(x.mq_key);
+    ReleaseBatch(x.b.get());
+    x.b.reset();
   }
 }
 
@@ -1164,8 +1170,9 @@ void Engine::Shutdown() {
   shutdown_ = true;
   if (pool_) pool_->Stop();
   // threads of THIS process that are blocked on the queue (samgraph_start's loops stopped before their last batch: the
-  // sampler waits for a free slot, the extractor for a message) give up; an arch5 process has no such thread of its own
-  // -- its peers live in other processes and finish by themselves
+  // sampler waits for a free slot, the extractor for a message; an arch5 trainer's StartExtract thread waiting for a
+  // message that no sampler will send any more) give up.  A receiver that gives up holds no claim (MemoryQueue::Recv)
+  // and hands back the slots of the batches it still had in flight (ExtractLoop)
   if (mq_ && (sample_thread_.joinable() || extract_thread_.joinable())) mq_->Close();
   if (sample_thread_.joinable()) sample_thread_.join();
   if (extract_thread_.joinable()) extract_thread_.join();

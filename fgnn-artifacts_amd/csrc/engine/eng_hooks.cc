@@ -1,6 +1,8 @@
 // eng_hooks.cc -- include/fgnn_engine_hooks.h
 #include <signal.h>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -8,6 +10,7 @@
 #include <vector>
 
 #include "eng_config.h"
+#include "eng_dataset.h"
 #include "eng_queue.h"
 #include "eng_shuffler.h"
 #include "fgnn_engine_hooks.h"
@@ -250,6 +253,33 @@ extern "C" void fgnn_host_queue_recv(void *q, uint64_t *key, uint64_t *value) {
   mq->Release(k);
 }
 extern "C" void fgnn_host_queue_close(void *q) { delete static_cast<MemoryQueue *>(q); }
+
+extern "C" int fgnn_host_queue_flip_word(const char *shm_name, size_t key, size_t word) {
+  int fd = shm_open(shm_name, O_RDWR, 0600);
+  if (fd < 0) return 2;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < kShmHeaderBytes + sizeof(QueueMeta)) {
+    close(fd);
+    return 1;
+  }
+  const size_t total = (size_t)st.st_size;
+  void *p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return 2;
+  const uint64_t *h = static_cast<const uint64_t *>(p);
+  auto *m = reinterpret_cast<QueueMeta *>(static_cast<char *>(p) + kShmHeaderBytes);
+  // is this region a queue?  (a job's regions are numbered, not named by content: the caller tries them in turn)
+  const bool is_queue = h[0] == kShmMagic && m->max_size >= 1 && m->max_size <= kMaxSlots && m->mq_nbytes % 256 == 0 &&
+                        m->mq_nbytes >= 256 && h[1] == sizeof(QueueMeta) + m->mq_nbytes * m->max_size &&
+                        total == h[1] + kShmHeaderBytes;
+  int rc = 1;
+  if (is_queue && key < m->send_cnt && word * 4 + 4 <= m->mq_nbytes) {
+    reinterpret_cast<uint32_t *>(m->data + (key % m->max_size) * m->mq_nbytes)[word] ^= 0x5A5A5A5Au;
+    rc = 0;
+  }
+  munmap(p, total);
+  return rc;
+}
 
 extern "C" int fgnn_host_config_probe(const char **keys, const char **vals, size_t n, size_t out[4]) {
   RunConfig rc;

@@ -279,17 +279,13 @@ void MemoryQueue::SimpleSend(size_t key) {
 }
 
 const void *MemoryQueue::Recv(size_t *key) {
-  if (!WaitFor([&] {
-        return __atomic_load_n(&meta_->recv_cnt, __ATOMIC_ACQUIRE) != __atomic_load_n(&meta_->send_cnt, __ATOMIC_ACQUIRE);
-      }, &meta_->aborted, closing_))
-    return nullptr;
-  const size_t k = __atomic_fetch_add(&meta_->recv_cnt, 1, __ATOMIC_ACQ_REL);
-  const size_t slot = k % meta_->max_size;
-  if (!WaitFor([&] { return __atomic_load_n(&meta_->pub_seq[slot], __ATOMIC_ACQUIRE) == k + 1; }, &meta_->aborted,
-               closing_))
-    return nullptr;
-  *key = k;
-  return meta_->data + slot * meta_->mq_nbytes;
+  // Blocks until the oldest message is PUBLISHED, then claims it (TryRecv): a receiver never holds a claim on a message
+  // it is still waiting for, so one that gives up (Close) leaves nothing behind -- a claimed and never released slot
+  // would block the sender that wraps around to it, in whatever process that sender lives.  (The reference's receivers
+  // pre-claim their key and wait for it, memory_queue.cc:104-138; any trainer takes any message either way.)
+  const void *data = nullptr;
+  if (!WaitFor([&] { return TryRecv(&data, key); }, &meta_->aborted, closing_)) return nullptr;
+  return data;
 }
 
 bool MemoryQueue::TryRecv(const void **data, size_t *key) {

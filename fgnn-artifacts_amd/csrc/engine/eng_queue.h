@@ -177,7 +177,7 @@ int LaunchUnpack(const UnpackArgs &a, hipStream_t stream);
 
 // SAMGRAPH_HANDOFF_CHECK.  Sender (verify == 0): position-weighted 64-bit sum of the message's words -> the two words
 // behind the message (`msg` = where the payload was packed; length from *d_words, written by the pack kernel).
-// (verify == 2: flip the stored sum, SAMGRAPH_HANDOFF_CHECK_SELFTEST.)  Receiver (verify == 1): the same sum over `words` words read through `msg`, compared with the trailer; *d_result |= 1
+// Receiver (verify == 1): the same sum over `words` words read through `msg`, compared with the trailer; *d_result |= 1
 // on a mismatch.
 int LaunchMessageChecksum(uint32_t *msg, const uint32_t *d_words, size_t words, int verify, uint32_t *d_result,
                           hipStream_t stream);

@@ -110,14 +110,36 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float *__res
                                                               uint32_t dl_ld, uint32_t *arrive) {
   const uint32_t lane = lane_id();
   __shared__ float wl[kWavesPerBlock];
+  // rows whose label is outside [0, C) are IGNORED like torch's ignore_index rows (default -100): no loss, a zero
+  // gradient row, and the mean runs over the other rows only.  Every workgroup counts them itself (n labels out of L2,
+  // ~1 us) -- the gradient's scale must be known before the first row is written
+  __shared__ uint32_t s_valid[kWavesPerBlock];
+  {
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+      const long long lab = labels[i];
+      cnt += (lab >= 0 && lab < (long long)C) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, kWave);
+    if (lane == 0) s_valid[wave_id()] = cnt;
+    __syncthreads();
+  }
+  uint32_t valid = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w) valid += s_valid[w];
+  const float inv_n = 1.0f / (float)(valid ? valid : 1u);
   float my = 0.f;
   // (a wave walks rows with the grid's stride: at most kXentBlocks arrivals at the counter below -- same-address
   // atomics complete one per ~29 ns on this GPU, a workgroup per four rows made the launch 56 us for 8 000 rows)
   for (uint32_t row = blockIdx.x * kWavesPerBlock + wave_id(); row < n; row += gridDim.x * kWavesPerBlock) {
     const float *x = logits + (size_t)row * ld;
     const long long lab = labels[row];
-    const float inv_n = 1.0f / (float)n;
     float *g = dlogits + (size_t)row * dl_ld;
+    if (lab < 0 || lab >= (long long)C) {  // ignored row
+      for (uint32_t c = lane; c < C; c += kWave) g[c] = 0.f;
+      continue;
+    }
     float lse;
     if (C <= 4u * kWave) {  // the row in registers: one pass over memory (class counts of the reference's datasets: 41-172)
       float v[4];
@@ -154,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float *__res
       const float inv_s = 1.0f / s;
       for (uint32_t c = lane; c < C; c += kWave) g[c] = (expf(x[c] - m) * inv_s - ((long long)c == lab ? 1.f : 0.f)) * inv_n;
     }
-    my += (lab >= 0 && lab < (long long)C) ? lse - x[lab] : 0.f;
+    my += lse - x[lab];
   }
   if (lane == 0) wl[wave_id()] = my;
   __shared__ uint32_t last;
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void softmax_xent_kernel(const float *__res
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    *loss = part[0] / (float)n;
+    *loss = part[0] * inv_n;  // mean over the rows that count (0 when none does; torch: nan)
     *arrive = 0;  // ready for the next launch (stream-ordered)
   }
 }

@@ -138,12 +138,19 @@ class _XentWs:
 
     @classmethod
     def get(cls, device, n):
-        key = (device, n)
+        key = (torch.device(device), n)
         ws = cls.cache.get(key)
         if ws is None:
             nbytes = _lib.load().fgnn_softmax_xent_scratch_bytes(C.c_size_t(n))
             ws = cls.cache[key] = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
         return ws
+
+
+def xent_scratch(device, n):
+    """creates the scratch softmax_xent uses for n rows on `device` (arrival counter zeroed once + partial sums): call
+    it BEFORE a graph capture whose first softmax_xent call would otherwise allocate -- and zero -- it inside the
+    capture (a memset node in every replay, a buffer of the graph's private pool in this module's cache)"""
+    return _XentWs.get(torch.device(device), n)
 
 
 _XENT_GRAD = {}

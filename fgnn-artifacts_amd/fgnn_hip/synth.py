@@ -18,6 +18,11 @@ DATASET_SHAPES = {
 }
 
 
+# a small graph with learnable labels (learnable_labels below) for the examples' --report-acc runs
+LEARNABLE_SHAPE = dict(num_node=50000, num_edge=1000000, feat_dim=64, num_class=8, num_train=20000, num_valid=2000,
+                       num_test=2000)
+
+
 def powerlaw_degrees(num_node, num_edge, rng, alpha=1.8, zero_frac=0.02):
     """Degrees ~ Pareto(alpha) scaled so that they sum to num_edge exactly; a few isolated rows."""
     raw = rng.pareto(alpha, size=num_node) + 0.05
@@ -108,9 +113,26 @@ def node_features(num_node, dim, seed=3, dtype=np.float32):
     return rng.standard_normal((num_node, dim), dtype=np.float32).astype(dtype)
 
 
+def learnable_labels(indptr, indices, feat, num_class, seed=5):
+    """Labels a GNN can learn from the graph (for accuracy checks: random labels teach nothing): the class of node v is
+    the argmax of a fixed random projection of x_v + mean_{u in row v} x_u -- what one mean-aggregator layer computes
+    from a node's own features and its neighbours'.  Isolated nodes are labelled from their own features."""
+    num_node = len(indptr) - 1
+    ip = indptr.astype(np.int64)
+    deg = np.diff(ip)
+    nz = np.nonzero(deg)[0]
+    sums = np.zeros((num_node, feat.shape[1]), dtype=np.float64)
+    if len(nz):
+        sums[nz] = np.add.reduceat(feat[indices.astype(np.int64)].astype(np.float64), ip[:-1][nz], axis=0)
+    mean = sums / np.maximum(deg, 1)[:, None]
+    proj = np.random.default_rng(seed).standard_normal((feat.shape[1], num_class))
+    return np.argmax((feat.astype(np.float64) + mean) @ proj, axis=1).astype(np.uint64)
+
+
 def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train, num_valid=0, num_test=0,
-                  seed=42, with_prefix=False, with_alias=False):
-    """Writes <root>/<name>/{meta.txt,indptr.bin,indices.bin,feat.bin,label.bin,*_set.bin}."""
+                  seed=42, with_prefix=False, with_alias=False, learnable=False):
+    """Writes <root>/<name>/{meta.txt,indptr.bin,indices.bin,feat.bin,label.bin,*_set.bin}.  learnable: labels that
+    follow from the features and the graph (learnable_labels) instead of uniform random ones."""
     d = os.path.join(root, name)
     os.makedirs(d, exist_ok=True)
     indptr, indices = powerlaw_csr(num_node, num_edge, seed)
@@ -120,8 +142,12 @@ def write_dataset(root, name, num_node, num_edge, feat_dim, num_class, num_train
         perm[num_train + num_valid:num_train + num_valid + num_test]
     indptr.tofile(os.path.join(d, "indptr.bin"))
     indices.tofile(os.path.join(d, "indices.bin"))
-    node_features(num_node, feat_dim, seed + 2).tofile(os.path.join(d, "feat.bin"))
-    rng.integers(0, num_class, size=num_node, dtype=np.uint64).tofile(os.path.join(d, "label.bin"))
+    feat = node_features(num_node, feat_dim, seed + 2)
+    feat.tofile(os.path.join(d, "feat.bin"))
+    random_labels = rng.integers(0, num_class, size=num_node, dtype=np.uint64)  # (drawn either way: same sets below)
+    (learnable_labels(indptr, indices, feat, num_class) if learnable else random_labels).tofile(
+        os.path.join(d, "label.bin"))
+    del feat
     train.tofile(os.path.join(d, "train_set.bin"))
     valid.tofile(os.path.join(d, "valid_set.bin"))
     test.tofile(os.path.join(d, "test_set.bin"))

@@ -58,6 +58,12 @@ void fgnn_host_queue_send(void *q, uint64_t key, uint64_t value);
 void fgnn_host_queue_recv(void *q, uint64_t *key, uint64_t *value);
 void fgnn_host_queue_close(void *q);
 
+/* Test of the hand-off check (SAMGRAPH_HANDOFF_CHECK) from OUTSIDE the engine: flips bits of 32-bit word `word` of the
+ * published message `key` in the host ring of a running job, found in the POSIX shared-memory object `shm_name`
+ * ("/<SAMGRAPH_SHM_PREFIX>.<k>").  0: done; 1: that object is not a message ring, or holds no such message (try the
+ * next k); 2: cannot be opened.  The engine itself has no switch that corrupts anything. */
+int fgnn_host_queue_flip_word(const char *shm_name, size_t key, size_t word);
+
 /* Parses a config through the same code as samgraph_config and returns 0; on an invalid config the
  * process aborts like the reference.  Writes steps-per-epoch style derived values for inspection:
  * out[0] = #layers, out[1] = fanout[0], out[2] = run_arch, out[3] = UseGPUCache. */

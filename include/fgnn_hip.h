@@ -346,7 +346,8 @@ int fgnn_relu_dropout(const float *x, float *y, size_t n, float p, uint64_t seed
 int fgnn_relu_dropout_backward(const float *y, const float *gy, float *gx, size_t n, float p, void *stream);
 /* CrossEntropyLoss(reduction='mean') and its gradient in one launch: *loss = mean_i (logsumexp(x_i) - x_i[label_i]),
  * dlogits[i, c] = (softmax(x_i)[c] - [c == label_i]) / n.  The mean is summed in a fixed order (bit-reproducible).
- * A label outside [0, num_class) adds nothing to the loss and marks no class (torch raises a device assert there).
+ * A row whose label is outside [0, num_class) is IGNORED the way torch ignores ignore_index rows (default -100): no
+ * loss, a zero gradient row, and n above is the number of the OTHER rows (no such row: loss 0, torch gives nan).
  * ws: fgnn_softmax_xent_scratch_bytes(n) bytes, its first 16 zeroed ONCE by the caller (the launches keep them zero). */
 size_t fgnn_softmax_xent_scratch_bytes(size_t n);
 int fgnn_softmax_xent(const float *logits, size_t ld, const long long *labels, size_t n, size_t num_class, float *loss,
@@ -420,9 +421,11 @@ typedef struct fgnn_batch_meta_s {
   uint64_t t_start, t_sampled, t_closed;
 } fgnn_batch_meta;
 
-/* Streams: a stream handed to any fgnn_sampler_* call must stay alive until fgnn_sampler_destroy (or until the caller
- * has synchronised it AND made a later call on another stream for each of the sampler's 6 slots): the sampler records
- * a slot's hand-over event lazily, on the stream that used the slot last, the first time another stream needs it. */
+/* Streams: the sampler keeps no stream handle beyond the call it was passed to (it compares handles to tell whether a
+ * slot or the CSR order changes streams, it never enqueues on a remembered one): a caller may destroy a stream once the
+ * work it enqueued there has finished.  Hand-overs between streams are ordered by events recorded at the END of the
+ * earlier call wherever the previous hand-over crossed streams too; the first crossing after a change of pattern (the
+ * pre-sampling stream -> the batch streams) waits for the device instead. */
 fgnn_sampler *fgnn_sampler_create(const fgnn_sampler_config *cfg, int *h_err);
 void fgnn_sampler_destroy(fgnn_sampler *s);
 /* weighted_khop_prefix samplers build, at creation, a 5-ary search tree over every prefix-table row longer than 64

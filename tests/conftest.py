@@ -46,3 +46,16 @@ def _forced_scan_helping_path():
         from fgnn_hip import lib
         lib.load().fgnn_debug_set_scan_help_after(int(os.environ["FGNN_SCAN_HELP_AFTER"]))
     yield
+
+
+def pytest_terminal_summary(terminalreporter):
+    """every skipped test with its reason, whatever -r flags the run was given: the log of the first multi-GPU box must
+    show at a glance whether the two-device hand-off tests RAN (they skip on a one-GPU box and say how many devices
+    they found)"""
+    skipped = terminalreporter.stats.get("skipped", [])
+    if not skipped:
+        return
+    terminalreporter.write_line("skipped tests and why (%d):" % len(skipped))
+    for rep in skipped:
+        reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) and len(rep.longrepr) == 3 else str(rep.longrepr)
+        terminalreporter.write_line("  %s -- %s" % (rep.nodeid, reason))

@@ -394,6 +394,10 @@ def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample
         import samgraph.torch as sam
         barrier.wait()  # samplers (and the presample) are done initialising
         sam.train_init(worker, TRAINER_DEV)
+        hold = os.environ.get("FGNN_TEST_HOLD_TRAINER")  # tests: this trainer starts receiving when the file appears
+        while hold and not os.path.exists(hold):
+            import time
+            time.sleep(0.01)
         # expected batches of every sampler, by key
         expected = {}
         rank = None

@@ -76,6 +76,38 @@ def test_plain_launch_spawns_ranks(gpus, samplers):
     assert not [f for f in set(os.listdir("/dev/shm")) - before if f.startswith("fgnn_bench_")]  # rank 0 cleaned up
 
 
+def test_sampler_count_is_chosen_from_measured_rates():
+    """--samplers auto: S = argmin max(t_s / S, t_t / (N - S)) over the two per-process rates measured before the roles
+    are given out (bench.choose_samplers / calibrate_roles; the reference tunes S per workload by hand,
+    exp/table4/README.md:79-90)"""
+    import bench
+    # this build's rates at presample_epoch 1 (sampler 0.10, trainer 0.29 ms per batch): the reference's 2S+6T balances
+    assert [bench.choose_samplers(n, 0.10, 0.29)[0] for n in (3, 4, 8)] == [1, 1, 2]
+    # a trainer twice as fast (a three-epoch ranking): a third sampler pays at 8 ranks, a second one at 4
+    assert [bench.choose_samplers(n, 0.10, 0.15)[0] for n in (3, 4, 8)] == [1, 2, 3]
+    best, pred = bench.choose_samplers(8, 0.10, 0.15)
+    assert pred[best] == min(pred.values()) and set(pred) == set(range(1, 8))
+    assert bench.choose_samplers(8, 1.0, 0.01)[0] == 7 and bench.choose_samplers(8, 0.01, 1.0)[0] == 1
+    assert bench.choose_samplers(4, 0.2, 0.2)[0] == 2  # (a tie between 1 and 3 never beats the balanced split)
+
+
+@pytest.mark.parametrize("gpus,rates,want", [(8, "0.1,0.29", 2), (8, "0.1,0.15", 3), (4, "0.1,0.15", 2), (2, "0.1,0.15", 1)])
+def test_rehearsal_line_shows_the_sampler_choice(gpus, rates, want):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = _run([sys.executable, "bench.py", "--gpus", str(gpus), "--steps", "10", "--warmup", "2", "--rehearse",
+                "--rehearse-rates", rates], env)
+    ch = out["pipeline"]["sampler_choice"]
+    assert out["pipeline"]["samplers"] == want and out["pipeline"]["trainers"] == gpus - want
+    if gpus >= 3:
+        ts, tt = [float(x) for x in rates.split(",")]
+        assert ch["mode"] == "auto" and ch["chosen"] == want and ch["sampler_ms_per_batch_alone"] == ts
+        assert ch["trainer_ms_per_batch_alone"] == tt and ch["reference_split"] == max(1, gpus // 4)
+        assert min(ch["predicted_ms_per_batch_by_samplers"].values()) == ch["predicted_ms_per_batch_by_samplers"][str(want)]
+    else:
+        assert "no choice" in ch["mode"]
+    _check_windows(out, gpus, want, 2, 10)
+
+
 def test_torchrun_launch():
     """the launch line of the task description: one rank per GPU started by torch.distributed.run"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

@@ -132,3 +132,15 @@ def test_shipped_kernel_library_reads_no_switch_from_the_environment():
     from fgnn_hip import lib
     data = open(lib.LIB_PATH, "rb").read()
     assert b"FGNN_" not in data, "an FGNN_* name is compiled into the shipped library"
+
+
+def test_shipped_engine_library_holds_no_test_switch():
+    """c_lib.so reads the reference's SAMGRAPH_* variables plus a few of its own (documented in INTEGRATION.md); none of
+    them may be a test hook -- the hand-off check's failure path is exercised from outside the engine (the hooks
+    library flips a word of a published message, tests/test_engine_gpu.py) -- or swap / tune the kernel library."""
+    data = open(ENGINE_LIB, "rb").read()
+    for name in (b"SELFTEST", b"FGNN_HIP_LIB", b"corrupt", b"FGNN_TEST"):
+        assert name not in data, "%r is compiled into the shipped engine library" % name
+    # and it knows none of the profiling build's A/B switches
+    for name in (b"FGNN_GATHER_", b"FGNN_FUSED_", b"FGNN_KHOP", b"FGNN_HT_", b"FGNN_SPLIT_", b"FGNN_PREFIX_TREE"):
+        assert name not in data, name

@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 RUNNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "engine_runner.py")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(tmp_path, *args, env=None):
@@ -171,20 +172,47 @@ def test_handoff_check_verifies_and_counts(tmp_path, slots):
 
 
 def test_handoff_check_refuses_a_corrupted_payload(tmp_path):
-    """the same with one payload word overwritten after the checksum was taken: the receiving trainer aborts
-    (non-zero exit of the job), it does not train on the batch"""
-    p = subprocess.run([sys.executable, RUNNER, "arch5", "khop2", str(tmp_path), "1", "1", "0.25", "pipeline"],
-                       capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, SAMGRAPH_HANDOFF_CHECK="3", SAMGRAPH_HANDOFF_CHECK_SELFTEST="corrupt"))
-    assert p.returncode != 0
-    assert "hand-off check: message" in p.stderr and "does not verify" in p.stderr, p.stderr[-3000:]
-    assert "'check_failed': 1" in p.stdout or "'check_failed': 1" in p.stderr, p.stdout[-2000:]
+    """a payload word of a published message overwritten between the sampler and the trainer -- from OUTSIDE the engine
+    (the test flips it in the job's shared ring through the host-only hooks library; the product has no switch that
+    corrupts anything): the receiving trainer aborts, it does not train on the batch"""
+    import ctypes as C
+    import time
+    subprocess.run([sys.executable, RUNNER, "dataset", "khop2", str(tmp_path)], check=True, timeout=600)
+    prefix = "fgnn_test_%d_flip" % os.getpid()
+    go = os.path.join(str(tmp_path), "go")
+    # payloads in the host ring (no device ring): that is the memory this test can reach
+    env = dict(os.environ, SAMGRAPH_SHM_PREFIX=prefix, SAMGRAPH_SHM_KEEP="1", SAMGRAPH_HANDOFF_CHECK="3",
+               SAMGRAPH_DEVICE_RING_SLOTS="0", FGNN_TEST_HOLD_TRAINER=go)
+    procs = {}
+    try:
+        for role in ("t", "s"):
+            procs[role] = subprocess.Popen([sys.executable, RUNNER, "arch5_named", "khop2", str(tmp_path), role, "0", "1",
+                                            "1", "0.25"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                           text=True)
+        s_out = procs["s"].communicate(timeout=600)[0]  # the sampler has published every batch and left
+        assert procs["s"].returncode == 0, s_out[-3000:]
+        hooks = C.CDLL(os.path.join(ROOT, "fgnn-artifacts_amd", "samgraph", "torch", "fgnn_engine_hooks.so"))
+        rcs = [hooks.fgnn_host_queue_flip_word(("/%s.%d" % (prefix, k)).encode(), C.c_size_t(1), C.c_size_t(13))
+               for k in range(32) if os.path.exists("/dev/shm/%s.%d" % (prefix, k))]
+        assert rcs.count(0) == 1, rcs  # exactly one of the job's regions is the message ring
+        open(go, "w").close()
+        t_out = procs["t"].communicate(timeout=600)[0]
+        assert procs["t"].returncode != 0
+        assert "hand-off check: message 1" in t_out and "does not verify" in t_out, t_out[-3000:]
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(prefix):
+                os.unlink(os.path.join("/dev/shm", f))
 
 
 def _two_gpu_env():
     import torch
-    if torch.cuda.device_count() < 2:  # counting devices does not initialise the GPU in this process
-        pytest.skip("needs two GPUs: sampler on cuda:0, trainers on cuda:1")
+    n = torch.cuda.device_count()  # counting devices does not initialise the GPU in this process
+    if n < 2:
+        pytest.skip("needs two GPUs (sampler on cuda:0, trainers on cuda:1): this box has %d" % n)
     return {"FGNN_TEST_SAMPLER_DEVICE": "cuda:0", "FGNN_TEST_TRAINER_DEVICE": "cuda:1", "SAMGRAPH_LOG_LEVEL": "info"}
 
 

@@ -312,3 +312,19 @@ def test_fused_sage_layer_loads_the_op_by_op_checkpoint_layout():
     ref2 = models.SAGE(12, 16, 5, 2, 0.0, fused=False)
     ref2.load_state_dict(back)
     torch.testing.assert_close(ref2([b0, b1], x), ref([b0, b1], x))
+    # DGL's two checkpoint layouts (advisor, round 5): < 0.8 keeps a bias in BOTH linear maps -- the layer adds their sum
+    # --, >= 0.8 bias-free maps plus a separate `bias`; both load strictly and give the reference's outputs
+    sd = ref.state_dict()
+    old, new = {}, {}
+    for k, v in sd.items():
+        if k.endswith("fc_neigh.bias"):
+            half = torch.randn_like(v)
+            old[k], old[k.replace("fc_neigh.bias", "fc_self.bias")] = v - half, half
+            new[k.replace("fc_neigh.bias", "bias")] = v
+        else:
+            old[k] = new[k] = v
+    for layout in (old, new):
+        m = models.SAGE(12, 16, 5, 2, 0.0, fused=True)
+        m.load_state_dict(dict(layout), strict=True)
+        m.eval()
+        torch.testing.assert_close(m([b0, b1], x), ref([b0, b1], x), rtol=1e-5, atol=1e-6)

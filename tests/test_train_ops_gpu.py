@@ -77,6 +77,25 @@ def test_softmax_xent_matches_cross_entropy(nn, n, c, pad):
         assert not grad[n:].any()
 
 
+@pytest.mark.parametrize("n,c", [(8000, 172), (37, 47), (300, 600)])
+def test_softmax_xent_ignores_out_of_range_labels_like_ignore_index(nn, n, c):
+    """rows labelled -100 (torch's default ignore_index): no loss, a zero gradient row, the mean over the other rows
+    (advisor, round 5: the kernel used to write softmax / n into such rows and divide by n)"""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    logits = (torch.randn((n, c), generator=g, device="cuda") * 2).requires_grad_()
+    y = torch.randint(0, c, (n,), generator=g, device="cuda")
+    y[torch.randperm(n, generator=g, device="cuda")[: n // 5]] = -100
+    want = torch.nn.functional.cross_entropy(logits, y)
+    (want_g,) = torch.autograd.grad(want, logits)
+    loss, grad = nn.softmax_xent(logits.detach(), y)
+    torch.testing.assert_close(loss, want, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(grad, want_g, rtol=1e-5, atol=1e-8)
+    assert not grad[y < 0].any()
+    # nothing to learn from: zero loss and gradient (torch: nan)
+    loss0, grad0 = nn.softmax_xent(logits.detach(), torch.full_like(y, -100))
+    assert float(loss0) == 0.0 and not grad0.any()
+
+
 @pytest.mark.parametrize("shapes,wd", [([(256, 256), (256,), (172, 512), (172,)], 0.0), ([(33,)] * 11, 0.01)])
 def test_adam_matches_torch_adam(nn, shapes, wd):
     g = torch.Generator(device="cuda").manual_seed(3)
