@@ -203,6 +203,22 @@ def pmc_traffic():
     return None, None, None
 
 
+def pmc_requests(workload):
+    """fabric requests per batch of the sampler-side stage from the newest committed counter pass
+    (profiles/r*_pmc_requests.json, tools/pmc_requests.sh: TCC_EA0_RDREQ / WRREQ per kernel) for this workload, or None"""
+    import glob
+    for name in sorted((os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_requests.json"))),
+                       reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)["workloads"].get(workload)
+            if d:
+                return d, name
+        except Exception:
+            continue
+    return None, None
+
+
 def algorithmic_bytes(metas, feat_dim, batch_size):
     """per batch, 4-byte ids.  Returns dict of per-stage algorithmic bytes (sums)."""
     sample = dedup = split = gather = 0
@@ -577,6 +593,13 @@ def run_single(args):
     torch.cuda.synchronize()
     run_region(prime, prime + args.warmup, False)
     torch.cuda.synchronize()
+    # what the memory system sustains for the sampling chain's access pattern HERE and NOW: independent random 4-byte
+    # reads from the CSR (6.5 GB: far beyond every cache), ~20 ms, nothing else on the GPU (roofline_sample's ceiling)
+    probe_reads_per_s = None
+    try:
+        probe_reads_per_s = lib.random_read_rate(indices)
+    except Exception:
+        pass
     # R timed windows of EXACTLY args.steps steps each, back to back (a 151-step window is ~20 ms: one window is a thin
     # basis for a headline); every window is bracketed by a device synchronise on both sides, all R values are
     # published and `value` is the MEDIAN window's
@@ -632,6 +655,30 @@ def run_single(args):
                                 "and publishes, uses three)" % stage_streams[0]}
         mode[0] = "full"
         stage_streams[0] = len(streams)
+    # the latency-bound stage against the chip's random-request rate: fabric requests per batch (committed counter pass
+    # of this workload) / the stage's time, against what the probe above sustained in this very run
+    roofline_sample = None
+    req, req_file = pmc_requests(args.workload) if args.sample_type == w["sample_type"] and args.graph == "rmat" else (None, None)
+    if sample_stage and req and probe_reads_per_s:
+        per_read = req.get("probe_requests_per_read") or 1.0
+        side = req["sampler_side_per_batch"]
+        total_req = side["read"] + side["write"]
+        ach = total_req / (sample_stage["ms_per_step"] * 1e-3)
+        peak = probe_reads_per_s * per_read
+        worst = sorted(((k, v["read_per_batch"] + v["write_per_batch"]) for k, v in req["kernels"].items()
+                        if not k.startswith("gather_rows")), key=lambda kv: -kv[1])
+        roofline_sample = {
+            "bound": "fabric random-request rate", "requests_per_batch": total_req, "read_requests_per_batch": side["read"],
+            "write_requests_per_batch": side["write"], "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G requests/s",
+            "frac": ach / peak, "stage_ms_per_step": sample_stage["ms_per_step"],
+            "probe": {"random_reads_per_s": probe_reads_per_s, "requests_per_read": per_read,
+                      "what": "fgnn_debug_random_reads: independent random 4-byte reads from this run's CSR array, four "
+                              "in flight per lane, alone on the GPU, in this run's warm-up"},
+            "requests_by_kernel_per_batch": {k: v for k, v in worst},
+            "requests_source": "profiles/%s (rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum, tools/pmc_requests.sh; "
+                               "counts of the one-stream run)" % req_file,
+            "note": "sampler-side stage = sample + dedup + remap + cache-index split; the stage is a chain of dependent "
+                    "random accesses, so the chip's random-request rate, not HBM bytes, is what bounds it"}
     metas.clear()
     gather_ms.clear()
     # the gather with nothing else on the GPU (one thread, one stream): separates the kernel's own efficiency from
@@ -764,6 +811,8 @@ def run_single(args):
                                  "on 8 V100s, exp/table4); the factored pipeline's epoch is measured by the N >= 2 runs"},
         "train_leg": train_leg,
         "sample_stage": sample_stage,
+        "roofline_sample": roofline_sample,
+        "probe_random_reads_per_s": probe_reads_per_s,
         "rows_per_s": rows / elapsed, "edges_per_step": edges / args.steps,
         "input_nodes_per_step": rows / args.steps,
         "algorithmic_bytes_per_step": {k: v / len(metas) for k, v in ab.items()},

@@ -74,6 +74,38 @@ extern "C" int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream)
   return fgnn::launch_status(__func__);
 }
 
+// What the memory system sustains for the sampling chain's access pattern, measured where and when the caller runs
+// (bench.py's roofline_sample): `num_items` INDEPENDENT random 4-byte reads from a caller's array (large: the CSR),
+// four in flight per lane, nothing else.  The same probe as tools/probe/rand_probe.hip's read4.
+__device__ __forceinline__ unsigned long long probe_mix(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+__global__ __launch_bounds__(256) void random_read_probe_kernel(const uint32_t *__restrict__ a, unsigned long long n_elems,
+                                                                unsigned long long n_items, unsigned long long salt,
+                                                                uint32_t *sink) {
+  constexpr int K = 4;
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (unsigned long long base = i * K; base < n_items; base += (unsigned long long)gridDim.x * 256 * K) {
+    uint32_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = a[probe_mix(base + k + salt) % n_elems];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc += v[k];
+  }
+  if (acc == 0x12345677u) sink[0] = acc;  // (keeps the loads alive; practically never true)
+}
+extern "C" int fgnn_debug_random_reads(const uint32_t *array, size_t num_elems, size_t num_items, uint64_t salt,
+                                       uint32_t *d_sink, void *stream) {
+  if (!array || !d_sink || num_elems == 0 || num_items == 0) return FGNN_EINVAL;
+  size_t grid = (num_items + 1023) / 1024;
+  if (grid > (1u << 20)) grid = 1u << 20;
+  hipLaunchKernelGGL(random_read_probe_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), array,
+                     (unsigned long long)num_elems, (unsigned long long)num_items, (unsigned long long)salt, d_sink);
+  return fgnn::launch_status(__func__);
+}
+
 extern "C" unsigned long long fgnn_debug_scan_helps(void) {
   unsigned long long v = 0, *p = fgnn::scan_help_counter();
   if (!p || hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;

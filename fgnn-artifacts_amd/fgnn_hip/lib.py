@@ -34,7 +34,7 @@ _T2DT = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.uint8
          torch.int8: I8, torch.int64: I64}
 
 EXPORTS = [
-    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_debug_set_scan_help_after", "fgnn_debug_set_partition_lds_limit", "fgnn_debug_sort_pairs", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
+    "fgnn_version", "fgnn_last_error", "fgnn_device_count", "fgnn_debug_phase_log_bytes", "fgnn_debug_phase_log", "fgnn_debug_occupy", "fgnn_debug_scan_helps", "fgnn_debug_set_scan_help_after", "fgnn_debug_set_partition_lds_limit", "fgnn_debug_sort_pairs", "fgnn_debug_random_reads", "fgnn_scratch_bytes", "fgnn_sanity_map_bytes", "fgnn_sanity_check_batch", "fgnn_sample_khop0", "fgnn_sample_khop2",
     "fgnn_weighted_scratch_bytes", "fgnn_sample_weighted_khop_prefix", "fgnn_random_walk_scratch_bytes",
     "fgnn_sample_random_walk", "fgnn_sample_khop1", "fgnn_sample_weighted_khop",
     "fgnn_hash_dedup_scratch_bytes", "fgnn_sample_weighted_khop_hash_dedup",
@@ -444,6 +444,26 @@ def gather_rows(out, src, src_index=None, dst_index=None, n=None, d_n=None, src_
                                    C.c_size_t(n), C.c_size_t(dim), C.c_int(_T2DT[out.dtype]), _stream()),
            "fgnn_gather_rows")
     return out
+
+
+def random_read_rate(array, num_items=4_000_000, repeats=24):
+    """independent random 4-byte reads per second the GPU sustains from `array` (an int32 device tensor far larger than
+    the caches) right now: fgnn_debug_random_reads, `repeats` launches of num_items reads between two events"""
+    _need_gpu(array)
+    sink = torch.zeros(1, dtype=torch.int32, device=array.device)
+    L = load()
+
+    def launch(salt):
+        _check(L.fgnn_debug_random_reads(_ptr(array), C.c_size_t(array.numel()), C.c_size_t(num_items), C.c_uint64(salt),
+                                         _ptr(sink), _stream()), "fgnn_debug_random_reads")
+    launch(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(repeats):
+        launch(2 + r * num_items)
+    e1.record()
+    e1.synchronize()
+    return repeats * num_items / (e0.elapsed_time(e1) * 1e-3)
 
 
 class CopySegment(C.Structure):

@@ -55,6 +55,12 @@ void fgnn_debug_phase_log(unsigned long long *d_buf);
 /* Diagnostics (tests/test_coresidency_gpu.py): a foreign tenant -- `workgroups` x 256 threads that keep their wave
  * slots for `usec` microseconds (<= 2 s) on `stream` and do nothing else. */
 int fgnn_debug_occupy(size_t workgroups, unsigned usec, void *stream);
+/* Diagnostics (bench.py, roofline_sample): num_items independent random 4-byte reads from array[0 .. num_elems), four in
+ * flight per lane, as one launch -- what the memory system sustains for the sampling chain's access pattern on this
+ * GPU right now (time it with events on `stream`; one read = one 64-byte fabric request when the array is far larger
+ * than the caches).  d_sink: one device word (never written in practice). */
+int fgnn_debug_random_reads(const uint32_t *array, size_t num_elems, size_t num_items, uint64_t salt, uint32_t *d_sink,
+                            void *stream);
 /* Diagnostics: how many tile aggregates of the single-pass kernels were recomputed by a waiting workgroup instead of
  * being read from the tile itself (current device, since the process started; synchronises).  0 on an idle GPU. */
 unsigned long long fgnn_debug_scan_helps(void);

@@ -269,6 +269,46 @@ def test_arch5_unrelated_processes_named_regions(tmp_path, sample_type, ns, nt, 
                 os.unlink(os.path.join("/dev/shm", f))
 
 
+@pytest.mark.parametrize("samplers", ["2", "auto"])
+def test_bench_pipeline_six_ranks_on_one_gpu(tmp_path, samplers):
+    """The first multi-GPU run rehearsed as far as one GPU allows: bench.py --gpus 6 through bench.main's launcher with
+    the REAL engine on every rank (the box lets six processes use its GPU at once, hence six and not eight; the 8-rank
+    control plane is rehearsed without a GPU in tests/test_bench_distributed.py) -- 2S+4T as the reference splits an
+    8-GPU node (--samplers 2), and the split chosen from the measured per-role rates (--samplers auto: two calibration
+    children run a 1S+1T job of their own first).  Windows, roles, the hand-off's verification counters, what
+    `degraded` means on a shared GPU, and the exit code."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--workload", "small", "--steps",
+                        "12", "--warmup", "4", "--no-train-leg", "--no-n1-point", "--empty-feat-bits", "16",
+                        "--samplers", samplers], capture_output=True, text=True, timeout=1200, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    pl = out["pipeline"]
+    S, T = pl["samplers"], pl["trainers"]
+    assert out["n_gpus"] == 6 and S + T == 6 and 1 <= S <= 5
+    ch = pl["sampler_choice"]
+    if samplers == "auto":
+        assert ch["mode"] == "auto" and ch["chosen"] == S, ch
+        assert ch["sampler_ms_per_batch_alone"] > 0 and ch["trainer_ms_per_batch_alone"] > 0
+        pred = ch["predicted_ms_per_batch_by_samplers"]
+        assert pred[str(S)] == min(pred.values())
+    else:
+        assert S == 2 and "fixed" in ch["mode"]
+    assert out["config"]["parallelism"].startswith("%dS+%dT" % (S, T))
+    wd = out["windows"]
+    assert wd["count"] == 5 and len(wd["median_window_keys"]) == 12 == len(set(wd["median_window_keys"]))
+    assert out["value"] > 0 and out["edges_per_step"] > 1000 and 0 < pl["hit_rate"] <= 1
+    # every sampler's warm-up messages were verified by whichever trainer received them, none failed
+    rings = pl["handoff"]["rings"]
+    assert len(rings) == S and all(r["verified"] > 0 and r["check_failed"] == 0 for r in rings), rings
+    # every trainer mapped every sampler's ring device to device; nothing went through pinned host memory unasked
+    tr = pl["handoff"]["trainers"]
+    assert len(tr) == T and all(len(t["rings"]) == S and all(r["state"] in (1, 2) for r in t["rings"]) for t in tr), tr
+    assert not pl["handoff"]["degraded"]
+    assert pl["links"]["rccl_world"] is None and "share" in pl["links"]["why"]  # six ranks, one GPU: no RCCL world
+
+
 def test_bench_pipeline_two_processes(tmp_path):
     """bench.py --gpus 2 = 1S+1T as two processes through bench.main's launcher, the engine and the device ring (both
     ranks share cuda:0 on a one-GPU box)."""
