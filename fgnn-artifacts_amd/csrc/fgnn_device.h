@@ -769,6 +769,10 @@ constexpr uint32_t kPrefixTreeMinLen = 64;
 struct PrefixTreeView {
   const uint32_t *tree_off;  // null: no trees
   const float *pool;
+  // one 16-byte record per node, {row offset, row length, tree root (or FGNN_EMPTY_KEY), bits of the row's last prefix
+  // value}: what a draw needs before its search, from ONE line instead of three (indptr pair, tree_off, the row's
+  // last entry) and one round trip earlier.  null: not built
+  const uint4 *rec;
 };
 struct PrefixTreeHost;
 PrefixTreeHost *prefix_tree_build(const uint32_t *indptr, const float *prefix, size_t num_node);  // synchronous
@@ -801,7 +805,7 @@ int sample_with_replacement_ex(int sample_type, const uint32_t *indptr, const ui
                                const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                                uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                                uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node,
-                               const RankWs *rank, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr});
+                               const RankWs *rank, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr, nullptr});
 // fgnn_sample_random_walk with look-back descriptors: the edge offsets and the compacted output come from one launch
 // (scan == null: per-workgroup sums -> scan -> emit, as the C entry point)
 int sample_random_walk_ex(const uint32_t *indptr, const uint32_t *indices, const uint32_t *input, size_t num_input,

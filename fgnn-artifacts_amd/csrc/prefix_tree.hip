@@ -112,11 +112,24 @@ __global__ __launch_bounds__(kBlock) void tree_mark_short_kernel(const uint32_t 
   if (r < num_node && sizes[r] == 0) tree_off[r] = FGNN_EMPTY_KEY;
 }
 
+// the per-node records (PrefixTreeView::rec), once the trees' roots are final
+__global__ __launch_bounds__(kBlock) void tree_node_rec_kernel(const uint32_t *__restrict__ indptr,
+                                                               const float *__restrict__ prefix,
+                                                               const uint32_t *__restrict__ tree_off, size_t num_node,
+                                                               uint4 *__restrict__ rec) {
+  const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= num_node) return;
+  const uint32_t off = indptr[r], len = indptr[r + 1] - off;
+  const uint32_t root = len > kPrefixTreeMinLen ? tree_off[r] : FGNN_EMPTY_KEY;
+  rec[r] = uint4{off, len, root, len ? __float_as_uint(prefix[off + len - 1]) : 0u};
+}
+
 }  // namespace
 
 struct PrefixTreeHost {
   uint32_t *tree_off = nullptr;
   float *pool = nullptr;
+  uint4 *rec = nullptr;
   size_t nodes = 0, long_rows = 0, refused = 0;
 };
 
@@ -124,11 +137,12 @@ void prefix_tree_destroy(PrefixTreeHost *t) {
   if (!t) return;
   if (t->tree_off) (void)hipFree(t->tree_off);
   if (t->pool) (void)hipFree(t->pool);
+  if (t->rec) (void)hipFree(t->rec);
   delete t;
 }
 
 PrefixTreeView prefix_tree_view(const PrefixTreeHost *t) {
-  return t ? PrefixTreeView{t->tree_off, t->pool} : PrefixTreeView{nullptr, nullptr};
+  return t ? PrefixTreeView{t->tree_off, t->pool, t->rec} : PrefixTreeView{nullptr, nullptr, nullptr};
 }
 
 // synchronous (init time); null if there is nothing to build or memory is short -- the sampler then searches every row
@@ -178,6 +192,19 @@ PrefixTreeHost *prefix_tree_build(const uint32_t *indptr, const float *prefix, s
                      t->tree_off, t->pool, counters + 1);
   if (hipMemcpy(h_counters, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return fail();
   t->refused = h_counters[1];
+  // 16 bytes per node (twitter shape: 0.67 GB); without the memory the draws read indptr / tree_off / the row as before
+  // (FGNN_PREFIX_REC=0, profiling build: A/B)
+  if (tune_int("FGNN_PREFIX_REC", 1) != 0 && hipMalloc(&t->rec, num_node * sizeof(uint4)) == hipSuccess) {
+    hipLaunchKernelGGL(tree_node_rec_kernel, dim3(nb), dim3(kBlock), 0, 0, indptr, prefix, t->tree_off, num_node, t->rec);
+    if (hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(t->rec);
+      t->rec = nullptr;
+    }
+  } else {
+    (void)hipGetLastError();
+    t->rec = nullptr;
+  }
   (void)hipFree(sizes);
   (void)hipFree(long_rows);
   (void)hipFree(counters);

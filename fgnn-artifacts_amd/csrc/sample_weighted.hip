@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t weighted_pick(const uint32_t *__restrict__ i
                                                   const uint32_t *__restrict__ alias, uint32_t off, uint32_t len,
                                                   uint32_t i, uint32_t j, uint64_t seed, uint64_t batch_key,
                                                   uint32_t tag, const float *tree_pool = nullptr,
-                                                  uint32_t tree_root = FGNN_EMPTY_KEY) {
+                                                  uint32_t tree_root = FGNN_EMPTY_KEY, const float *up_known = nullptr) {
   if (len == 0) return FGNN_EMPTY_KEY;
   if (MODE == 1) return indices[off + philox_u32(seed, batch_key, tag, i, j) % len];
   if (MODE == 2) {
@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t weighted_pick(const uint32_t *__restrict__ i
     const uint32_t k = r0 % len;
     return uniform_float(r1) < prefix[off + k] ? indices[off + k] : alias[off + k];
   }
-  const float up = prefix[off + len - 1];
+  const float up = up_known ? *up_known : prefix[off + len - 1];  // (the node record carries the row's last entry)
   const float x = uniform_float(philox_u32(seed, batch_key, tag, i, j)) * up;
   if (tree_root != FGNN_EMPTY_KEY) return indices[off + tree_search(len, tree_pool, tree_root, x)];
   if (x <= prefix[off]) return indices[off];
@@ -121,17 +121,28 @@ __global__ __launch_bounds__(kBlock) void weighted_draw_count_kernel(
     const size_t i = w * G + g;
     const bool seed_here = lane_used && i < cap;
     uint32_t rid = FGNN_EMPTY_KEY, off = 0, len = 0, root = FGNN_EMPTY_KEY;
+    float up = 0.f;
+    const bool rec = MODE == 0 && tree.rec != nullptr;
     if (seed_here && i < n) {
       rid = input[i];
-      off = indptr[rid];
-      len = indptr[rid + 1] - off;
-      // (the root's index is fetched with the row bounds: no extra round trip; the F lanes of a seed share the address)
-      if (MODE == 0 && tree.tree_off) root = tree.tree_off[rid];
-      if (len <= kPrefixTreeMinLen) root = FGNN_EMPTY_KEY;
+      if (rec) {  // row bounds, tree root and row sum from ONE line (three lines and one more round trip without)
+        const uint4 rc = tree.rec[rid];
+        off = rc.x;
+        len = rc.y;
+        root = rc.z;
+        up = __uint_as_float(rc.w);
+      } else {
+        off = indptr[rid];
+        len = indptr[rid + 1] - off;
+        // (the root's index is fetched with the row bounds: no extra round trip; the F lanes of a seed share the address)
+        if (MODE == 0 && tree.tree_off) root = tree.tree_off[rid];
+        if (len <= kPrefixTreeMinLen) root = FGNN_EMPTY_KEY;
+      }
     }
     uint32_t pick = FGNN_EMPTY_KEY;
     if (seed_here && i < n) {
-      pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag, tree.pool, root);
+      pick = weighted_pick<MODE>(indices, prefix, alias, off, len, (uint32_t)i, j, seed, batch_key, tag, tree.pool, root,
+                                 rec ? &up : nullptr);
       tmp_dst[i * F + j] = pick;
     }
     // a draw is dropped when it equals the seed's NEXT draw; the last one is always kept (count_edge, prefix.cu:94-112)
@@ -465,7 +476,7 @@ int launch_with_replacement(int mode, int sample_type, const uint32_t *indptr, c
                             const uint32_t *d_num_input, size_t num_input_cap, size_t fanout, uint32_t *out_src,
                             uint32_t *out_dst, size_t *d_num_out, int src_mode, uint64_t seed, uint64_t batch_key,
                             uint32_t layer, void *ws, size_t ws_bytes, void *stream, size_t num_node = 0,
-                            const RankWs *rank = nullptr, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr}) {
+                            const RankWs *rank = nullptr, PrefixTreeView tree = PrefixTreeView{nullptr, nullptr, nullptr}) {
   // rank != null: the caller guarantees unique seeds below num_node (the batch driver's frontier) and owns an all-zero
   // bitmap over the id space: the seeds are ordered by counting bits, nothing is sorted and no library is called
   auto st = static_cast<hipStream_t>(stream);
@@ -575,7 +586,7 @@ int fgnn::sample_with_replacement_ex(int sample_type, const uint32_t *indptr, co
   const int mode = sample_type == FGNN_KHOP1 ? 1 : sample_type == FGNN_WEIGHTED_KHOP ? 2 : 0;
   return launch_with_replacement(mode, sample_type, indptr, indices, table_f, alias, input, num_input, d_num_input,
                                  num_input_cap, fanout, out_src, out_dst, d_num_out, src_mode, seed, batch_key, layer,
-                                 ws, ws_bytes, stream, num_node, rank, mode == 0 ? tree : PrefixTreeView{nullptr, nullptr});
+                                 ws, ws_bytes, stream, num_node, rank, mode == 0 ? tree : PrefixTreeView{nullptr, nullptr, nullptr});
 }
 
 extern "C" int fgnn_sample_weighted_khop_prefix(const uint32_t *indptr, const uint32_t *indices, const float *prefix,
