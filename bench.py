@@ -1918,6 +1918,10 @@ def run_pipeline_rank(args, rank, world):
                                  "includes its waits on a full ring, a trainer's its waits on an empty one -- each "
                                  "stage ALONE only with --decoupled",
                     "sampler_busy_s": s_loop, "trainer_busy_s": t_loop,
+                    # steady state of the consuming side: the second half of the span's stamps (the first batches of a
+                    # process pay its pool's first allocations; with --decoupled this is the trainers ALONE)
+                    "consumed_second_half_ms_per_batch":
+                        (merged[-1][0] - merged[len(merged) // 2][0]) / max(len(merged) - 1 - len(merged) // 2, 1) * 1e3,
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
                     "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff, "links": links,

@@ -38,6 +38,18 @@ struct fgnn_sampler {
     bool was_used = false;
     bool done_recorded = false, csr_recorded = false;  // the event covers the slot's last batch
     bool expect_cross = false;            // the slot's last reuse came from another stream: record `done` for the next
+    // a batch whose sampling chain has been enqueued and whose tail (the last layer's dedup fill, fix-ups, the table's
+    // generation bump) has not yet: fgnn_sampler_sample_begin / _end
+    struct Pend {
+      bool active = false;
+      uint64_t seq = 0;
+      fgnn_batch *out = nullptr;
+      hipStream_t st = nullptr;           // the chain's stream: the tail goes there too
+      bool ran = false;                   // the batch had seeds: layer 0's fill is owed
+      size_t ecap0 = 0;                   // worst-case edges of layer 0 for THIS batch
+      bool resolved0 = false, inserted0 = false;
+      fgnn::FixTail owed;                 // the remap fix-up the layer-1 fill left for the next launch to carry
+    } pend;
     fgnn::ScanWsHost scan_sample;         // look-back descriptors of the single-pass sampler
     uint32_t *rank_bitmap = nullptr;      // with-replacement samplers: seed ranking bitmap over the node ids (all zero
                                           // between batches), fgnn::RankWs
@@ -311,6 +323,7 @@ struct SeqGuard {
   hipStream_t st;
   bool csr_marked = false;
   bool finished = false;  // the success path has reset the slot's table and closed the slot itself
+  bool detached = false;  // the batch's chain is enqueued, its tail follows in a later call (Slot::pend): nothing to close yet
   // end of the slot's use by this batch: remember the stream, record `done` if slots have been seen to change streams
   void close_slot() {
     fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
@@ -348,6 +361,7 @@ struct SeqGuard {
     s->cv.notify_all();
   }
   ~SeqGuard() {
+    if (detached) return;
     if (!finished) abandon();
     mark_csr();
     std::lock_guard<std::mutex> lk(s->mu);
@@ -362,157 +376,219 @@ struct SeqGuard {
 
 // DoGPUSample (cuda_loops.cc:50-267) for batch `seq`.  owed_fix != null: the caller takes over the last layer's remap
 // fix-up (it lets a later launch of the batch carry it, FixTail); null: the batch's edge lists are final on return.
+//
+// Two halves.  CHAIN: everything up to and including the batch's LAST sampler launch -- for khop2, whose kernels rewrite
+// CSR rows, the part that must run in batch order on the GPU: S(L-1) -> dedup -> ... -> S(0), then the next batch's
+// S(L-1).  TAIL: the last layer's dedup fill, the fix-ups, the table's generation bump (and whatever the caller
+// appends: cache split, gather, message pack) -- nothing of the next batch waits for it.  A caller that enqueues whole
+// batches one after the other puts the next batch's chain BEHIND this batch's tail in its own enqueueing order: ~6
+// launches, 25-40 us of host time during which the GPU has finished S(0) and the chain idles (an arch5 sampler process:
+// 30 us between S(0) of batch k and S(L-1) of batch k + 1, a third of its 100 us per batch).  phase = kChain then kTail
+// (fgnn_sampler_sample_begin / _end) lets a caller enqueue chain(k + 1) BEFORE tail(k); kWhole is both, back to back.
+enum { kWhole = 0, kChain = 1, kTail = 2 };
 int sample_impl(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
-                fgnn_batch *out, void *stream, fgnn::FixTail *owed_fix) {
+                fgnn_batch *out, void *stream, fgnn::FixTail *owed_fix, int phase = kWhole) {
   if (owed_fix) *owed_fix = fgnn::no_fix_tail();
-  if (!s || !out || out->owner != s || (!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)
-    return FGNN_EINVAL;
+  const bool do_chain = phase != kTail, do_tail = phase != kChain;
+  if (!s || !out || out->owner != s) return FGNN_EINVAL;
+  if (do_chain && ((!d_seeds && num_seeds) || num_seeds > s->cfg.max_batch_size)) return FGNN_EINVAL;
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t L = s->cfg.num_layers;
   const bool mutates = s->cfg.sample_type == FGNN_KHOP2;
   const bool ordered = mutates && s->opt_unordered == 0;
-  {
+  fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
+  if (do_chain) {
     // the slot is free once call seq - kSlots has returned (its device work is ordered below)
     std::unique_lock<std::mutex> lk(s->mu);
     // sequence numbers must be consecutive and used once; a gap would wait forever, so give up loudly instead
     if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return seq < s->returned + kSlots; })) return FGNN_EINVAL;
     if (seq < s->returned) return FGNN_EINVAL;
+  } else if (!sl.pend.active || sl.pend.seq != seq || sl.pend.out != out || sl.pend.st != st) {
+    return FGNN_EINVAL;  // no chain of this batch is waiting for its tail (on this stream)
   }
   SeqGuard guard{s, seq, st};
+  if (!do_chain) {
+    guard.csr_marked = true;  // (the chain half has passed the CSR on)
+    sl.pend.active = false;
+  }
   fgnn::ScanErrorSink sink(&out->d_meta->overflow);  // a timed-out cross-workgroup wait marks the batch invalid
-  fgnn_sampler::Slot &sl = s->slot[seq % kSlots];
   fgnn_hashtable *ht = sl.ht;
   uint32_t *tmp_dst = sl.tmp_dst;
   void *ws = sl.ws;
-  out->num_output = num_seeds;
-  out->meta_copied = false;
-  // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
-  // stream, by the slot's event otherwise
-  sl.expect_cross = sl.was_used && sl.last_st != st;
-  // Events are recorded where the LAST hand-over crossed streams (the guess for the next one).  A hand-over that crosses
-  // without a recorded event -- a change of pattern: the pre-sampling epoch's stream -> the batch streams -- waits for
-  // the device instead.  (Until round 5 the event was recorded late on the other stream's handle, which the caller may
-  // have destroyed by then: a dangling hipStream_t is undefined behaviour, not an error return.)
-  if (sl.expect_cross) {
-    if (sl.done_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
-    else FGNN_HIP_CHECK(hipDeviceSynchronize());
-  }
-  if (ordered && seq > 0) {
-    // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
-    {
-      std::unique_lock<std::mutex> lk(s->mu);
-      if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
-    }
-    fgnn_sampler::Slot &prev = s->slot[(seq - 1) % kSlots];
-    const bool cross = prev.last_st != st;
-    s->csr_cross.store(cross, std::memory_order_relaxed);  // this batch records its own hand-over if it needed one
-    if (cross) {
-      if (prev.csr_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
-      else FGNN_HIP_CHECK(hipDeviceSynchronize());  // change of pattern (see above)
-    }
-  }
-  // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
-  int rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
-  if (rc != FGNN_OK) return rc;
-  // Reset state + FillWithUnique(seeds) + output_nodes copy + summary header: done by the first sampler launch itself
-  // for the k-hop samplers (BatchStart), by one small launch otherwise
+  int rc = FGNN_OK;
   const bool khop_fused = s->cfg.sample_type == FGNN_KHOP2 || s->cfg.sample_type == FGNN_KHOP0;
-  const bool start_in_sampler = khop_fused && num_seeds > 0;
-  if (!start_in_sampler) {
-    rc = fgnn_hashtable_start_batch(ht, d_seeds, num_seeds, out->output_nodes, out->d_meta, batch_key, (uint32_t)L,
-                                    stream);
-    if (rc != FGNN_OK) return rc;
-  }
-
   // a layer's remap fix-up is not launched by itself: the next fill's insert launch carries it (FixTail) -- nothing of
   // the next layer's sampling reads the remapped edges -- and the last layer's goes to the caller or runs at the end
   fgnn::FixTail owed = fgnn::no_fix_tail();
-  // Samplers that never look the dedup table up (all but the fused k-hop ones) may run EVERY fill through the
-  // partitioned, table-free path -- decided once per batch: if one layer's worst case is too large for it (beyond the
-  // one-launch count+assign, ~12.6 M items), a fill that fell back to the global insert would dedup against a table the
-  // earlier partitioned fills never wrote to.  Then every fill but the last takes the global path
-  bool table_free = !khop_fused;
-  for (size_t l = L, ic = num_seeds; table_free && l-- > 0;) {
-    const size_t ec = ic * s->cfg.fanout[l];
-    table_free = ec == 0 || fgnn::hashtable_can_partition(ht, ec);
-    ic += ec;
-  }
-  const uint32_t *cur = d_seeds;
-  const uint32_t *d_cur_n = nullptr;  // first layer: host count
-  size_t cur_n_host = num_seeds;
-  size_t in_cap = num_seeds;          // tighter than the create-time worst case when the batch is short
-  for (long l = (long)L - 1; l >= 0 && num_seeds; --l) {
-    const size_t fan = s->cfg.fanout[l];
-    const size_t ecap = in_cap * fan;
-    bool resolved = false, split = false;
+  bool ran = false, resolved0 = false, inserted0 = false;
+  size_t ecap0 = 0;
+
+  // FillWithDuplicates + remap of layer l; its last pass also records num_dst / num_src / num_input of the layer
+  auto fill = [&](long l, size_t ecap, bool inserted, bool resolved, bool table_free) -> int {
     size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
-    if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX || s->cfg.sample_type == FGNN_KHOP1 ||
-        s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
-    {
-      // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
-      // FGNN_RANK_BITMAP=0 (profiling build, A/B only): order the seeds with scan.hip's sort like the stateless
-      // C entry points
-      static const bool use_rank = fgnn::tune_int("FGNN_RANK_BITMAP", 1) != 0;
-      const fgnn::RankWs rank{use_rank ? sl.rank_bitmap : nullptr, &sl.scan_sample};
-      rc = fgnn::sample_with_replacement_ex(
-          s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
-          s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX ? s->cfg.prob_prefix : s->cfg.prob_table, s->cfg.alias_table,
-          cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key,
-          (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, rank.bitmap ? &rank : nullptr,
-          fgnn::prefix_tree_view(s->ptree));
+    fgnn::FixTail mine = fgnn::no_fix_tail();
+    const int r = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
+                                               LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
+                                                            &out->d_meta->num_input},
+                                               inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed,
+                                               table_free && l != 0);  // (the last fill decides for itself: nothing follows it)
+    owed = mine;
+    return r;
+  };
+
+  if (do_chain) {
+    out->num_output = num_seeds;
+    out->meta_copied = false;
+    // the slot's scratch and table were last used kSlots batches ago: ordered by the stream itself when that was this
+    // stream, by the slot's event otherwise
+    sl.expect_cross = sl.was_used && sl.last_st != st;
+    // Events are recorded where the LAST hand-over crossed streams (the guess for the next one).  A hand-over that crosses
+    // without a recorded event -- a change of pattern: the pre-sampling epoch's stream -> the batch streams -- waits for
+    // the device instead.  (Until round 5 the event was recorded late on the other stream's handle, which the caller may
+    // have destroyed by then: a dangling hipStream_t is undefined behaviour, not an error return.)
+    if (sl.expect_cross) {
+      if (sl.done_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, sl.done, 0));
+      else FGNN_HIP_CHECK(hipDeviceSynchronize());
     }
-    else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
-      rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
-                                   cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
-                                   s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream, &sl.scan_sample);
-    else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
-      // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
-      rc = fgnn::sample_random_walk_ex(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
-                                       s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
-                                       d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
-                                       stream, &sl.scan_sample);
-    else {
-      // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
-      const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
-      const bool first = start_in_sampler && l == (long)L - 1;
-      // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one.  khop2 rewrites CSR rows,
-      // so the sampler kernels of consecutive batches form ONE chain however the batches overlap: layer-(L-1) sampler
-      // -> its dedup -> ... -> layer-0 sampler -> next batch.  The layer-0 launch is the long one, and half of it is
-      // the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's sampling
-      // starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more launch
-      // and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt).  Not when this launch also inserts
-      // the seeds: their local ids would replace pending edges without a note.
-      split = ordered && l == 0 && !first && s->opt_split_l0 != 0;
-      if (split)
-        rc = fgnn::sample_khop_plain(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
-                                     out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
-                                     stream, &sl.scan_sample);
-      else {
-        // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
-        resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
-        rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
-                               out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes,
-                               stream, &sl.scan_sample, first ? &start : nullptr, resolved);
+    if (ordered && seq > 0) {
+      // khop2 swaps CSR entries in place: its kernels run in batch order even when batches overlap
+      {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (!s->cv.wait_for(lk, std::chrono::seconds(60), [&] { return s->csr_passed >= seq; })) return FGNN_EINVAL;
+      }
+      fgnn_sampler::Slot &prev = s->slot[(seq - 1) % kSlots];
+      const bool cross = prev.last_st != st;
+      s->csr_cross.store(cross, std::memory_order_relaxed);  // this batch records its own hand-over if it needed one
+      if (cross) {
+        if (prev.csr_recorded) FGNN_HIP_CHECK(hipStreamWaitEvent(st, prev.csr, 0));
+        else FGNN_HIP_CHECK(hipDeviceSynchronize());  // change of pattern (see above)
       }
     }
+    // new nodes are appended straight into the batch's input_nodes buffer (input_nodes = unique, cuda_loops.cc:258)
+    rc = fgnn_hashtable_set_n2o(ht, out->input_nodes);
     if (rc != FGNN_OK) return rc;
-    if (mutates && l == 0) guard.pass_csr(true);  // last sampler kernel of this batch: the next batch may touch the CSR
-    const bool inserted = khop_fused && !split;
-    // FillWithDuplicates + remap; its last pass also records num_dst / num_src / num_input of the layer
-    fgnn::FixTail mine = fgnn::no_fix_tail();
-    rc = hashtable_fill_duplicates_ex(ht, tmp_dst, 0, d_ne, ecap, out->row[l], ws, s->ws_bytes, stream,
-                                      LayerSummary{&out->d_meta->num_dst[l], &out->d_meta->num_src[l],
-                                                   &out->d_meta->num_input},
-                                      inserted, nullptr, /*final_fill=*/l == 0, resolved, &mine, &owed,
-                                      table_free && l != 0);  // (the last fill decides for itself: nothing follows it)
-    if (rc != FGNN_OK) return rc;
-    owed = mine;
-    in_cap += ecap;
-    cur = out->input_nodes;
-    d_cur_n = fgnn_hashtable_d_num_items(ht);
-    cur_n_host = 0;
+    // Reset state + FillWithUnique(seeds) + output_nodes copy + summary header: done by the first sampler launch itself
+    // for the k-hop samplers (BatchStart), by one small launch otherwise
+    const bool start_in_sampler = khop_fused && num_seeds > 0;
+    if (!start_in_sampler) {
+      rc = fgnn_hashtable_start_batch(ht, d_seeds, num_seeds, out->output_nodes, out->d_meta, batch_key, (uint32_t)L,
+                                      stream);
+      if (rc != FGNN_OK) return rc;
+    }
+    // Samplers that never look the dedup table up (all but the fused k-hop ones) may run EVERY fill through the
+    // partitioned, table-free path -- decided once per batch: if one layer's worst case is too large for it (beyond the
+    // one-launch count+assign, ~12.6 M items), a fill that fell back to the global insert would dedup against a table the
+    // earlier partitioned fills never wrote to.  Then every fill but the last takes the global path
+    bool table_free = !khop_fused;
+    for (size_t l = L, ic = num_seeds; table_free && l-- > 0;) {
+      const size_t ec = ic * s->cfg.fanout[l];
+      table_free = ec == 0 || fgnn::hashtable_can_partition(ht, ec);
+      ic += ec;
+    }
+    const uint32_t *cur = d_seeds;
+    const uint32_t *d_cur_n = nullptr;  // first layer: host count
+    size_t cur_n_host = num_seeds;
+    size_t in_cap = num_seeds;          // tighter than the create-time worst case when the batch is short
+    for (long l = (long)L - 1; l >= 0 && num_seeds; --l) {
+      const size_t fan = s->cfg.fanout[l];
+      const size_t ecap = in_cap * fan;
+      bool resolved = false, split = false;
+      size_t *d_ne = reinterpret_cast<size_t *>(&out->d_meta->num_edge[l]);
+      if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX || s->cfg.sample_type == FGNN_KHOP1 ||
+          s->cfg.sample_type == FGNN_WEIGHTED_KHOP)
+      {
+        // the frontier is a list of unique node ids: seed order by bitmap ranking, no sort (sample_weighted.hip)
+        // FGNN_RANK_BITMAP=0 (profiling build, A/B only): order the seeds with scan.hip's sort like the stateless
+        // C entry points
+        static const bool use_rank = fgnn::tune_int("FGNN_RANK_BITMAP", 1) != 0;
+        const fgnn::RankWs rank{use_rank ? sl.rank_bitmap : nullptr, &sl.scan_sample};
+        rc = fgnn::sample_with_replacement_ex(
+            s->cfg.sample_type, s->cfg.indptr, s->cfg.indices,
+            s->cfg.sample_type == FGNN_WEIGHTED_KHOP_PREFIX ? s->cfg.prob_prefix : s->cfg.prob_table, s->cfg.alias_table,
+            cur, cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key,
+            (uint32_t)l, ws, s->ws_bytes, stream, s->cfg.num_node, rank.bitmap ? &rank : nullptr,
+            fgnn::prefix_tree_view(s->ptree));
+      }
+      else if (s->cfg.sample_type == FGNN_WEIGHTED_KHOP_HASH_DEDUP)
+        rc = fgnn::sample_hash_dedup(s->cfg.indptr, s->cfg.indices, s->cfg.prob_table, s->cfg.alias_table, cur,
+                                     cur_n_host, d_cur_n, in_cap, fan, out->col[l], tmp_dst, d_ne, FGNN_SRC_LOCAL,
+                                     s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes, stream, &sl.scan_sample);
+      else if (s->cfg.sample_type == FGNN_RANDOM_WALK)
+        // fanout[l] == RunConfig::num_neighbor (CHECK_EQ at cuda_loops.cc:129)
+        rc = fgnn::sample_random_walk_ex(s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, s->cfg.walk_len,
+                                         s->cfg.restart_prob, s->cfg.num_walks, fan, out->col[l], tmp_dst, out->data[l],
+                                         d_ne, FGNN_SRC_LOCAL, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
+                                         stream, &sl.scan_sample);
+      else {
+        // k-hop: the sampler inserts every edge it emits into the dedup table itself (pass 1 of FillWithDuplicates)
+        const fgnn::BatchStart start{ht->n2o, out->output_nodes, out->d_meta, batch_key, (uint32_t)L, (uint32_t)l};
+        const bool first = start_in_sampler && l == (long)L - 1;
+        // khop2's last layer runs as sampler kernel + insert kernel instead of the fused one.  khop2 rewrites CSR rows,
+        // so the sampler kernels of consecutive batches form ONE chain however the batches overlap: layer-(L-1) sampler
+        // -> its dedup -> ... -> layer-0 sampler -> next batch.  The layer-0 launch is the long one, and half of it is
+        // the dedup insert of its edges, which nothing in the chain waits for: split off, the next batch's sampling
+        // starts ~25 us earlier (papers100M shape, three batches in flight: 0.133 -> 0.118 ms per batch; one more launch
+        // and one re-read of the layer's neighbour list; profiles/r02_split_ab.txt).  Not when this launch also inserts
+        // the seeds: their local ids would replace pending edges without a note.
+        split = ordered && l == 0 && !first && s->opt_split_l0 != 0;
+        if (split)
+          rc = fgnn::sample_khop_plain(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
+                                       out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ws, s->ws_bytes,
+                                       stream, &sl.scan_sample);
+        else {
+          // last fill of the batch: the insert hands its outcome to the dedup pass, which then never touches the table
+          resolved = l == 0 && !first && fgnn::hashtable_can_resolve(ht, ecap);
+          rc = sample_khop_fused(mutates, s->cfg.indptr, s->cfg.indices, cur, cur_n_host, d_cur_n, in_cap, fan,
+                                 out->col[l], tmp_dst, d_ne, s->cfg.seed, batch_key, (uint32_t)l, ht, ws, s->ws_bytes,
+                                 stream, &sl.scan_sample, first ? &start : nullptr, resolved);
+        }
+      }
+      if (rc != FGNN_OK) return rc;
+      const bool inserted = khop_fused && !split;
+      if (l == 0) {
+        // last sampler kernel of this batch: the next batch may touch the CSR; the layer's fill belongs to the tail
+        if (mutates) guard.pass_csr(true);
+        ran = true;
+        ecap0 = ecap;
+        resolved0 = resolved;
+        inserted0 = inserted;
+        break;
+      }
+      rc = fill(l, ecap, inserted, resolved, table_free);
+      if (rc != FGNN_OK) return rc;
+      in_cap += ecap;
+      cur = out->input_nodes;
+      d_cur_n = fgnn_hashtable_d_num_items(ht);
+      cur_n_host = 0;
+    }
+    if (mutates) guard.pass_csr(true);  // (a batch without seeds still takes its turn)
+    if (!do_tail) {
+      sl.pend.active = true;
+      sl.pend.seq = seq;
+      sl.pend.out = out;
+      sl.pend.ran = ran;
+      sl.pend.ecap0 = ecap0;
+      sl.pend.resolved0 = resolved0;
+      sl.pend.inserted0 = inserted0;
+      sl.pend.owed = owed;
+      sl.pend.st = st;
+      sl.last_st = st;
+      guard.mark_csr();  // (samplers that do not touch the CSR take their turn here)
+      guard.detached = true;
+      return launch_status(__func__);
+    }
+  } else {
+    ran = sl.pend.ran;
+    ecap0 = sl.pend.ecap0;
+    resolved0 = sl.pend.resolved0;
+    inserted0 = sl.pend.inserted0;
+    owed = sl.pend.owed;
   }
-  if (mutates) guard.pass_csr(true);  // (a batch without seeds still takes its turn)
+  // ---- tail
+  if (ran) {
+    rc = fill(0, ecap0, inserted0, resolved0, false);
+    if (rc != FGNN_OK) return rc;
+  }
   if (owed.mapped) {
     if (owed_fix) *owed_fix = owed;
     else if ((rc = fgnn::hashtable_map_fix(owed, stream)) != FGNN_OK) return rc;
@@ -551,6 +627,35 @@ extern "C" int fgnn_sampler_sample(fgnn_sampler *s, const uint32_t *d_seeds, siz
     seq = s->next_seq++;
   }
   return fgnn_sampler_sample_ordered(s, seq, d_seeds, num_seeds, batch_key, out, stream);
+}
+
+// the two halves of a batch as calls of their own (sample_impl): a caller with several batches in flight enqueues
+// begin(k + 1) BEFORE end(k), so that khop2's cross-batch sampler chain never waits for the host to get through a
+// batch's tail.  end = the tail [+ the cache-index split, which carries the last remap fix-up]; the caller then appends
+// extraction / message pack and fgnn_batch_finish on the same stream.
+extern "C" int fgnn_sampler_sample_begin(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                                         fgnn_batch *out, void *stream, uint64_t *seq_out) {
+  if (!s || !seq_out) return FGNN_EINVAL;
+  uint64_t seq;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    seq = s->next_seq++;
+  }
+  *seq_out = seq;
+  return sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, nullptr, kChain);
+}
+
+extern "C" int fgnn_sampler_sample_begin_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds,
+                                                 size_t num_seeds, uint64_t batch_key, fgnn_batch *out, void *stream) {
+  return sample_impl(s, seq, d_seeds, num_seeds, batch_key, out, stream, nullptr, kChain);
+}
+
+extern "C" int fgnn_sampler_sample_end(fgnn_sampler *s, uint64_t seq, fgnn_batch *out, const uint32_t *cache_table,
+                                       void *stream) {
+  fgnn::FixTail owed = fgnn::no_fix_tail();
+  int rc = sample_impl(s, seq, nullptr, 0, 0, out, stream, cache_table ? &owed : nullptr, kTail);
+  if (rc == FGNN_OK && cache_table) rc = batch_cache_index(out, cache_table, stream, &owed);
+  return rc;
 }
 
 // DoGPUSample + DoGetCacheMissIndex (dist_loops_arch5.cc:86-105: what an arch5 sampler does per batch) in one call, with
@@ -802,6 +907,22 @@ extern "C" int fgnn_sampler_run_range(fgnn_sampler *s, const fgnn_run_plan *p, u
     return FGNN_OK;
   };
   int rc = FGNN_OK;
+  // chain(i) is enqueued BEFORE tail(i - 1) (sample_impl): with whole batches enqueued one after the other the next
+  // batch's first sampler launch sits behind ~6 launches of this batch's tail in the host's order, and on a slow host
+  // khop2's cross-batch chain waits for the host, not for the GPU.  Needs a second buffer (the tail of batch i - 1 is
+  // still owed when batch i starts)
+  const bool pipelined = p->num_batches >= 2;
+  constexpr uint64_t kNone = ~0ull;
+  uint64_t owed_rest = kNone;  // the batch whose chain is enqueued and whose tail is not
+  auto rest = [&](uint64_t i) -> int {  // tail + cache split + extraction + finish of batch i
+    fgnn_batch *b = p->batches[i % p->num_batches];
+    void *st = p->streams[i % p->num_streams];
+    int r = fgnn_sampler_sample_end(s, i, b, p->cache_table, st);
+    if (r == FGNN_OK && p->cached) r = fgnn_batch_extract_cached(b, p->cache_rows, p->full_feat, p->label, st);
+    else if (r == FGNN_OK && (p->feat || p->label)) r = fgnn_batch_extract(b, p->feat, p->label, st);
+    if (r == FGNN_OK) r = fgnn_batch_finish(b, st);
+    return r;
+  };
   for (uint64_t i = first_seq; i < first_seq + count && rc == FGNN_OK; ++i) {
     if (i - first_seq >= p->num_batches && (rc = collect(i - p->num_batches)) != FGNN_OK) break;
     const size_t step = (size_t)(i % steps);
@@ -810,11 +931,23 @@ extern "C" int fgnn_sampler_run_range(fgnn_sampler *s, const fgnn_run_plan *p, u
     fgnn_batch *b = p->batches[i % p->num_batches];
     void *st = p->streams[i % p->num_streams];
     const auto t0 = std::chrono::steady_clock::now();
-    if (p->cached)
+    if (pipelined) {
+      rc = fgnn_sampler_sample_begin_ordered(s, i, p->d_train + b0, n, step, b, st);
+      if (rc == FGNN_OK) {
+        if (owed_rest != kNone) rc = rest(owed_rest);
+        owed_rest = i;
+      }
+    } else if (p->cached)
       rc = fgnn_sampler_run_batch_cached(s, i, p->d_train + b0, n, step, b, p->cache_table, p->cache_rows, p->full_feat,
                                          p->label, st);
     else
       rc = fgnn_sampler_run_batch(s, i, p->d_train + b0, n, step, b, p->cache_table, p->feat, p->label, st);
+    busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (owed_rest != kNone) {  // the last batch's tail (also after an error: its slot must be closed)
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc2 = rest(owed_rest);
+    if (rc == FGNN_OK) rc = rc2;
     busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   // drain: every buffer that still holds an uncollected batch (also after an error: the buffers are reusable afterwards)

@@ -529,6 +529,7 @@ void Engine::BuildCacheTable() {
 }
 
 void Engine::PublishPending() {
+  FlushOwedTail();
   std::unique_lock<std::mutex> lk(pub_mu_);
   pub_cv_.wait(lk, [&] { return pub_q_.empty(); });
 }
@@ -536,12 +537,37 @@ void Engine::PublishPending() {
 void Engine::PublisherLoop() {
   SAM_HIP(hipSetDevice(device_));
   for (;;) {
-    int cur;
+    int cur = -1;
+    bool overdue = false;
     {
       std::unique_lock<std::mutex> lk(pub_mu_);
-      pub_cv_.wait(lk, [&] { return pub_stop_ || !pub_q_.empty(); });
-      if (pub_q_.empty()) return;
-      cur = pub_q_.front();
+      auto ready = [&] { return pub_stop_ || !pub_q_.empty(); };
+      const uint64_t since = tail_since_us_.load(std::memory_order_acquire);
+      if (since == 0) {
+        // (woken by notify_all when a tail becomes owed: the predicate then also holds for "re-evaluate the wait")
+        pub_cv_.wait(lk, [&] { return ready() || tail_since_us_.load(std::memory_order_acquire) != 0; });
+      } else {
+        // a batch's tail is owed to the next sample_once: if none comes (the end of a script's loop), finish it here
+        const uint64_t now = Timer::NowMicro();
+        const uint64_t left = now >= since + kOwedTailUs ? 0 : since + kOwedTailUs - now;
+        if (!pub_cv_.wait_for(lk, std::chrono::microseconds(left + 1), ready)) overdue = true;
+      }
+      if (!pub_q_.empty()) {
+        cur = pub_q_.front();
+        overdue = false;
+      } else if (pub_stop_) {
+        return;
+      }
+    }
+    if (cur < 0) {
+      if (overdue && tail_since_us_.load(std::memory_order_acquire) != 0 &&
+          Timer::NowMicro() >= tail_since_us_.load(std::memory_order_acquire) + kOwedTailUs && enq_mu_.try_lock()) {
+        // (try_lock: a sample_once that is running right now finishes the tail itself)
+        if (tail_owed_ >= 0 && Timer::NowMicro() >= tail_since_us_.load(std::memory_order_acquire) + kOwedTailUs)
+          FinishBatch(tail_owed_);
+        enq_mu_.unlock();
+      }
+      continue;
     }
     PublishSlot(cur);
     {
@@ -594,6 +620,14 @@ void Engine::PublishSlot(int slot) {
   sstat_.pub_rest += t_pub.Passed();
 }
 
+// One call = one batch ENQUEUED, in two halves (fgnn_sampler_sample_begin / _end): this call enqueues the sampling CHAIN
+// of batch k -- for khop2 the kernels that rewrite CSR rows and therefore run in batch order on the GPU -- and only then
+// the TAIL of batch k - 1 (last dedup fill, cache-index split, message pack, hand-over to the publisher thread).  With
+// whole batches enqueued one after the other, the first sampler launch of batch k sat behind ~7 launches and the queue
+// calls of batch k - 1's tail in this thread's order: 30 of a sampler GPU's 100 us per batch were the chain waiting for
+// the host (profiles/r06_a_pipeline_stages.txt).  The batch whose tail is owed is finished by the next call, by
+// whoever asks for published results (PublishPending), or -- when no further call comes: the end of a script's loop --
+// by the publisher thread after kOwedTailUs.
 void Engine::SampleOnceArch5() {
   SAM_HIP(hipSetDevice(device_));
   const uint32_t *d_batch = nullptr;
@@ -609,11 +643,36 @@ void Engine::SampleOnceArch5() {
     if (!publish_thread_.joinable()) publish_thread_ = std::thread([this] { PublisherLoop(); });
   }
   sstat_.slot_wait += t_wait.Passed();
+  std::lock_guard<std::mutex> enq(enq_mu_);  // (the publisher thread finishes an overdue tail under the same lock)
+  Timer t_enq;
   s.started = Timer();
   s.started_us = RC().option_dump_trace ? Timer::NowMicro() : 0;
   s.key = key;
+  SAM_FGNN(fgnn_sampler_sample_begin(sampler_, d_batch, bsize, key, s.fb, s.st, &s.seq));
+  if (tail_owed_ >= 0) FinishBatch(tail_owed_);
+  // Only a sampler PROCESS owes tails.  Where sampler and extractor share a process (arch2-4, arch6) the thread that
+  // asks for published results (samgraph_get_log_*, PublishPending) may be the one that consumes the batches: finishing
+  // an owed tail there can wait for a free slot of the in-process ring, which only that thread's consumption frees
+  if (RC().run_arch == kArch5 && dist_type_ == DistType::Sample) {
+    tail_owed_ = cur;
+    tail_since_us_.store(Timer::NowMicro(), std::memory_order_release);
+    pub_cv_.notify_all();  // the publisher thread now waits with a time limit
+  } else {
+    FinishBatch(cur);
+  }
+  sstat_.enqueue += t_enq.Passed();
+  ++sstat_.n;
+  // (the reference drains its pipeline at the end of an epoch because the next call reshuffles the seed array in place,
+  // dist_loops_arch5.cc:131-137; the shuffler here keeps the previous epoch's device array alive instead)
+}
+
+// the batch in slot `cur` has its chain enqueued: tail, cache-index split, message pack, hand-over.  enq_mu_ is held
+void Engine::FinishBatch(int cur) {
+  Slot &s = slots_[cur];
+  tail_owed_ = -1;
+  tail_since_us_.store(0, std::memory_order_release);
   const bool use_cache = RC().UseGPUCache();
-  SAM_FGNN(fgnn_sampler_sample_indexed(sampler_, d_batch, bsize, key, s.fb, use_cache ? d_cache_table_ : nullptr, s.st));
+  SAM_FGNN(fgnn_sampler_sample_end(sampler_, s.seq, s.fb, use_cache ? d_cache_table_ : nullptr, s.st));
   // serialise straight into a queue slot (MessageTaskQueue::Send, task_queue.cc:378-386)
   void *slot = mq_->GetPtr(&s.mq_key);
   if (!slot) return;  // this process is shutting down (MemoryQueue::Close): the batch is dropped, Shutdown syncs its stream
@@ -656,10 +715,18 @@ void Engine::SampleOnceArch5() {
     pub_q_.push_back(cur);
   }
   pub_cv_.notify_all();
-  sstat_.enqueue += s.started.Passed();
-  ++sstat_.n;
-  // (the reference drains its pipeline at the end of an epoch because the next call reshuffles the seed array in place,
-  // dist_loops_arch5.cc:131-137; the shuffler here keeps the previous epoch's device array alive instead)
+}
+
+// a batch whose chain is enqueued and whose tail is not: finish it now (callers that need everything published)
+void Engine::FlushOwedTail() {
+  // nothing owed (always the case where sampler and extractor share a process): do not even wait for the enqueueing
+  // thread -- it may be waiting for a free ring slot that only the CALLER's consumption frees
+  if (tail_since_us_.load(std::memory_order_acquire) == 0) return;
+  std::lock_guard<std::mutex> enq(enq_mu_);
+  if (tail_owed_ >= 0) {
+    SAM_HIP(hipSetDevice(device_));
+    FinishBatch(tail_owed_);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,6 +1244,7 @@ void Engine::Shutdown() {
   if (sample_thread_.joinable()) sample_thread_.join();
   if (extract_thread_.joinable()) extract_thread_.join();
   if (publish_thread_.joinable()) {  // publishes what is still in flight, then stops
+    FlushOwedTail();
     {
       std::lock_guard<std::mutex> lk(pub_mu_);
       pub_stop_ = true;

@@ -154,6 +154,8 @@ class Engine {
   void TrainerOnce();
   void ExtractLoop(size_t count);
   struct ExtractCtx;
+  void FinishBatch(int slot);
+  void FlushOwedTail();
   void TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key);
   void TrainerComplete(ExtractCtx &x);
   void BuildTrainerCache();
@@ -221,6 +223,7 @@ class Engine {
     Timer started;
     uint64_t started_us = 0;  // SAMGRAPH_DUMP_TRACE: wall clock of the sample_once call
     uint32_t *d_msg_words = nullptr;  // SAMGRAPH_HANDOFF_CHECK: message length left by the pack kernel
+    uint64_t seq = 0;                 // the batch's number in the kernel-level sampler (sample_begin -> sample_end)
   };
   std::vector<Slot> slots_;
   size_t next_slot_ = 0;
@@ -233,6 +236,12 @@ class Engine {
   std::condition_variable pub_cv_;
   std::thread publish_thread_;
   bool pub_stop_ = false;
+  // the batch whose sampling chain is enqueued and whose tail is owed to the next sample_once (eng_engine.cc:
+  // SampleOnceArch5); enq_mu_ serialises the enqueueing thread and the publisher thread's finish of an overdue tail
+  std::mutex enq_mu_;
+  int tail_owed_ = -1;                          // slot index, under enq_mu_
+  std::atomic<uint64_t> tail_since_us_{0};      // wall clock (us) since when; 0: none
+  static constexpr uint64_t kOwedTailUs = 300;  // ~3 batch intervals
 
   // arch5 shared state (created before fork)
   MemoryQueue *mq_ = nullptr;

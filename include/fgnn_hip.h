@@ -463,6 +463,20 @@ int fgnn_sampler_sample_indexed(fgnn_sampler *s, const uint32_t *d_seeds, size_t
  * is this with an internal counter (do not mix the two on one sampler). */
 int fgnn_sampler_sample_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                                 uint64_t batch_key, fgnn_batch *out, void *stream);
+/* A batch in two calls, for callers that keep several batches in flight.  begin: everything up to and including the
+ * batch's LAST sampler launch -- for khop2, whose kernels rewrite CSR rows in batch order, the part the NEXT batch's first
+ * sampler launch waits for on the GPU.  end: the last layer's dedup fill, the fix-ups, the table's reset [+ the cache
+ * index split when cache_table != NULL]; the caller then appends extraction / fgnn_batch_finish on the same stream.
+ * Enqueue begin(k + 1) BEFORE end(k): whole batches enqueued one after the other put the next batch's first sampler
+ * launch behind ~6 launches of this batch's tail in the host's enqueueing order, and the cross-batch chain then waits
+ * for the host (an arch5 sampler process: 30 us of every 100).  begin: internal sequence counter (as fgnn_sampler_sample),
+ * *seq_out = the batch's number for end; begin_ordered: explicit numbers (as fgnn_sampler_sample_ordered).  Results are
+ * those of the one-call forms.  `stream` of end = the stream of begin. */
+int fgnn_sampler_sample_begin(fgnn_sampler *s, const uint32_t *d_seeds, size_t num_seeds, uint64_t batch_key,
+                              fgnn_batch *out, void *stream, uint64_t *seq_out);
+int fgnn_sampler_sample_begin_ordered(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
+                                      uint64_t batch_key, fgnn_batch *out, void *stream);
+int fgnn_sampler_sample_end(fgnn_sampler *s, uint64_t seq, fgnn_batch *out, const uint32_t *cache_table, void *stream);
 /* sample_ordered + cache_index (if cache_table) + extract (if feat/label) + finish in one call. */
 int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seeds, size_t num_seeds,
                            uint64_t batch_key, fgnn_batch *out, const uint32_t *cache_table, const void *feat,
