@@ -108,6 +108,20 @@ def test_rehearsal_line_shows_the_sampler_choice(gpus, rates, want):
     _check_windows(out, gpus, want, 2, 10)
 
 
+def test_pipeline_half_is_importable_without_the_entry_point():
+    """bench.py is the entry point only; the N >= 2 half (benchlib/pipeline.py) and the N = 1 half import and expose their
+    pieces on their own, and bench re-exports the names the tools use"""
+    import importlib
+    pl = importlib.import_module("benchlib.pipeline")
+    assert pl.choose_samplers(8, 0.1, 0.29)[0] == 2 and pl.pipeline_roles(8, "auto") == (2, 6)
+    assert pl.span_margins(5, 6) == (340, 12)
+    sg = importlib.import_module("benchlib.single")
+    assert callable(sg.run_single) and callable(sg.run_extract_leg)
+    import bench
+    assert bench.choose_samplers is pl.choose_samplers and bench.WORKLOADS is pl.WORKLOADS
+    assert len(open(bench.BENCH_PY).read().splitlines()) < 300
+
+
 def test_torchrun_launch():
     """the launch line of the task description: one rank per GPU started by torch.distributed.run"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

@@ -26,6 +26,28 @@ done
 python3 tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/${tag}_pmc_FETCH_SIZE.log > gpurun_out/${tag}_pmc_traffic.json 2> gpurun_out/${tag}_pmc.err
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 head -12 gpurun_out/${tag}_pmc_traffic.json; tail -3 gpurun_out/${tag}_pmc.err
+# config 3's trainer-side leg from KERNEL durations: (a) bench.py's roofline_extract (this GPU samples too), (b) the
+# trainer process of the decoupled 1S+1T run (the trainer drains a full queue alone); rocprofv3's preloaded library is
+# inherited by the rank processes bench.py starts, one trace per process
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/px1 -- python3 bench.py --steps 64 --warmup 5 --windows 1 --no-train-leg --no-cpu-baseline --presample-variants "" > gpurun_out/${tag}_prof_extract_leg.log 2>&1 || exit 1
+python3 - <<P > gpurun_out/${tag}_extract_kernel_stats.md
+import json, subprocess
+l = json.loads([x for x in open("gpurun_out/${tag}_prof_extract_leg.log") if x.startswith("{")][-1])
+r = l["roofline_extract"]
+print("## roofline_extract under rocprofv3 --kernel-trace (presample_epoch %d, hit rate %.4f, %.4f ms per batch in this profiled run)" % (r["presample_epoch"], r["hit_rate"], r["ms_per_step"]))
+print(subprocess.run(["python3", "tools/extract_kernel_rates.py", "gpurun_out/px1", str(r["miss"]["bytes_per_step"]), str(r["cached"]["bytes_per_step"])], capture_output=True, text=True).stdout)
+P
+python3 tools/stats_summary.py gpurun_out/px1 >> gpurun_out/${tag}_extract_kernel_stats.md; rm -rf gpurun_out/px1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/px2 -- python3 bench.py --gpus 2 --decoupled --no-train-leg --no-cpu-baseline > gpurun_out/${tag}_prof_decoupled.log 2>&1 || exit 1
+python3 - <<P >> gpurun_out/${tag}_extract_kernel_stats.md
+import json, subprocess
+l = json.loads([x for x in open("gpurun_out/${tag}_prof_decoupled.log") if x.startswith("{")][-1])
+pl = l["pipeline"]
+rows = l["input_nodes_per_step"]; miss_b = pl["miss"]["bytes_per_step"]; hit_b = (rows - miss_b / 512.0) * (2 * 512 + 8)
+print("\n## the trainer PROCESS of bench.py --gpus 2 --decoupled under rocprofv3 --kernel-trace (it drains a full queue alone; %.4f ms per batch, second half %.4f)" % (l["ms_per_step"], pl["consumed_second_half_ms_per_batch"]))
+print(subprocess.run(["python3", "tools/extract_kernel_rates.py", "gpurun_out/px2", str(miss_b), str(hit_b)], capture_output=True, text=True).stdout)
+P
+rm -rf gpurun_out/px2; cat gpurun_out/${tag}_extract_kernel_stats.md
 timeout -k 10 500 python3 bench.py --gpus 2 --no-cpu-baseline > gpurun_out/${tag}_bench_gpus2.json 2> gpurun_out/${tag}_bench_gpus2.err; echo "bench2 rc=$?"
 tail -c 800 gpurun_out/${tag}_bench_gpus2.err
 python3 tools/show_bench.py gpurun_out/${tag}_bench_gpus2.json | head -60
