@@ -654,6 +654,22 @@ class Sampler:
         _check(load().fgnn_sampler_sample_indexed(self.h, _ptr(seeds), C.c_size_t(seeds.numel()), C.c_uint64(batch_key),
                                                   batch.h, _ptr(cache_table), _stream()), "fgnn_sampler_sample_indexed")
 
+    def sample_begin(self, seq, seeds, batch_key, batch, stream=None):
+        """fgnn_sampler_sample_begin_ordered: the batch's sampling CHAIN (everything up to its last sampler launch).
+        Enqueue begin(k + 1) before end(k) to keep khop2's cross-batch chain busy; `stream` of end = that of begin."""
+        _need_gpu(seeds)
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        _check(load().fgnn_sampler_sample_begin_ordered(self.h, C.c_uint64(seq), _ptr(seeds), C.c_size_t(seeds.numel()),
+                                                        C.c_uint64(batch_key), batch.h, st),
+               "fgnn_sampler_sample_begin_ordered")
+
+    def sample_end(self, seq, batch, cache_table=None, stream=None):
+        """fgnn_sampler_sample_end: the batch's TAIL (last dedup fill, fix-ups, table reset) [+ the cache-index split];
+        extraction / finish are the caller's, on the same stream"""
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        _check(load().fgnn_sampler_sample_end(self.h, C.c_uint64(seq), batch.h, _ptr(cache_table), st),
+               "fgnn_sampler_sample_end")
+
     def run_batch(self, seq, seeds, batch_key, batch, cache_table=None, feat=None, label=None, stream=None):
         """sample + cache index + extract + finish in ONE C call on `stream` (a torch stream; default current).
         Safe to call from several Python threads (ctypes releases the GIL)."""

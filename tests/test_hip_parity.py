@@ -444,6 +444,76 @@ def test_batch_driver_matches_oracle(hip, oracle, kind, fanouts, batch, dim):
     np.testing.assert_array_equal(host_u32(d_indices), o_indices)
 
 
+@pytest.mark.parametrize("kind,fanouts", [("khop2", [10, 5]), ("khop2", [6]), ("khop0", [4, 3, 2]),
+                                          ("weighted_khop_prefix", [3, 4])])
+def test_batch_in_two_halves_matches_oracle(hip, oracle, kind, fanouts):
+    """fgnn_sampler_sample_begin / _end: the sampling chain of batch k + 1 (k + 2) enqueued BEFORE the tail of batch k,
+    batches rotating over three streams -- every batch equals the oracle's sequential replay (khop2: the CSR swaps happen
+    in chain order), the tails in any order; a tail without its chain, or on another stream, is refused."""
+    from fgnn_hip import synth
+    num_node, batch, dim = 60000, 700, 16
+    indptr, indices = synth.powerlaw_csr(num_node, 900000, seed=16)
+    feat = synth.node_features(num_node, dim)
+    table = oracle.cache_table_build(np.random.default_rng(3).permutation(num_node).astype(np.uint32), num_node // 5, num_node)
+    prefix = synth.prob_prefix_table(indptr, indices) if kind == "weighted_khop_prefix" else None
+    d_indices, d_feat, d_table = dev(indices.copy()), dev(feat), dev(table)
+    st = {"khop2": hip.KHOP2, "khop0": hip.KHOP0, "weighted_khop_prefix": hip.WEIGHTED_KHOP_PREFIX}[kind]
+    sampler = hip.Sampler(dev(indptr), d_indices, fanouts, batch, sample_type=st, seed=SEED,
+                          prob_prefix=dev(prefix) if prefix is not None else None)
+    nb = 9
+    batches = [sampler.new_batch(dim, hip.F32, hip.I64) for _ in range(6)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    seeds = [_seeds(batch if b % 4 else 1 + b, num_node, seed=300 + b) for b in range(nb)]
+    d_seeds = [dev(x) for x in seeds]
+
+    def begin(b):
+        sampler.sample_begin(b, d_seeds[b], 50 + b, batches[b % 6], stream=streams[b % 3])
+
+    def end(b):
+        with torch.cuda.stream(streams[b % 3]):
+            sampler.sample_end(b, batches[b % 6], d_table, stream=streams[b % 3])
+            batches[b % 6].extract(d_feat, None)
+            batches[b % 6].finish()
+    with pytest.raises(hip.FgnnError):
+        sampler.sample_end(0, batches[0], d_table, stream=streams[0])  # no chain waits for this tail
+    # chains run up to two batches ahead of the tails; the tails of a pair in reverse order
+    begin(0)
+    begin(1)
+    with pytest.raises(hip.FgnnError):
+        sampler.sample_end(0, batches[0], d_table, stream=streams[1])  # not the chain's stream
+    order = [("b", 2), ("e", 1), ("e", 0), ("b", 3), ("e", 2), ("b", 4), ("b", 5), ("e", 4), ("e", 3), ("e", 5)]
+    done = set()
+    got = {}
+    oht = oracle.HashTable(num_node, sampler.max_nodes)
+    rng = oracle.make_rng(oracle.RNG_PHILOX, SEED)
+    o_indices = indices.copy()
+    okind = {"khop2": oracle.KHOP2, "khop0": oracle.KHOP0, "weighted_khop_prefix": oracle.WEIGHTED_KHOP_PREFIX}[kind]
+    want = [oracle.do_sample(indptr, o_indices, seeds[b], fanouts, okind, rng, 50 + b, oht, prob_prefix=prefix)
+            for b in range(6)]
+
+    def check(b):
+        bt = batches[b % 6]
+        m = bt.wait()
+        assert m.key == 50 + b and m.overflow == 0
+        for li in range(len(fanouts)):
+            row, col, nsrc, ndst = bt.graph(li)
+            g = want[b]["graphs"][li]
+            assert (len(row), nsrc, ndst) == (g["num_edge"], g["num_src"], g["num_dst"])
+            np.testing.assert_array_equal(host_u32(row), g["row"])
+            np.testing.assert_array_equal(host_u32(col), g["col"])
+        nodes = host_u32(bt.input_nodes())
+        np.testing.assert_array_equal(nodes, want[b]["input_nodes"])
+        for gotten, w in zip(bt.cache_index_arrays(), oracle.get_miss_cache_index(table, nodes)):
+            np.testing.assert_array_equal(host_u32(gotten), w)
+        assert bt.feat().cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
+    for what, b in order:
+        (begin if what == "b" else end)(b)
+    for b in range(6):
+        check(b)
+    if kind == "khop2":
+        np.testing.assert_array_equal(host_u32(d_indices), o_indices)
+
+
 @pytest.mark.parametrize("fanout", [1, 5, 15])
 def test_weighted_prefix_matches_oracle(hip, oracle, fanout):
     from fgnn_hip import synth
