@@ -1007,7 +1007,7 @@ void Engine::TrainerIssue(ExtractCtx &x, const void *taken, size_t taken_key) {
     j.label_dtype = FGNN_I64;
     j.segs = segs;
     j.num_segs = ua.num_segments;
-    j.link_workgroups = ExtractorSharesGpu() ? FGNN_LINK_WGS_SHARED : FGNN_LINK_WGS_DEDICATED;
+    j.link_workgroups = ExtractLinkWgs();
     const size_t grid = fgnn_extract_fused_grid(&j);
     if (grid) {
       // per-band durations (kLogL3CacheCombine{Miss,Cache}Time): every workgroup posts its start / end clock into

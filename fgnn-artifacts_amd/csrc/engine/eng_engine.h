@@ -119,6 +119,12 @@ class Engine {
     if (forced >= 0) return forced;
     return sampler_ != nullptr && device_ == tdevice_;
   }
+  // workgroups of the one-launch extraction's link band (SAMGRAPH_EXTRACT_LINK_WGS=n fixes it: A/B runs)
+  int ExtractLinkWgs() const {
+    static const int forced = [] { const char *e = getenv("SAMGRAPH_EXTRACT_LINK_WGS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    return ExtractorSharesGpu() ? FGNN_LINK_WGS_SHARED : FGNN_LINK_WGS_DEDICATED;
+  }
   uint32_t FeatRowMask() const {
     return RC().option_empty_feat ? (uint32_t)((1ull << RC().option_empty_feat) - 1) : 0xFFFFFFFFu;
   }

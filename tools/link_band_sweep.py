@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--batches", type=int, default=120)
     ap.add_argument("--streams", type=int, default=4)
-    ap.add_argument("--bands", default="16,32,64,96,128,192,256,512")
+    ap.add_argument("--bands", default="1,2,4,8,16,32,64,128,256,512")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -65,8 +65,25 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / batches * 1e3
 
+    for b in bufs:  # per-workgroup start / end clocks of the launch (pinned: the kernel posts them, nothing is copied)
+        b["stamps"] = torch.zeros(2 * 4096, dtype=torch.int64).pin_memory()
+    shape = {}
+
     def fused(link):
-        return lambda b: lib.extract_fused(b["out"], host, cache, b["ms"], b["md"], b["cs"], b["cd"], link_workgroups=link)
+        def f(b):
+            shape["grid"], shape["link"] = lib.extract_fused(b["out"], host, cache, b["ms"], b["md"], b["cs"], b["cd"],
+                                                             link_workgroups=link, stamps=b["stamps"])
+        return f
+
+    def band_ms():
+        """(link band, HBM band) duration of the buffers' last launches: first start .. last end (100 MHz clock)"""
+        ln, hb = [], []
+        for b in bufs:
+            st = b["stamps"][:2 * shape["grid"]].view(-1, 2).numpy()
+            for lo, hi, acc in ((0, shape["link"], ln), (shape["link"], shape["grid"], hb)):
+                if hi > lo:
+                    acc.append((st[lo:hi, 1].max() - st[lo:hi, 0].min()) * 1e-5)
+        return float(np.mean(ln)) if ln else 0.0, float(np.mean(hb)) if hb else 0.0
 
     def two_launch(shared):
         def f(b):
@@ -76,10 +93,14 @@ def main():
 
     res = []
 
-    def report(name, ms):
+    def report(name, ms, bands=None):
         gbs = n_miss * row_b / (ms * 1e-3) / 1e9
-        res.append({"variant": name, "ms_per_batch": ms, "link_GBps": gbs, "link_frac_of_64": gbs / 64.0})
-        print("%-34s %.4f ms/batch   link %.1f GB/s (%.2f of 64)" % (name, ms, gbs, gbs / 64.0), flush=True)
+        res.append({"variant": name, "ms_per_batch": ms, "link_GBps": gbs, "link_frac_of_64": gbs / 64.0, "band_ms": bands})
+        extra = ""
+        if bands:
+            hbm_gbs = n_hit * (2 * row_b + 8) / (bands[1] * 1e-3) / 1e9 if bands[1] else 0.0
+            extra = "   link band %.3f ms, HBM band %.3f ms = %.0f GB/s" % (bands[0], bands[1], hbm_gbs)
+        print("%-34s %.4f ms/batch   link %.1f GB/s (%.2f of 64)%s" % (name, ms, gbs, gbs / 64.0, extra), flush=True)
 
     print("# %d rows/batch, hit rate %.3f: %d miss rows (%.1f MB over the link), %d hit rows; %d batches in flight"
           % (a.rows, a.hit_rate, n_miss, n_miss * row_b / 1e6, n_hit, a.streams), flush=True)
@@ -92,7 +113,8 @@ def main():
         for band in [int(x) for x in a.bands.split(",")]:
             f = fused(band)
             run(f, 16)
-            report("fused band=%d unroll=%d" % (band, ul), min(run(f, a.batches) for _ in range(3)))
+            t = min(run(f, a.batches) for _ in range(3))
+            report("fused band=%d unroll=%d" % (band, ul), t, band_ms())
     # the band alone (no hit rows): what the link gives this access pattern
     os.environ["FGNN_FUSED_LINK_UNROLL"] = "8"
     for band in (64, 128, 256):
