@@ -655,7 +655,11 @@ void Engine::SampleOnceArch5() {
   // an owed tail there can wait for a free slot of the in-process ring, which only that thread's consumption frees
   if (RC().run_arch == kArch5 && dist_type_ == DistType::Sample) {
     tail_owed_ = cur;
-    tail_since_us_.store(Timer::NowMicro(), std::memory_order_release);
+    {  // (under the publisher's mutex: it either sees the value when it checks its wait condition or is already waiting
+       // when the notification comes -- a lost wake-up would leave the last batch of a script's loop unpublished)
+      std::lock_guard<std::mutex> lk(pub_mu_);
+      tail_since_us_.store(Timer::NowMicro(), std::memory_order_release);
+    }
     pub_cv_.notify_all();  // the publisher thread now waits with a time limit
   } else {
     FinishBatch(cur);

@@ -381,6 +381,12 @@ def _sampler_proc(worker, num_sampler, barrier, err):
         for _ in range(NUM_EPOCH):
             for _ in range(local):
                 sam.sample_once()
+        # tests: a script whose sampler loop ends and then WAITS (an epoch barrier) without calling anything -- the last
+        # batch's tail must be finished and published by the engine itself (publisher thread), not by the next call
+        linger = float(os.environ.get("FGNN_TEST_SAMPLER_LINGER", "0"))
+        if linger:
+            import time
+            time.sleep(linger)
         sam.shutdown()
     except BaseException:
         traceback.print_exc()
@@ -412,10 +418,14 @@ def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample
         if pipeline:
             sam.extract_start(mine)
         seen = miss_total = 0
+        import time
+        max_wait = 0.0
         for _ in range(mine):
             if not pipeline:
                 sam.sample_once()
+            t_get = time.time()
             key = sam.get_next_batch()
+            max_wait = max(max_wait, time.time() - t_get)
             seeds, task, rep = expected.pop(key)
             check_batch(sam, key, seeds, task, rep, "arch5 key %d" % key)
             if presample:
@@ -433,8 +443,8 @@ def _trainer_proc(worker, num_trainer, num_sampler, path, sample_type, presample
         if num_trainer == 1:
             assert not expected
         sam.shutdown()
-        print("trainer %d checked %d batches, %d miss rows (rank head %s)" % (worker, seen, miss_total,
-                                                                              None if rank is None else rank[:4]))
+        print("trainer %d checked %d batches, %d miss rows (rank head %s), longest wait for a batch %.3f s"
+              % (worker, seen, miss_total, None if rank is None else rank[:4], max_wait))
     except BaseException:
         traceback.print_exc()
         err.value = 1

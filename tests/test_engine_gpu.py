@@ -150,6 +150,19 @@ def test_arch5_pipelined_trainer_on_a_tiny_queue(tmp_path, mq_bytes, ns, nt):
     assert "ok" in out
 
 
+def test_last_batch_of_a_sampler_loop_is_published_without_a_further_call(tmp_path):
+    """An arch5 sampler enqueues the sampling chain of batch k and the TAIL of batch k - 1 per sample_once (the chain
+    must not wait for the host to get through a tail).  The reference's scripts end a sampler's epoch loop with a
+    barrier while the trainers still need the epoch's last batch: that batch's tail is finished by the engine's
+    publisher thread 300 us after the last call -- here the samplers sit for four seconds after their loops before
+    they call shutdown, and no trainer ever waits anywhere near that long for a batch."""
+    import re
+    out = _run(tmp_path, "arch5", "khop2", 2, 1, 0.25, "pipeline", env={"FGNN_TEST_SAMPLER_LINGER": "4"})
+    assert "ok" in out
+    waits = [float(x) for x in re.findall(r"longest wait for a batch ([0-9.]+) s", out)]
+    assert waits and max(waits) < 2.0, out[-2000:]
+
+
 @pytest.mark.parametrize("slots", [None, 0])
 def test_handoff_check_verifies_and_counts(tmp_path, slots):
     """SAMGRAPH_HANDOFF_CHECK=n: every sampler appends a checksum to its first n messages, the receiving trainer
