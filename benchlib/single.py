@@ -76,6 +76,7 @@ def run_single(args):
     t_setup = time.time() - t_setup
 
     metas, gather_ms, host_busy = [], [], [0.0] * NT
+    gather_clock_ms = []  # the same launches by their own clock stamps (native loop only)
     cached_ms = []
     lock = threading.Lock()
 
@@ -146,6 +147,7 @@ def run_single(args):
         if timed:
             metas.extend(ms)
             gather_ms.extend(t[0] if mode[0] == "full" else -1.0 for t in tm)
+            gather_clock_ms.extend(t[1] if mode[0] == "full" else -1.0 for t in tm)
             if mode[0] == "cached":
                 cached_ms.extend(tm)
 
@@ -203,11 +205,12 @@ def run_single(args):
     for r in range(R):
         metas.clear()
         gather_ms.clear()
+        gather_clock_ms.clear()
         for t in range(NT):
             host_busy[t] = 0.0
         el = timed_region(seq0 + r * args.steps, seq0 + (r + 1) * args.steps)
         assert len(metas) == args.steps, (len(metas), args.steps)
-        windows.append(dict(elapsed=el, metas=list(metas), gather_ms=list(gather_ms),
+        windows.append(dict(elapsed=el, metas=list(metas), gather_ms=list(gather_ms), gather_clock_ms=list(gather_clock_ms),
                             host_enqueue_ms=sum(host_busy) / args.steps * 1e3))
     order = sorted(range(R), key=lambda r: windows[r]["elapsed"])
     med = windows[order[(R - 1) // 2]]  # the median window (the slower of the middle two for an even R)
@@ -215,6 +218,7 @@ def run_single(args):
     host_enqueue_ms = med["host_enqueue_ms"]  # of that timed window only
     metas[:] = med["metas"]
     gather_ms[:] = med["gather_ms"]
+    gather_clock_t = [x for x in med["gather_clock_ms"] if x >= 0]
     window_ms = [wd["elapsed"] / args.steps * 1e3 for wd in windows]
     del windows
 
@@ -377,6 +381,13 @@ def run_single(args):
                      if pmc_file else None,
                      "traffic_over_algorithmic_per_kernel": per_kernel,
                      "kernel": "gather_rows16_kernel (feature gather)", "avg_launch_ms": gather_avg_ms,
+                     # the same launches by the kernel's OWN clock (first workgroup's start .. last one's end, 100 MHz
+                     # words posted to pinned memory): what a kernel trace reports as the duration -- the HIP-event
+                     # bracket above also holds the launch gap and the wait for wave slots behind other batches' kernels
+                     "kernel_clock": ({"avg_kernel_ms": float(np.mean(gather_clock_t)),
+                                       "achieved": gather_feat_bytes / len(metas) / (float(np.mean(gather_clock_t)) * 1e-3) / 1e9,
+                                       "frac": gather_feat_bytes / len(metas) / (float(np.mean(gather_clock_t)) * 1e-3) / 1e9
+                                       / HBM_PEAK_GBS, "launches": len(gather_clock_t)} if gather_clock_t else None),
                      "timed_launches": len(gather_ms),
                      "timing": "HIP events on the launch's own stream around every third batch's gather inside the timed "
                                "window (event records on every batch cost the step 3 %)",

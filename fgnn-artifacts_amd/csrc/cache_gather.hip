@@ -212,6 +212,11 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
                                                                const uint32_t *d_n, size_t cap, uint32_t cpr_rt,
                                                                uint32_t src_mask, GatherTail tail) {
   const uint32_t cpr = CPR ? (uint32_t)CPR : cpr_rt;
+  const bool stamped = tail.stamps != nullptr && blockIdx.x < kGatherStampBlocks;
+  if (stamped && threadIdx.x == 0) {
+    tail.stamps[2 * blockIdx.x] = wall_clock64();
+    if (blockIdx.x == 0) tail.stamps[2 * kGatherStampBlocks] = gridDim.x;
+  }
   if (tail.label_out) {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < tail.num_label; i += stride) {
@@ -280,6 +285,10 @@ __global__ __launch_bounds__(kBlock) void gather_rows16_kernel(chunk16 *__restri
         out[drow * cpr + col] = src[srow * cpr + col];
       }
     }
+  }
+  if (stamped) {
+    __syncthreads();
+    if (threadIdx.x == 0) tail.stamps[2 * blockIdx.x + 1] = wall_clock64();
   }
 }
 
@@ -584,7 +593,7 @@ int fgnn::gather_rows_ex(void *out, const void *src, const uint32_t *src_index, 
                          const uint32_t *d_n, size_t n_cap, size_t dim, int dtype, uint32_t src_row_mask,
                          void *stream, const GatherTail *tail_in, size_t host_grid, size_t wg_per_cu_in) {
   auto s = static_cast<hipStream_t>(stream);
-  const GatherTail tail = tail_in ? *tail_in : GatherTail{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+  const GatherTail tail = tail_in ? *tail_in : GatherTail{nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
   if (tail_in && !gather_takes_tail(out, src, d_n ? n_cap : n, dim, dtype)) return FGNN_EINVAL;
   const size_t esz = dtype_bytes(dtype);
   size_t cap = d_n ? n_cap : n;

@@ -96,6 +96,7 @@ struct fgnn_batch {
                                           // fgnn_batch_extract / the miss-row gather of fgnn_batch_extract_cached,
                                           // t1..t2 the cached-row gather
   bool timed2;
+  bool stamped;                           // the last fgnn_batch_extract launch posted its workgroups' clocks to h_stamps
   unsigned long long *h_stamps;           // pinned: per-workgroup start / end clocks of the one-launch cached extraction
   size_t stamp_cap, stamp_grid, stamp_link;
   bool timing, timed;
@@ -711,6 +712,19 @@ extern "C" float fgnn_batch_gather_ms(fgnn_batch *b) {
   return ms;
 }
 
+extern "C" float fgnn_batch_gather_kernel_ms(fgnn_batch *b) {
+  if (!b || !b->timed || !b->stamped || !b->h_stamps) return -1.0f;
+  unsigned long long n = b->h_stamps[2 * fgnn::kGatherStampBlocks];
+  if (n == 0) return -1.0f;
+  if (n > fgnn::kGatherStampBlocks) n = fgnn::kGatherStampBlocks;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (unsigned long long k = 0; k < n; ++k) {
+    t0 = b->h_stamps[2 * k] < t0 ? b->h_stamps[2 * k] : t0;
+    t1 = b->h_stamps[2 * k + 1] > t1 ? b->h_stamps[2 * k + 1] : t1;
+  }
+  return t1 >= t0 ? (float)((double)(t1 - t0) * 1e-5) : -1.0f;
+}
+
 extern "C" int fgnn_batch_extract_cached_ms(fgnn_batch *b, float out[2]) {
   if (!b || !out) return FGNN_EINVAL;
   out[0] = out[1] = -1.0f;
@@ -752,7 +766,7 @@ namespace {
 bool make_tail(fgnn_batch *b, const void *src, const void *label, fgnn::GatherTail *t) {
   if (!fgnn::gather_takes_tail(b->feat, src, b->feat_rows_cap, b->feat_dim, b->feat_dtype)) return false;
   *t = fgnn::GatherTail{nullptr, nullptr, nullptr, 0, 0, reinterpret_cast<uint32_t *>(b->h_meta),
-                        reinterpret_cast<const uint32_t *>(b->d_meta), (uint32_t)(sizeof(fgnn_batch_meta) / 4)};
+                        reinterpret_cast<const uint32_t *>(b->d_meta), (uint32_t)(sizeof(fgnn_batch_meta) / 4), nullptr};
   if (label && b->num_output) {
     t->label_out = b->label;
     t->label_src = label;
@@ -775,6 +789,22 @@ extern "C" int fgnn_batch_extract(fgnn_batch *b, const void *feat, const void *l
       hipLaunchKernelGGL(batch_rows_overflow_kernel, dim3(1), dim3(1), 0, st, b->d_meta, (uint32_t)b->feat_rows_cap);
     fgnn::GatherTail tail;
     tailed = make_tail(b, feat, label, &tail);
+    b->stamped = false;
+    if (b->timing && tailed) {
+      // the launch's own duration from its workgroups' clock words (pinned memory), next to the HIP-event bracket: the
+      // events also hold the launch gap and the wait for wave slots behind other batches' kernels
+      if (b->stamp_cap < fgnn::kGatherStampBlocks + 1) {
+        if (b->h_stamps) (void)hipHostFree(b->h_stamps);
+        b->h_stamps = nullptr;
+        b->stamp_cap = 0;
+        FGNN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b->h_stamps),
+                                     2 * (fgnn::kGatherStampBlocks + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        b->stamp_cap = fgnn::kGatherStampBlocks + 1;
+      }
+      b->h_stamps[2 * fgnn::kGatherStampBlocks] = 0;
+      tail.stamps = b->h_stamps;
+      b->stamped = true;
+    }
     if (b->timing) FGNN_HIP_CHECK(hipEventRecord(b->t0, st));
     rc = fgnn::gather_rows_ex(b->feat, feat, b->input_nodes, nullptr, 0, &b->d_meta->num_input, b->feat_rows_cap,
                               b->feat_dim, b->feat_dtype, b->feat_row_mask, stream, tailed ? &tail : nullptr, 0,
@@ -902,7 +932,10 @@ extern "C" int fgnn_sampler_run_range(fgnn_sampler *s, const fgnn_run_plan *p, u
       float *t = h_gather_ms + 2 * (i - first_seq);
       t[0] = t[1] = -1.0f;
       if (p->cached) (void)fgnn_batch_extract_cached_ms(b, t);
-      else t[0] = fgnn_batch_gather_ms(b);
+      else {
+        t[0] = fgnn_batch_gather_ms(b);
+        t[1] = fgnn_batch_gather_kernel_ms(b);
+      }
     }
     return FGNN_OK;
   };

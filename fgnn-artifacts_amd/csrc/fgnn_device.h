@@ -709,7 +709,11 @@ struct GatherTail {
   uint32_t *meta_dst;           // null: no summary copy (else host-mapped, 4-byte words)
   const uint32_t *meta_src;
   uint32_t meta_words;          // <= 256
+  // null, or u64[2 * kGatherStampBlocks + 1] in pinned host memory: workgroup b posts its start / end clock (100 MHz) at
+  // [2b], [2b + 1], workgroup 0 the grid size at [2 * kGatherStampBlocks] -- the launch's own duration without events
+  unsigned long long *stamps = nullptr;
 };
+constexpr uint32_t kGatherStampBlocks = 4096;  // (the gather's grid is at most 4-6 workgroups per CU)
 // can this gather carry a tail (16-byte row path, one launch)?
 bool gather_takes_tail(const void *out, const void *src, size_t n_cap, size_t dim, int dtype);
 int gather_rows_ex(void *out, const void *src, const uint32_t *src_index, const uint32_t *dst_index, size_t n,

@@ -533,7 +533,7 @@ EXPORTS += [
     "fgnn_sampler_create", "fgnn_sampler_destroy", "fgnn_sampler_max_nodes", "fgnn_sampler_max_edges",
     "fgnn_batch_create", "fgnn_batch_destroy", "fgnn_sampler_sample", "fgnn_sampler_sample_ordered",
     "fgnn_sampler_run_batch", "fgnn_batch_enable_timing", "fgnn_batch_gather_ms", "fgnn_batch_cache_index", "fgnn_batch_extract",
-    "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_extract_launch_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
+    "fgnn_batch_extract_cached", "fgnn_sampler_run_batch_cached", "fgnn_batch_extract_cached_ms", "fgnn_batch_extract_launch_ms", "fgnn_batch_gather_kernel_ms", "fgnn_batch_finish", "fgnn_batch_wait", "fgnn_batch_row", "fgnn_batch_col",
     "fgnn_batch_data", "fgnn_batch_input_nodes", "fgnn_batch_output_nodes", "fgnn_batch_feat", "fgnn_batch_label",
     "fgnn_batch_cache_index_ptr", "fgnn_batch_device_meta", "fgnn_batch_host_meta", "fgnn_batch_meta_copied",
     "fgnn_sampler_run_range", "fgnn_sampler_sample_indexed", "fgnn_sampler_sample_begin", "fgnn_sampler_sample_begin_ordered", "fgnn_sampler_sample_end", "fgnn_sampler_prefix_tree_stats",

@@ -489,8 +489,8 @@ int fgnn_sampler_run_batch(fgnn_sampler *s, uint64_t seq, const uint32_t *d_seed
  * in batch order.  cached == 0: fgnn_sampler_run_batch(cache_table, feat, label); cached != 0:
  * fgnn_sampler_run_batch_cached(cache_table, cache_rows, full_feat, label).  The call returns when every batch of the
  * range has finished: h_metas[count] receives the summaries in order, h_gather_ms (NULL or float[count][2]) the
- * HIP-event times of the batches whose buffers have timing enabled ({gather, -1} or {miss gather, cached gather}; -1
- * where not timed), *h_enqueue_s (NULL ok) the host time spent enqueueing. Sequence numbers must continue those of
+ * times of the batches whose buffers have timing enabled ({gather by HIP events, gather by its own clock stamps} or
+ * {link band, HBM band of the one-launch cached extraction}; -1 where not timed), *h_enqueue_s (NULL ok) the host time spent enqueueing. Sequence numbers must continue those of
  * earlier calls on the sampler.  num_streams of 1, 2, 3 or 6 needs no event between a slot's uses. */
 typedef struct {
   const uint32_t *d_train;
@@ -533,6 +533,10 @@ float fgnn_batch_extract_launch_ms(fgnn_batch *b);
  * fgnn_batch_gather_ms returns the elapsed time of the last bracketed launch after fgnn_batch_wait, or -1. */
 int fgnn_batch_enable_timing(fgnn_batch *b, int on);
 float fgnn_batch_gather_ms(fgnn_batch *b);
+/* the same launch's OWN duration: first start .. last end over its workgroups (100 MHz device clock words the kernel
+ * posts to pinned memory) -- what a kernel trace reports; the event bracket also holds the launch gap and the wait for
+ * wave slots behind other batches' kernels.  -1 when not timed (or the gather did not take the 16-byte-row path). */
+float fgnn_batch_gather_kernel_ms(fgnn_batch *b);
 /* async copy of the summary to pinned host memory + event */
 int fgnn_batch_finish(fgnn_batch *b, void *stream);
 /* A caller whose own kernel runs last on the batch's stream anyway (the engine's message pack kernel) can let that
