@@ -1,4 +1,5 @@
 # link band packed onto one XCD (FGNN_FUSED_XCD=1, profiling build) against the spread band: shared-GPU extract leg
+# (the switch existed only in the build that measured it: no gain, removed -- profiles/NOTES_rejected_experiments.md, round 6)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06c
 for v in "0 32 4" "1 32 4" "1 16 4" "1 64 4" "1 32 8" "1 64 8" "1 128 4" "0 16 4"; do
