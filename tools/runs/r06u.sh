@@ -1,3 +1,4 @@
+# (the kernel this A/B measured -- fgnn_colsum, FGNN_TORCH_COLSUM=1 for torch -- was slower and is not in the tree: NOTES_rejected_experiments.md, round 6)
 # fgnn_colsum (bias gradients + slice sums of the split weight-gradient GEMMs) against torch's reduce_kernel in the training step
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06u
