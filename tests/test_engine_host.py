@@ -328,3 +328,42 @@ def test_fused_sage_layer_loads_the_op_by_op_checkpoint_layout():
         m.load_state_dict(dict(layout), strict=True)
         m.eval()
         torch.testing.assert_close(m([b0, b1], x), ref([b0, b1], x), rtol=1e-5, atol=1e-6)
+
+
+def test_flip_word_hook_finds_the_ring_among_a_jobs_regions_and_corrupts_one_published_message(tmp_path):
+    """fgnn_host_queue_flip_word (the outside half of the hand-off check's failure test, tests/test_engine_gpu.py): in a
+    subprocess with named regions, a ring is opened after another region, three messages are published, the hook -- tried
+    on every region of the job -- refuses the region that is not a ring and the message that does not exist, flips
+    bits of message 1's second word, and the receiver sees exactly that message changed."""
+    code = r"""
+import ctypes as C, os, sys
+eng = C.CDLL(sys.argv[1])
+eng.fgnn_host_queue_open.restype = C.c_void_p
+prefix = os.environ["SAMGRAPH_SHM_PREFIX"]
+first = C.c_void_p(eng.fgnn_host_queue_open(C.c_size_t(2), C.c_size_t(256)))      # region .0: a ring of another geometry
+q = C.c_void_p(eng.fgnn_host_queue_open(C.c_size_t(4), C.c_size_t(4096)))          # region .1: the ring under test
+for k in range(3):
+    eng.fgnn_host_queue_send(q, C.c_uint64(100 + k), C.c_uint64(7))
+name = lambda i: ("/%s.%d" % (prefix, i)).encode()
+assert eng.fgnn_host_queue_flip_word(name(5), C.c_size_t(1), C.c_size_t(2)) == 2          # no such region
+assert eng.fgnn_host_queue_flip_word(name(0), C.c_size_t(1), C.c_size_t(2)) == 1          # a ring, but message 1 was never sent there
+assert eng.fgnn_host_queue_flip_word(name(1), C.c_size_t(3), C.c_size_t(2)) == 1          # no message 3
+assert eng.fgnn_host_queue_flip_word(name(1), C.c_size_t(1), C.c_size_t(1 << 20)) == 1    # beyond the slot
+assert eng.fgnn_host_queue_flip_word(name(1), C.c_size_t(1), C.c_size_t(2)) == 0          # low half of message 1's value
+got = []
+for _ in range(3):
+    k, v = C.c_uint64(), C.c_uint64()
+    eng.fgnn_host_queue_recv(q, C.byref(k), C.byref(v))
+    got.append((k.value, v.value))
+assert got == [(100, 7), (101, 7 ^ 0x5A5A5A5A), (102, 7)], got
+print("ok")
+"""
+    prefix = "fgnn_test_%d_flipcpu" % os.getpid()
+    env = dict(os.environ, SAMGRAPH_SHM_PREFIX=prefix, SAMGRAPH_SHM_KEEP="1")
+    try:
+        p = subprocess.run([sys.executable, "-c", code, HOOKS], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
+    finally:
+        for f in os.listdir("/dev/shm"):
+            if f.startswith(prefix):
+                os.unlink(os.path.join("/dev/shm", f))
