@@ -171,6 +171,7 @@ def main():
     # the HIP runtime's hardware queues per process (read at its first call): an arch5 rank runs five streams
     # (samgraph_config sets the same default; here it also covers the torch side of a trainer rank)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # hipIpc handles of the samplers' HBM rings (and RCCL) need it
     args = parse_args()
     if args.kernel_lib:  # measurement tools only: the profiling build of the kernel library
         lib.use_library(lib.PROF_LIB_PATH if args.kernel_lib == "prof" else args.kernel_lib)

@@ -28,6 +28,10 @@ void samgraph_config(const char **config_keys, const char **config_values, const
   // GPU idle 21 % -> 7 %).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the
   // process -- after this call in the reference's call order (config before any init); a value set by the user wins.
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // the samplers' HBM message rings go to the trainer processes through hipIpc handles: on hosts whose driver only
+  // supports dmabuf IPC the export fails ("invalid argument") unless the legacy mode is off, and the hand-off would
+  // fall back to the pinned host ring.  Same rule: read at the runtime's first call, a value set by the user wins
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
   RC().Parse(config_keys, config_values, num_config_items);
 }
 

@@ -16,6 +16,10 @@ _THIS = sys.modules[__name__]
 # unless told otherwise, and reads the variable at its first call -- usually after this import (samgraph_config sets the
 # same default for C callers; a value set by the user wins)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the samplers' HBM message rings are shared with the trainer processes through hipIpcGetMemHandle / hipIpcOpenMemHandle,
+# which on hosts whose driver only supports dmabuf IPC fail ("invalid argument") unless the legacy IPC mode is off -- the
+# hand-off then falls back to the reference's pinned host ring.  Read by the runtime at its first call; a user's value wins
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def _enum(names, start=0):
