@@ -329,6 +329,16 @@ class HostTable:
             self.ptr = None
 
 
+def sampler_config_keys(w, sample_type):
+    """the sampler's part of a samgraph run config for workload `w` (operation.cc:58-164): fan-outs for the k-hop
+    samplers (train_graphsage.py:77, train_gcn.py:72), the walk parameters for random_walk (train_pinsage.py:130-134)"""
+    if sample_type == "random_walk":
+        # (workloads without walk parameters of their own: the reference's defaults, train_pinsage.py:130-134)
+        return dict(random_walk_length=w.get("walk_len", 3), random_walk_restart_prob=w.get("restart_prob", 0.5),
+                    num_random_walk=w.get("num_walks", 4), num_neighbor=w["fanout"][0], num_layer=len(w["fanout"]))
+    return dict(num_fanout=len(w["fanout"]), fanout=w["fanout"])
+
+
 def write_dataset(args, w, dev, out_dir):
     """the engine's on-disk layout without feat.bin (SAMGRAPH_EMPTY_FEAT, like papers100M_empty)"""
     os.makedirs(out_dir, exist_ok=True)
@@ -338,6 +348,22 @@ def write_dataset(args, w, dev, out_dir):
     with open(os.path.join(out_dir, "indices.bin"), "wb") as f:
         for a in range(0, ne, chunk):
             f.write(indices[a:a + chunk].cpu().numpy().view(np.uint32).tobytes())
+    if args.sample_type == "weighted_khop_prefix":
+        # the per-row inclusive prefix sums of the edge weights (create_prob_prefix_table.cc; the N = 1 path's generator)
+        prefix = gen_prefix_on_gpu(indptr, ne, 11, dev)
+        with open(os.path.join(out_dir, "prob_prefix_table.bin"), "wb") as f:
+            for a in range(0, ne, chunk):
+                f.write(prefix[a:a + chunk].cpu().numpy().tobytes())
+        del prefix
+    elif args.sample_type in ("weighted_khop", "weighted_khop_hash_dedup"):
+        prob_t, alias_t = gen_alias_on_gpu(indices, ne, 12, dev)
+        with open(os.path.join(out_dir, "prob_table.bin"), "wb") as f:
+            for a in range(0, ne, chunk):
+                f.write(prob_t[a:a + chunk].cpu().numpy().tobytes())
+        with open(os.path.join(out_dir, "alias_table.bin"), "wb") as f:
+            for a in range(0, ne, chunk):
+                f.write(alias_t[a:a + chunk].cpu().numpy().view(np.uint32).tobytes())
+        del prob_t, alias_t
     del indptr, indices
     from fgnn_hip import rmat
     train = rmat.train_set(w["num_node"], w["num_train"], 1, dev)

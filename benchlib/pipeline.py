@@ -8,6 +8,7 @@ import sys
 import time
 
 from .common import (  # noqa: F401
+    sampler_config_keys,
     BENCH_PY, HBM_PEAK_GBS, HOST_LINK_GBS, QUEUE_SLOTS, ROOT, WORKLOADS, XGMI_LINK_GBS,
     gpu_numa_node, local_step_range, no_gc, numa_nodes_with_memory, torch, write_dataset)
 
@@ -64,8 +65,7 @@ def run_calibrate_child():
                batch_size=req["batch_size"], num_epoch=(warm + K + spe - 1) // spe + 1,
                _cache_policy=sam.cache_policies["pre_sample"], presample_epoch=req["presample_epochs"],
                cache_percentage=req["cache_ratio"], max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8,
-               num_sample_worker=1, num_train_worker=1, num_fanout=len(req["fanout"]), fanout=req["fanout"],
-               seed=req["seed"])
+               num_sample_worker=1, num_train_worker=1, seed=req["seed"], **req["sampler_keys"])
     sam.config(cfg)
     sam.data_init()
     bar = _FileBarrier(req["sync_dir"], req["role"], 2)
@@ -126,7 +126,8 @@ def calibrate_roles(args, w, dist, rank, world, dev_id, job, steps_per_epoch, ca
                "role": "s" if rank == 0 else "t", "dev_id": cal_dev, "dir": job["dir"], "sync_dir": sync, "warm": warm,
                "steps": steps, "steps_per_epoch": steps_per_epoch, "sample_type": args.sample_type,
                "batch_size": w["batch_size"], "cache_ratio": args.cache_ratio,
-               "presample_epochs": max(1, args.presample_epochs), "fanout": w["fanout"], "seed": args.seed}
+               "presample_epochs": max(1, args.presample_epochs), "fanout": w["fanout"], "seed": args.seed,
+               "sampler_keys": sampler_config_keys(w, args.sample_type)}
         try:
             o, _ = cal_child.communicate((json.dumps(req) + "\n").encode(),
                                          timeout=float(os.environ.get("FGNN_BENCH_CAL_TIMEOUT", "240")))
@@ -225,8 +226,9 @@ class EngineBackend:
         cfg = dict(dataset_path=job["dir"], _arch=sam.kArch5, _sample_type=sam.sample_types[args.sample_type],
                    batch_size=w["batch_size"], num_epoch=num_epoch, _cache_policy=sam.cache_policies["pre_sample"],
                    presample_epoch=max(1, args.presample_epochs), cache_percentage=args.cache_ratio,
-                   max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8, num_sample_worker=S, num_train_worker=T, num_fanout=len(w["fanout"]),
-                   fanout=w["fanout"], seed=args.seed)
+                   max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8, num_sample_worker=S, num_train_worker=T,
+                   seed=args.seed, **sampler_config_keys(w, args.sample_type))
+        self.weighted_blocks = args.sample_type == "random_walk"  # PinSAGE: visit counts as edge weights
         sam.config(cfg)
         sam.data_init()  # attaches to / creates the job's shared regions; no GPU touched
 
@@ -250,7 +252,8 @@ class EngineBackend:
         return self.sam.get_next_batch()
 
     def blocks(self, key):
-        return self.sam.get_dgl_blocks(key, len(self.w["fanout"]))
+        get = self.sam.get_dgl_blocks_with_weights if self.weighted_blocks else self.sam.get_dgl_blocks
+        return get(key, len(self.w["fanout"]))
 
     def sampler_stats(self, keys):
         sam = self.sam
@@ -463,7 +466,10 @@ def run_pipeline_rank(args, rank, world):
         if not is_sampler and K2:
             sys.path.insert(0, os.path.join(ROOT, "examples"))
             from models import MODELS
-            model = MODELS["graphsage"](w["feat_dim"], 256, w["num_class"], len(w["fanout"]), 0.5).to("cuda:%d" % dev_id)
+            # the reference's model per workload: GraphSAGE (khop2), GCN (weighted sampling, multi_gpu/train_gcn.py),
+            # PinSAGE (random walks, visit counts as edge weights, multi_gpu/train_pinsage.py)
+            kind = {"weighted_khop_prefix": "gcn", "random_walk": "pinsage"}.get(args.sample_type, "graphsage")
+            model = MODELS[kind](w["feat_dim"], 256, w["num_class"], len(w["fanout"]), 0.5).to("cuda:%d" % dev_id)
             if T > 1:
                 model = torch.nn.parallel.DistributedDataParallel(
                     model, device_ids=[dev_id] if n_dev >= world else None, process_group=tgroup)
@@ -576,7 +582,7 @@ def run_pipeline_rank(args, rank, world):
                        "dev_id": dev_id, "dir": job["dir"], "lead": lead, "windows": R, "steps": K, "tail": tail,
                        "steps_per_epoch": steps_per_epoch, "sample_type": args.sample_type, "batch_size": bs,
                        "cache_ratio": args.cache_ratio, "presample_epochs": max(1, args.presample_epochs),
-                       "fanout": w["fanout"], "seed": args.seed,
+                       "fanout": w["fanout"], "seed": args.seed, "sampler_keys": sampler_config_keys(w, args.sample_type),
                        "row_bytes": w["feat_dim"] * 4}
                 try:
                     o, _ = n1_child.communicate((json.dumps(req) + "\n").encode(), timeout=float(
@@ -859,7 +865,7 @@ def run_n1_point_child():
                _cache_policy=sam.cache_policies["pre_sample"], presample_epoch=req["presample_epochs"],
                cache_percentage=req["cache_ratio"],
                max_sampling_jobs=10, max_copying_jobs=2, omp_thread_num=8, sampler_ctx=ctx, trainer_ctx=ctx,
-               num_fanout=len(req["fanout"]), fanout=req["fanout"], seed=req["seed"])
+               seed=req["seed"], **req["sampler_keys"])
     sam.config(cfg)
     t0 = time.time()
     sam.init()

@@ -108,6 +108,17 @@ def test_rehearsal_line_shows_the_sampler_choice(gpus, rates, want):
     _check_windows(out, gpus, want, 2, 10)
 
 
+def test_sampler_keys_of_the_run_config_per_workload():
+    """bench.py --gpus N hands the engine the reference's config keys for the workload's sampler: fan-outs for the k-hop
+    samplers, the walk parameters for PinSAGE's random walks (operation.cc:58-164)"""
+    import bench
+    assert bench.sampler_config_keys(bench.WORKLOADS["papers100M"], "khop2") == {"num_fanout": 2, "fanout": [25, 10]}
+    assert bench.sampler_config_keys(bench.WORKLOADS["twitter"], "weighted_khop_prefix") == {"num_fanout": 3, "fanout": [5, 10, 15]}
+    assert bench.sampler_config_keys(bench.WORKLOADS["uk-2006-05"], "random_walk") == {
+        "random_walk_length": 3, "random_walk_restart_prob": 0.5, "num_random_walk": 25, "num_neighbor": 5, "num_layer": 3}
+    assert bench.sampler_config_keys(bench.WORKLOADS["small"], "random_walk")["num_random_walk"] == 4  # the reference's default
+
+
 def test_pipeline_half_is_importable_without_the_entry_point():
     """bench.py is the entry point only; the N >= 2 half (benchlib/pipeline.py) and the N = 1 half import and expose their
     pieces on their own, and bench re-exports the names the tools use"""

@@ -323,6 +323,25 @@ def test_bench_pipeline_five_ranks_on_one_gpu(tmp_path, samplers):
     assert pl["links"]["rccl_world"] is None and "share" in pl["links"]["why"]  # five ranks, one GPU: no RCCL world
 
 
+@pytest.mark.parametrize("sample_type", ["weighted_khop_prefix", "random_walk"])
+def test_bench_pipeline_two_processes_weighted_and_walks(tmp_path, sample_type):
+    """BASELINE configs 4 and 5 in their PIPELINE form through bench.main: weighted sampling (the dataset gets its
+    prob_prefix_table.bin, the trainers a GCN) and random walks (walk parameters in the run config, visit counts shipped
+    as edge data, the trainers a PinSAGE) -- sampler process -> HBM ring -> trainer process, training span included."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small",
+                        "--sample-type", sample_type, "--steps", "10", "--warmup", "3", "--train-steps", "4",
+                        "--no-n1-point", "--empty-feat-bits", "16"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["edges_per_step"] > 1000 and sample_type in out["metric"]
+    assert 0 < out["pipeline"]["hit_rate"] <= 1 and out["epoch_time_s"]["with_training"] > 0
+    rings = out["pipeline"]["handoff"]["rings"]
+    assert rings[0]["verified"] > 0 and rings[0]["check_failed"] == 0 and not out["pipeline"]["handoff"]["degraded"]
+
+
 def test_bench_pipeline_two_processes(tmp_path):
     """bench.py --gpus 2 = 1S+1T as two processes through bench.main's launcher, the engine and the device ring (both
     ranks share cuda:0 on a one-GPU box)."""
