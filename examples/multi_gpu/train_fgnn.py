@@ -30,7 +30,11 @@ import samgraph.torch as sam  # noqa: E402
 from models import MODELS  # noqa: E402
 
 
-def parse_args():
+# run-config entries that belong to the script, not to sam.config()
+SCRIPT_KEYS = ("sample_workers", "train_workers", "model", "no_train", "report_acc", "op_by_op")
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="graphsage", choices=list(MODELS))
     ap.add_argument("--dataset-path", default="/tmp/fgnn_ds/synth")
@@ -60,7 +64,11 @@ def parse_args():
     ap.add_argument("--num-random-walk", type=int, default=4)
     ap.add_argument("--num-neighbor", type=int, default=5)
     ap.add_argument("--num-layer", type=int, default=3)
-    return ap.parse_args()
+    return ap
+
+
+def parse_args():
+    return build_parser().parse_args()
 
 
 def get_run_config(args):
@@ -198,8 +206,8 @@ def run_train(worker_id, rc):
     sam.shutdown()
 
 
-def main():
-    args = parse_args()
+def make_dataset(args):
+    """--make-dataset: a synthetic dataset directory in the reference's on-disk format (engine.cc:73-264)"""
     if args.make_dataset:
         from fgnn_hip import synth
         shape = dict(synth.DATASET_SHAPES["products"]) if args.make_dataset == "products" else \
@@ -211,10 +219,14 @@ def main():
                             learnable=args.make_dataset == "learnable",
                             with_prefix=args.sample_type == "weighted_khop_prefix",
                             with_alias=args.sample_type in ("weighted_khop", "weighted_khop_hash_dedup"))
+
+
+def main():
+    args = parse_args()
+    make_dataset(args)
     rc = get_run_config(args)
     ns, nt = rc["num_sample_worker"], rc["num_train_worker"]
-    sam.config({k: v for k, v in rc.items() if isinstance(v, (int, float, str, list)) and k not in
-                ("sample_workers", "train_workers", "model", "no_train", "report_acc", "op_by_op")})
+    sam.config({k: v for k, v in rc.items() if isinstance(v, (int, float, str, list)) and k not in SCRIPT_KEYS})
     sam.data_init()  # before fork: nothing here touches the GPU
     ctx = mp.get_context("fork")
     rc["global_barrier"] = ctx.Barrier(ns + nt)

@@ -1,6 +1,7 @@
 """End-to-end through the drop-in boundary on a real GPU: `import samgraph.torch as sam` -> samgraph_* C ABI ->
 HIP kernels, every batch compared bit-for-bit with the oracle (tests/engine_runner.py)."""
 import os
+import re
 import subprocess
 import sys
 
@@ -480,6 +481,31 @@ def test_fgnn_training_example_runs(tmp_path, model, extra):
                        capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:pipeline_train_epoch_time=" in p.stdout and "test_result:sample_time=" in p.stdout
+
+
+@pytest.mark.parametrize("model,extra", [
+    ("pinsage", ["--num-random-walk", "6", "--num-train-worker", "2", "--cache-percentage", "0.2",
+                 "--switch-cache-percentage", "0.1"]),
+    ("graphsage", ["--fanout", "10", "5", "--cache-percentage", "0.2", "--no-switcher"]),
+])
+def test_switcher_training_example_runs(tmp_path, model, extra):
+    """examples/balance_switcher/train_switcher.py = the reference's balance_switcher scripts' shape (BASELINE config 5):
+    a switcher process next to every sampler starts training on the sampler's GPU once the sampler has produced its
+    share of the epoch; permits per batch; parameter deltas through one model in shared host memory.  Every batch of
+    every epoch is consumed exactly once (the script exits non-zero otherwise); second case: the same without switcher
+    processes."""
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "balance_switcher",
+                      "train_switcher.py")
+    p = subprocess.run([sys.executable, ex, "--model", model, "--make-dataset", "small", "--dataset-path",
+                        str(tmp_path / "small"), "--num-epoch", "2", "--batch-size", "2000", "--single-gpu"] + extra,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    consumed = int(re.search(r"test_result:batches_consumed=(\d+)", p.stdout).group(1))
+    switched = int(re.search(r"test_result:batches_by_switchers=(\d+)", p.stdout).group(1))
+    assert consumed == 3 * 20 and "test_result:epoch_time:total=" in p.stdout  # (2 + the warm-up epoch) x 40000 / 2000
+    assert (switched == 0) == ("--no-switcher" in extra), p.stdout[-2000:]
+    losses = [float(x) for x in re.findall(r"loss ([0-9.]+)", p.stdout)]
+    assert losses and all(x == x and x < 20 for x in losses), losses
 
 
 @pytest.mark.parametrize("extra", [["--arch", "arch6", "--num-worker", "2", "--single-gpu", "--cache-percentage", "0.2"],
