@@ -205,7 +205,9 @@ void fgnn_oracle_task_free(fgnn_oracle_task *t);
 /* Direct-map cache table, cuda/cuda_cache_manager_host.cc:80-100, dist/dist_engine.cc:193-229 */
 void fgnn_oracle_cache_table_build(const uint32_t *ranking_nodes, size_t num_cached, size_t num_node,
                                    uint32_t *table);
-/* GetMissCacheIndex, cuda/cuda_cache.cu:33-234: stable two-way partition. */
+/* GetMissCacheIndex, cuda/cuda_cache.cu:33-234: stable two-way partition (the host body of the same split,
+ * dist/dist_cache_manager_host.cc:129-155, gives it with one OpenMP thread; that file needs cuda_runtime.h through
+ * function.h and cannot be compiled into oracle/_ref: pinned by reading). */
 void fgnn_oracle_get_miss_cache_index(const uint32_t *table, const uint32_t *nodes, size_t n,
                                       uint32_t *miss_src, uint32_t *miss_dst, size_t *num_miss,
                                       uint32_t *cache_src, uint32_t *cache_dst, size_t *num_cache);
