@@ -636,6 +636,16 @@ void fgnn_oracle_extract(void *dst, const void *src, const uint32_t *index, size
     memcpy((char *)dst + i * row, (const char *)src + (size_t)index[i] * row, row);
 }
 
+/* cpu_mock_extract / CPUMockExtract, cpu/cpu_extraction.cc:44-62, 92-116 (gpu_mock_extract, cuda_extraction.cu:50-70):
+ * the row id is masked to a table of 2^empty_feat_bits rows */
+void fgnn_oracle_mock_extract(void *dst, const void *src, const uint32_t *index, size_t num_index, size_t dim,
+                              int dtype, unsigned empty_feat_bits) {
+  const size_t row = dim * fgnn_dtype_bytes(dtype);
+  const size_t mask = ((size_t)1 << empty_feat_bits) - 1;
+  for (size_t i = 0; i < num_index; ++i)
+    memcpy((char *)dst + i * row, (const char *)src + ((size_t)index[i] & mask) * row, row);
+}
+
 void fgnn_oracle_combine(void *out, const void *rows, const uint32_t *src_index, const uint32_t *dst_index,
                          size_t n, size_t dim, int dtype) {
   const size_t row = dim * fgnn_dtype_bytes(dtype);

@@ -214,6 +214,9 @@ void fgnn_oracle_get_miss_cache_index(const uint32_t *table, const uint32_t *nod
 /* GPUExtract / CPUExtract, cuda/cuda_extraction.cu:30-117, cpu/cpu_extraction.cc:31-116 */
 void fgnn_oracle_extract(void *dst, const void *src, const uint32_t *index, size_t num_index, size_t dim,
                          int dtype);
+/* GPUMockExtract / CPUMockExtract, cuda/cuda_extraction.cu:50-70, cpu/cpu_extraction.cc:44-62, 92-116 */
+void fgnn_oracle_mock_extract(void *dst, const void *src, const uint32_t *index, size_t num_index, size_t dim,
+                              int dtype, unsigned empty_feat_bits);
 /* CombineMissData / CombineCacheData, cuda/cuda_cache_manager_device.cu:165-210 */
 void fgnn_oracle_combine(void *out, const void *rows, const uint32_t *src_index /* NULL => i */,
                          const uint32_t *dst_index, size_t n, size_t dim, int dtype);

@@ -312,6 +312,18 @@ def extract(src, index):
     return out
 
 
+def mock_extract(src, index, empty_feat_bits):
+    """CPUMockExtract: rows of a 2^empty_feat_bits-row table, ids masked"""
+    src = np.ascontiguousarray(src)
+    index, pi = _u32(index)
+    dim = 1 if src.ndim == 1 else src.shape[1]
+    out = np.empty((len(index),) + src.shape[1:], dtype=src.dtype)
+    lib().fgnn_oracle_mock_extract(out.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), pi,
+                                   C.c_size_t(len(index)), C.c_size_t(dim), C.c_int(_NP2DT[src.dtype]),
+                                   C.c_uint(empty_feat_bits))
+    return out
+
+
 def combine(out, rows, src_index, dst_index):
     assert out.flags.c_contiguous
     rows = np.ascontiguousarray(rows)

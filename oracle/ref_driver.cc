@@ -7,7 +7,7 @@
  * in the build container (the GPU box has no /root/reference; it uses the committed fixtures).
  *
  * What is linked: cpu/cpu_sampling_khop0.cc, cpu/cpu_sampling_khop2.cc, cpu/cpu_random.cc,
- * cpu/cpu_extraction.cc, cpu/cpu_hashtable2.cc, run_config.cc, constant.cc, logging.cc -- all
+ * cpu/cpu_extraction.cc (CPUExtract and CPUMockExtract), cpu/cpu_hashtable2.cc, run_config.cc, constant.cc, logging.cc -- all
  * unmodified.  The reference's Device/Tensor layer (device.cc, common.cc) needs cuda_runtime.h and
  * is NOT built and NOT replaced: the four symbols it would provide (Device::Get, CPU, GetEnv,
  * IsEnvSet) stay unresolved: the driver is a shared object opened with dlopen(RTLD_LAZY) by the
@@ -135,6 +135,20 @@ extern "C" int ref_driver_main(const char *jobfile) {
       size_t esz = dtype == kF32 || dtype == kI32 ? 4 : (dtype == kF64 || dtype == kI64 ? 8 : (dtype == kF16 ? 2 : 1));
       std::vector<char> dstv(idx.size() * dim * esz + 1);
       cpu::CPUExtract(dstv.data(), src.data(), idx.data(), idx.size(), dim, static_cast<DataType>(dtype));
+      save(out, dstv.data(), idx.size() * dim * esz);
+    } else if (cmd == "mock_extract") {
+      // CPUMockExtract (cpu/cpu_extraction.cc:44-62, 92-116): row ids masked to a 2^bits-row table (SAMGRAPH_EMPTY_FEAT)
+      std::string a, b, out;
+      size_t dim, bits;
+      int dtype;
+      ss >> a >> b >> dim >> dtype >> bits >> out;
+      auto src = load<char>(a);
+      auto idx = load<IdType>(b);
+      size_t esz = dtype == kF32 || dtype == kI32 ? 4 : (dtype == kF64 || dtype == kI64 ? 8 : (dtype == kF16 ? 2 : 1));
+      std::vector<char> dstv(idx.size() * dim * esz + 1);
+      RunConfig::option_empty_feat = bits;
+      cpu::CPUMockExtract(dstv.data(), src.data(), idx.data(), idx.size(), dim, static_cast<DataType>(dtype));
+      RunConfig::option_empty_feat = 0;
       save(out, dstv.data(), idx.size() * dim * esz);
     } else {
       std::cerr << "unknown command " << cmd << "\n";

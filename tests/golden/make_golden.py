@@ -141,6 +141,31 @@ def golden_extract():
     print("extract ok")
 
 
+def golden_mock_extract():
+    """CPUMockExtract (cpu/cpu_extraction.cc:44-62, 92-116): ids far beyond the 2^bits-row table, masked by the
+    reference itself (RunConfig::option_empty_feat = SAMGRAPH_EMPTY_FEAT)"""
+    rng = np.random.default_rng(6)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        lines = []
+        idx = rng.integers(0, 1 << 32, size=91, dtype=np.uint64).astype(np.uint32)
+        idx[:3] = (0, 0xFFFFFFFF, 255)
+        idx.tofile(f"{tmp}/idx.bin")
+        out["index"] = idx
+        cases = (("f32_d128_b8", np.float32, 0, 128, 8), ("f32_d5_b3", np.float32, 0, 5, 3),
+                 ("i64_d1_b6", np.int64, 6, 1, 6), ("u8_d3_b1", np.uint8, 3, 3, 1), ("f16_d9_b4", np.float16, 2, 9, 4))
+        for name, dtype, code, dim, bits in cases:
+            src = (rng.standard_normal((1 << bits, dim)) * 100).astype(dtype)
+            src.tofile(f"{tmp}/{name}.bin")
+            lines.append(f"mock_extract {tmp}/{name}.bin {tmp}/idx.bin {dim} {code} {bits} {tmp}/{name}.out")
+            out[name + "_src"] = src
+        run_job(lines, tmp)
+        for name, _, _, dim, _ in cases:
+            out[name + "_out"] = np.fromfile(f"{tmp}/{name}.out", dtype=out[name + "_src"].dtype).reshape(91, dim)
+    np.savez_compressed(os.path.join(HERE, "mock_extract.npz"), **out)
+    print("mock_extract ok")
+
+
 def golden_shuffle():
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "probe")
@@ -173,9 +198,9 @@ def golden_constants():
 if __name__ == "__main__":
     if not os.path.exists(DRIVER):
         sys.exit("build oracle/_ref first: make -C oracle _ref")
-    golden_khop_pipeline("khop0", "khop0_pipeline.npz")
-    golden_khop_pipeline("khop2", "khop2_pipeline.npz")
-    golden_edge_cases()
-    golden_extract()
-    golden_shuffle()
-    golden_constants()
+    steps = {"khop0": lambda: golden_khop_pipeline("khop0", "khop0_pipeline.npz"),
+             "khop2": lambda: golden_khop_pipeline("khop2", "khop2_pipeline.npz"),
+             "edge_cases": golden_edge_cases, "extract": golden_extract, "mock_extract": golden_mock_extract,
+             "shuffle": golden_shuffle, "constants": golden_constants}
+    for name in (sys.argv[1:] or list(steps)):  # python make_golden.py [fixture ...]
+        steps[name]()

@@ -11,7 +11,8 @@ through the C ABI of libfgnn_hip.so:
 * cpu_sampling_khop{0,2}.cc: the emitted src column (min(deg, fanout) entries per seed, seed-major), rows with
   deg <= fanout copied whole in CSR order, longer rows = `fanout` distinct positions of the row; khop2 leaves
   every row a permutation of itself;
-* cpu_extraction.cc:31-116: fgnn_gather_rows byte-equal for every dtype / width of extract.npz.
+* cpu_extraction.cc:31-116: fgnn_gather_rows byte-equal for every dtype / width of extract.npz, and with the
+  reference's row-id mask (CPUMockExtract) for mock_extract.npz.
 Bar: bit-exact."""
 import os
 
@@ -211,6 +212,22 @@ def test_batch_driver_on_reference_fixture_rows(hip, golden_dir):
             cur = np.array(n2o, dtype=np.uint32)
         np.testing.assert_array_equal(host_u32(bt.input_nodes(), len(n2o)), cur)
         np.testing.assert_array_equal(host_u32(d_indices), indices)  # nothing sampled from: khop2 wrote nothing
+
+
+def test_gather_rows_reference_mock_extract(hip, golden_dir):
+    """cpu_extraction.cc:44-62, 92-116 (CPUMockExtract = gpu_mock_extract, cuda_extraction.cu:50-70) outputs: the gather
+    with a source-row mask, ids up to 2^32 - 1 against tables of 2 .. 256 rows"""
+    g = _load(golden_dir, "mock_extract.npz")
+    d_idx = dev(g["index"])
+    names = sorted(k[:-4] for k in g.files if k.endswith("_src"))
+    assert len(names) == 5
+    for name in names:
+        bits = int(name.rsplit("_b", 1)[1])
+        src, want = g[name + "_src"], g[name + "_out"]
+        out = torch.empty(want.shape, dtype=torch.from_numpy(want).dtype, device="cuda")
+        hip.gather_rows(out, torch.from_numpy(np.ascontiguousarray(src)).cuda(), src_index=d_idx,
+                        src_row_mask=(1 << bits) - 1)
+        assert out.cpu().numpy().tobytes() == want.tobytes(), name
 
 
 def test_gather_rows_reference_extract(hip, golden_dir):

@@ -103,6 +103,20 @@ def test_extract_matches_reference_cpu(oracle, golden_dir):
         assert out.tobytes() == g[name + "_out"].tobytes(), name
 
 
+def test_mock_extract_matches_reference_cpu(oracle, golden_dir):
+    """CPUMockExtract (cpu/cpu_extraction.cc:44-62, 92-116; the GPU twin gpu_mock_extract, cuda_extraction.cu:50-70):
+    the reference's own masking of row ids to a 2^SAMGRAPH_EMPTY_FEAT-row table, ids up to 2^32 - 1"""
+    g = _load(golden_dir, "mock_extract.npz")
+    names = sorted(k[:-4] for k in g.files if k.endswith("_src"))
+    assert len(names) == 5
+    for name in names:
+        bits = int(name.rsplit("_b", 1)[1])
+        out = oracle.mock_extract(g[name + "_src"], g["index"], bits)
+        assert out.tobytes() == g[name + "_out"].tobytes(), name
+        # the mask is the whole difference to CPUExtract
+        assert out.tobytes() == oracle.extract(g[name + "_src"], g["index"] & ((1 << bits) - 1)).tobytes(), name
+
+
 def test_shuffle_matches_libstdcxx(oracle, golden_dir):
     """Shufflers' Fisher-Yates with std::default_random_engine(epoch) (dist/dist_shuffler.cc:112-131):
     cumulative over epochs, seed = epoch."""
