@@ -4,7 +4,8 @@ example/samgraph/multi_gpu/train_{graphsage,gcn,pinsage}.py: the parent configur
 (`sam.config`, `sam.data_init`) and forks sampler processes (`sample_init` + `sample_once` per step, the pre-sampling
 cache policy computed by sampler 0) and trainer processes (`train_init`, `extract_start`, `get_next_batch`,
 `get_dgl_blocks[_with_weights]`), linked by the pinned shared-memory queue; trainers synchronise gradients with
-torch.distributed (backend "nccl" = RCCL) when there is more than one.
+torch.distributed (backend "nccl" = RCCL) when there is more than one, or -- `--async`, the reference's
+multi_gpu/async/train_graphsage.py -- send them to one model in shared host memory whose optimizer they step.
 
     # 1 sampler GPU + 1 trainer GPU (BASELINE config 3); --single-gpu puts every worker on cuda:0
     python examples/multi_gpu/train_fgnn.py --model graphsage --dataset-path /tmp/ds/papers --cache-percentage 0.2 \\
@@ -31,7 +32,7 @@ from models import MODELS  # noqa: E402
 
 
 # run-config entries that belong to the script, not to sam.config()
-SCRIPT_KEYS = ("sample_workers", "train_workers", "model", "no_train", "report_acc", "op_by_op")
+SCRIPT_KEYS = ("sample_workers", "train_workers", "model", "no_train", "report_acc", "op_by_op", "async_train")
 
 
 def build_parser():
@@ -56,6 +57,10 @@ def build_parser():
     ap.add_argument("--cache-policy", default="pre_sample", choices=list(sam.cache_policies))
     ap.add_argument("--cache-percentage", type=float, default=0.0)
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--async", dest="async_train", action="store_true",
+                    help="no gradient all-reduce: every trainer sends its gradients to ONE model in shared host memory, "
+                         "steps that model's optimizer and takes the parameters back (multi_gpu/async/train_graphsage.py:"
+                         "204-211, 260, 320-326)")
     ap.add_argument("--no-train", action="store_true", help="trainers only consume batches: measures sample + hand-off "
                     "+ extract throughput")
     # PinSAGE (multi_gpu/train_pinsage.py:130-134)
@@ -96,7 +101,8 @@ def get_run_config(args):
         rc["sample_workers"] = ["cuda:%d" % i for i in range(ns)]
         rc["train_workers"] = ["cuda:%d" % (ns + i) for i in range(nt)]
     rc.update(model=args.model, num_hidden=args.num_hidden, lr=args.lr, dropout=args.dropout,
-              pipeline=not args.no_pipeline, no_train=args.no_train, report_acc=args.report_acc, op_by_op=args.op_by_op)
+              pipeline=not args.no_pipeline, no_train=args.no_train, report_acc=args.report_acc, op_by_op=args.op_by_op,
+              async_train=args.async_train)
     return rc
 
 
@@ -132,7 +138,8 @@ def run_train(worker_id, rc):
     nt = rc["num_train_worker"]
     dev = torch.device(ctx)
     torch.cuda.set_device(dev)
-    if nt > 1:
+    shared = rc.get("global_cpu_model")  # --async
+    if nt > 1 and shared is None:
         torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % rc["dist_port"], rank=worker_id,
                                              world_size=nt, timeout=datetime.timedelta(seconds=600))
     sam.wait_for_sampler_ready(barrier)
@@ -145,10 +152,17 @@ def run_train(worker_id, rc):
         import train_accuracy
         graph, valid_set, test_set, feat, label = train_accuracy.load_accuracy_data(rc["dataset_path"])
         accuracy = train_accuracy.Accuracy(graph, valid_set, test_set, feat, label, rc["fanout"], rc["batch_size"], dev)
-    if nt > 1:
+    ddp = nt > 1 and shared is None
+    if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev)
     loss_fcn = nn.CrossEntropyLoss().to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=rc["lr"], fused=True)
+    if shared is not None:
+        model.load_state_dict(shared.state_dict())
+        params, cpu_params = list(model.parameters()), list(shared.parameters())
+        opt = torch.optim.Adam(params, lr=rc["lr"])  # (only its zero_grad is used: the shared model's optimizer steps)
+        cpu_opt = torch.optim.Adam(cpu_params, lr=rc["lr"])
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=rc["lr"], fused=True)
     num_epoch, num_step = sam.num_epoch(), sam.steps_per_epoch()
     my_step = num_step // nt + (1 if worker_id < num_step % nt else 0)  # multi_gpu/train_graphsage.py:293-298
     get_blocks = sam.get_dgl_blocks_with_weights if rc["model"] == "pinsage" else sam.get_dgl_blocks
@@ -172,7 +186,15 @@ def run_train(worker_id, rc):
                 loss = loss_fcn(model(blocks, batch_input), batch_label)
                 opt.zero_grad()
                 loss.backward()
-                opt.step()
+                if shared is None:
+                    opt.step()
+                else:
+                    with rc["global_lock"], torch.no_grad():
+                        for p, c in zip(params, cpu_params):
+                            c.grad = p.grad.to("cpu")
+                        cpu_opt.step()
+                        for p, c in zip(params, cpu_params):
+                            p.copy_(c)
             else:
                 loss = 0.0
             # the batch's buffers go back to the pool at the next get_next_batch: wait for THIS stream's work only
@@ -182,7 +204,7 @@ def run_train(worker_id, rc):
             t_train += time.time() - t1
             if accuracy is not None and (epoch * my_step + step) % rc["report_acc"] == 0:
                 tt = time.time()
-                acc = accuracy.valid_acc(model.module if nt > 1 else model, dev)
+                acc = accuracy.valid_acc(model.module if ddp else model, dev)
                 print("Valid Acc: {:.2f}% | Acc Time: {:.4f} | Total Step: {:d}".format(
                     acc * 100.0, time.time() - tt, epoch * my_step + step))
         totals.append(time.time() - tic)
@@ -195,7 +217,7 @@ def run_train(worker_id, rc):
     barrier.wait()  # results
     if accuracy is not None:
         tt = time.time()
-        acc = accuracy.test_acc(model.module if nt > 1 else model, dev)
+        acc = accuracy.test_acc(model.module if ddp else model, dev)
         print("Test Acc: {:.2f}% | Acc Time: {:.4f}".format(acc * 100.0, time.time() - tt))
         print("test_result:test_acc={:.4f}".format(acc))
     if worker_id == 0:
@@ -229,6 +251,15 @@ def main():
     sam.config({k: v for k, v in rc.items() if isinstance(v, (int, float, str, list)) and k not in SCRIPT_KEYS})
     sam.data_init()  # before fork: nothing here touches the GPU
     ctx = mp.get_context("fork")
+    if rc["async_train"]:
+        # (one CPU thread here: an OpenMP pool created by the parent would not survive the fork)
+        torch.set_num_threads(1)
+        torch.manual_seed(0)
+        kw = dict(fused=False) if rc["op_by_op"] and rc["model"] == "graphsage" else {}
+        rc["global_cpu_model"] = MODELS[rc["model"]](sam.feat_dim(), rc["num_hidden"], sam.num_class(), rc["num_layer"],
+                                                     rc["dropout"], **kw)
+        rc["global_cpu_model"].share_memory()
+        rc["global_lock"] = ctx.Lock()
     rc["global_barrier"] = ctx.Barrier(ns + nt)
     rc["dist_port"] = 29500 + os.getpid() % 2000
     procs = [ctx.Process(target=run_sample, args=(i, rc)) for i in range(ns)]

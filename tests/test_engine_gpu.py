@@ -470,6 +470,8 @@ def test_training_example_runs(tmp_path, extra):
     ("graphsage", ["--cache-percentage", "0.2", "--fanout", "10", "5"]),
     ("gcn", ["--sample-type", "weighted_khop_prefix", "--fanout", "3", "4", "5", "--cache-percentage", "0.1"]),
     ("pinsage", ["--num-random-walk", "6", "--num-sample-worker", "2"]),
+    # the reference's multi_gpu/async variant: gradients to one model in shared host memory, no all-reduce
+    ("graphsage", ["--async", "--num-train-worker", "2", "--fanout", "10", "5", "--cache-percentage", "0.2"]),
 ])
 def test_fgnn_training_example_runs(tmp_path, model, extra):
     """examples/multi_gpu/train_fgnn.py = the reference's multi_gpu scripts' shape (parent config + data_init, forked
