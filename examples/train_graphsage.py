@@ -10,6 +10,9 @@ DGLBlocks and dgl.nn.SAGEConv works unchanged.
 
     python examples/train_graphsage.py --dataset-path /tmp/ds/synth --num-epoch 3
     python examples/train_graphsage.py --make-dataset products   # writes a products-shaped synthetic dataset first
+    # the reference's train_gcn.py / train_pinsage.py (single process): GCN on khop0 [5,10,15], PinSAGE on random walks
+    python examples/train_graphsage.py --model gcn --sample-type khop0 --fanout 5 10 15 ...
+    python examples/train_graphsage.py --model pinsage --num-random-walk 4 --num-neighbor 5 ...
 """
 import argparse
 import os
@@ -27,11 +30,18 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 import samgraph.torch as sam  # noqa: E402
 
 
-from models import SAGE  # noqa: E402  (examples/models.py: torch-op SAGEConv on the engine's COO blocks)
+from models import MODELS, SAGE  # noqa: E402  (examples/models.py: torch-op layers on the engine's COO blocks)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="graphsage", choices=list(MODELS))
+    # PinSAGE (example/samgraph/train_pinsage.py: random walks, visit counts as edge weights)
+    ap.add_argument("--random-walk-length", type=int, default=3)
+    ap.add_argument("--random-walk-restart-prob", type=float, default=0.5)
+    ap.add_argument("--num-random-walk", type=int, default=4)
+    ap.add_argument("--num-neighbor", type=int, default=5)
+    ap.add_argument("--num-layer", type=int, default=3)
     ap.add_argument("--dataset-path", default="/tmp/fgnn_ds/synth")
     ap.add_argument("--make-dataset", default=None, choices=["products", "small", "learnable"],
                     help="write a synthetic dataset of that shape to --dataset-path first (learnable: a small graph whose "
@@ -80,19 +90,28 @@ def main():
                       _sample_type=sam.sample_types[args.sample_type],
                       batch_size=args.batch_size, num_epoch=args.num_epoch + 1,  # + one warm-up epoch (common_config.py:163)
                       _cache_policy=sam.cache_policies[args.cache_policy], cache_percentage=args.cache_percentage, max_sampling_jobs=10,
-                      max_copying_jobs=2, omp_thread_num=8, sampler_ctx=sampler_ctx, trainer_ctx=trainer_ctx,
-                      num_fanout=len(args.fanout), fanout=args.fanout)
+                      max_copying_jobs=2, omp_thread_num=8, sampler_ctx=sampler_ctx, trainer_ctx=trainer_ctx)
+    if args.model == "pinsage":
+        run_config.update(_sample_type=sam.sample_types["random_walk"], random_walk_length=args.random_walk_length,
+                          random_walk_restart_prob=args.random_walk_restart_prob, num_random_walk=args.num_random_walk,
+                          num_neighbor=args.num_neighbor, num_layer=args.num_layer)
+    else:
+        run_config.update(num_fanout=len(args.fanout), fanout=args.fanout)
     sam.config(run_config)
     sam.init()
     pipeline = args.pipeline and arch != "arch1"  # arch1 doesn't support pipelining (common_config.py:212-214)
     if pipeline:
         sam.start()
     dev = th.device(trainer_ctx)
-    num_layer = len(args.fanout)
-    model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout,
-                 fused=not args.op_by_op).to(dev)
+    num_layer = args.num_layer if args.model == "pinsage" else len(args.fanout)
+    if args.model == "graphsage":
+        model = SAGE(sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout,
+                     fused=not args.op_by_op).to(dev)
+    else:
+        model = MODELS[args.model](sam.feat_dim(), args.num_hidden, sam.num_class(), num_layer, args.dropout).to(dev)
+    get_blocks = sam.get_dgl_blocks_with_weights if args.model == "pinsage" else sam.get_dgl_blocks
     accuracy = None
-    if args.report_acc:
+    if args.report_acc and args.model != "pinsage":
         import train_accuracy
         graph, valid_set, test_set, feat, label = train_accuracy.load_accuracy_data(args.dataset_path)
         accuracy = train_accuracy.Accuracy(graph, valid_set, test_set, feat, label, args.fanout, args.batch_size,
@@ -109,7 +128,7 @@ def main():
             if not pipeline:
                 sam.sample_once()
             batch_key = sam.get_next_batch()
-            blocks, batch_input, batch_label = sam.get_dgl_blocks(batch_key, num_layer)
+            blocks, batch_input, batch_label = get_blocks(batch_key, num_layer)
             t1 = time.time()
             loss = loss_fcn(model(blocks, batch_input), batch_label)
             opt.zero_grad()

@@ -453,15 +453,19 @@ def test_arch5_switcher(tmp_path, sample_type):
 @pytest.mark.parametrize("extra", [[], ["--arch", "arch3", "--cache-percentage", "0.2", "--pipeline"],
                                    ["--arch", "arch3", "--cache-percentage", "0.2", "--cache-policy", "presample_static"],
                                    ["--arch", "arch4", "--cache-policy", "dynamic_cache", "--sample-type", "khop0",
-                                    "--pipeline"]])
+                                    "--pipeline"],
+                                   # the reference's single-process train_gcn.py / train_pinsage.py
+                                   ["--model", "gcn", "--sample-type", "khop0", "--fanout", "3", "4", "5"],
+                                   ["--model", "pinsage", "--num-random-walk", "6", "--arch", "arch3", "--pipeline",
+                                    "--cache-percentage", "0.1"]])
 def test_training_example_runs(tmp_path, extra):
     """examples/train_graphsage.py = the reference's single-process script shape (config -> init -> [start] ->
     sample_once -> get_next_batch -> get_dgl_blocks -> fwd/bwd) with a torch-op SAGEConv; prints the reference's
     test_result lines.  Second case: the reference's default arch3 with its background threads."""
     ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_graphsage.py")
     p = subprocess.run([sys.executable, ex, "--make-dataset", "small", "--dataset-path", str(tmp_path / "small"),
-                        "--num-epoch", "2", "--batch-size", "2000", "--fanout", "10", "5"] + extra,
-                       capture_output=True, text=True, timeout=1500)
+                        "--num-epoch", "2", "--batch-size", "2000"] + ([] if "--fanout" in extra else ["--fanout", "10", "5"])
+                       + extra, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "test_result:epoch_time:total=" in p.stdout and "test_result:sampled_edges_per_epoch=" in p.stdout
 
