@@ -571,6 +571,15 @@ def run_pipeline_rank(args, rank, world):
         maps = [None] * world
         dist.all_gather_object(maps, None if is_sampler else {"rank": rank, "device": dev_id,
                                                              "rings": be.ring_mappings(S)})
+        # open descriptors per rank while every ring is still mapped (a trainer imports up to S x 170 ring slots, each an
+        # IPC buffer of its own) next to the soft limit the process runs under
+        import resource
+        nfiles = [None] * world
+        try:
+            mine_fd = len(os.listdir("/proc/self/fd"))
+        except OSError:
+            mine_fd = None
+        dist.all_gather_object(nfiles, mine_fd)
         be.shutdown()
         dist.barrier()
         n1_point = None
@@ -696,6 +705,7 @@ def run_pipeline_rank(args, rank, world):
                     "trainer_rows_per_s": rows / t_max, "hit_rate": hit_rows / max(rows, 1.0),
                     "handoff_bytes_per_step": handoff_bytes / K, "handoff_GBps": handoff_bytes / t_max / 1e9,
                     "handoff_peak_GBps": XGMI_LINK_GBS, "handoff": handoff, "links": links,
+                    "open_files": {"per_rank": nfiles, "soft_limit": resource.getrlimit(resource.RLIMIT_NOFILE)[0]},
                     "numa": {"gpu_node_of_rank": gnodes, "nodes_with_memory": numa_nodes_with_memory(),
                              "host_feat_policy": os.environ.get("SAMGRAPH_HOST_FEAT_NUMA",
                                                                 "interleave over the nodes with memory (default)"),

@@ -2,6 +2,7 @@
 // torch/adapter.{h,cc}).
 #include <cstdlib>
 #include <signal.h>
+#include <sys/resource.h>
 #include <sys/wait.h>
 
 #include "eng_engine.h"
@@ -32,6 +33,17 @@ void samgraph_config(const char **config_keys, const char **config_values, const
   // supports dmabuf IPC the export fails ("invalid argument") unless the legacy mode is off, and the hand-off would
   // fall back to the pinned host ring.  Same rule: read at the runtime's first call, a value set by the user wins
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+  // every slot of a sampler's HBM ring is its own allocation and its own IPC handle (eng_queue.h): a trainer of an
+  // S-sampler job imports up to S x 170 buffers.  On the development boxes' driver an imported slot keeps no
+  // descriptor open (13-25 open files per rank with every ring mapped, bench.py's pipeline.open_files); a driver
+  // whose dmabuf import does must not run into the usual soft limit of 1024 (the hard limit is the user's to set)
+  {
+    struct rlimit rl;
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < 65536 && rl.rlim_cur < rl.rlim_max) {
+      rl.rlim_cur = rl.rlim_max < 65536 ? rl.rlim_max : 65536;
+      (void)setrlimit(RLIMIT_NOFILE, &rl);
+    }
+  }
   RC().Parse(config_keys, config_values, num_config_items);
 }
 
