@@ -1,5 +1,5 @@
 # the arch5 sampler PROCESS alone (--decoupled: it fills the ring with nobody draining) over batch buffers x streams,
-# with the chain-first order: SAMGRAPH_SAMPLER_STREAMS / _SLOTS (default 3 streams, 6 buffers)
+# with the chain-first order: SAMGRAPH_SAMPLER_STREAMS / _SLOTS (default 3 streams, 9 buffers)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06aa
 for v in "3 6" "2 4" "2 6" "3 9" "4 8" "4 12" "6 12" "3 6"; do
