@@ -119,6 +119,55 @@ def test_full_size_determinism(world):
             assert torch.equal(b1.graph(l)[0], b2.graph(l)[0]) and torch.equal(b1.graph(l)[1], b2.graph(l)[1])
 
 
+def test_full_size_cached_extraction_invariants(world):
+    """BASELINE config 3's trainer side at its full size: 0.2 of papers100M's rows in an HBM cache (22.2 M rows, 11.4 GB),
+    every other row pulled out of a pinned HOST table by the same launch (2^24 rows, ids masked: SAMGRAPH_EMPTY_FEAT /
+    the reference's CPUMockExtract), three batches of [25, 10] x 8000.  Checked with what any correct run satisfies:
+    hit rows = the cache's rows = the feature table's rows, miss rows = the host table's rows of the masked ids, every
+    output row written exactly once (CombineMissData + CombineCacheData, cuda_cache_manager_device.cu:165-210), labels
+    of the seeds; and the one-launch path against the two gathers of the plain C ABI on the same lists."""
+    lib, w = world["lib"], world["w"]
+    dev = world["feat"].device
+    bits = 24
+    mask = (1 << bits) - 1
+    host = torch.empty((1 << bits, w["feat_dim"]), dtype=torch.float32).pin_memory()
+    host.copy_(world["feat"][:1 << bits])
+    tab = world["table"].long()
+    n_cached = int((tab >= 0).sum())
+    slot_node = torch.empty(n_cached, dtype=torch.int64, device=dev)
+    cached_nodes = torch.nonzero(tab >= 0).flatten()
+    slot_node[tab[cached_nodes]] = cached_nodes
+    cache_rows = torch.empty((n_cached, w["feat_dim"]), dtype=torch.float32, device=dev)
+    lib.gather_rows(cache_rows, world["feat"], src_index=slot_node.to(torch.int32))
+    del slot_node, cached_nodes
+    sampler = lib.Sampler(world["indptr"], world["indices"], w["fanout"], w["batch_size"], sample_type=lib.KHOP0, seed=11)
+    for b in range(3):
+        bt = sampler.new_batch(w["feat_dim"], lib.F32, lib.I64)
+        lib.load().fgnn_batch_set_feat_row_mask(bt.h, mask)
+        seeds = world["train"][b * 8000:(b + 1) * 8000]
+        bt.feat_buffer().fill_(float("nan"))  # a row nobody writes stays NaN
+        sampler.run_batch_cached(b, seeds, 100 + b, bt, world["table"], cache_rows, host, world["label"])
+        m = bt.wait()
+        assert m.overflow == 0
+        nodes = bt.input_nodes().long() & 0xFFFFFFFF
+        U = nodes.numel()
+        assert int(m.num_miss) + int(m.num_cache) == U and int(m.num_miss) > 0 and int(m.num_cache) > 0
+        hit = tab[nodes] >= 0
+        assert int(hit.sum()) == int(m.num_cache)
+        feat = bt.feat()
+        assert not bool(torch.isnan(feat).any())
+        want = torch.where(hit[:, None], world["feat"][nodes], world["feat"][nodes & mask])
+        assert torch.equal(feat, want)
+        assert torch.equal(bt.label(), world["label"][seeds.long()])
+        # the same lists through the two-call C ABI (fgnn_gather_rows_masked from the host table, fgnn_gather_rows
+        # from the cache) into a second buffer
+        ms, md, cs, cd = bt.cache_index_arrays()
+        two = torch.full_like(feat, float("nan"))
+        lib.gather_rows(two, host, src_index=ms, dst_index=md, src_row_mask=mask)
+        lib.gather_rows(two, cache_rows, src_index=cs, dst_index=cd)
+        assert torch.equal(two, feat)
+
+
 @pytest.mark.gpu
 def test_gather_larger_than_one_launch_is_sliced():
     from fgnn_hip import lib as hip
